@@ -1,0 +1,305 @@
+// api.hip -- extern "C" boundary of libproslam_hip.so (declared in include/proslam_hip.h).
+#include <stdlib.h>
+#include <string.h>
+
+#include "prs_host.h"
+
+namespace prs {
+
+int ctx_fail(prs_context* ctx, int status, const char* what) {
+  if (ctx) {
+    ctx->last_error = what ? what : "";
+  }
+  return status;
+}
+
+int ctx_fail_hip(prs_context* ctx, hipError_t e, const char* what) {
+  if (ctx) {
+    ctx->last_error = std::string(what ? what : "") + ": " + hipGetErrorString(e);
+  }
+  return PRS_ERR_HIP;
+}
+
+void* ctx_device_scratch(prs_context* ctx, size_t bytes) {
+  if (bytes <= ctx->d_scratch_size) {
+    return ctx->d_scratch;
+  }
+  if (ctx->d_scratch) {
+    (void) hipStreamSynchronize(ctx->stream);
+    (void) hipFree(ctx->d_scratch);
+    ctx->d_scratch      = nullptr;
+    ctx->d_scratch_size = 0;
+  }
+  size_t want = bytes + bytes / 2 + 4096;
+  if (hipMalloc(&ctx->d_scratch, want) != hipSuccess) {
+    ctx->d_scratch = nullptr;
+    return nullptr;
+  }
+  ctx->d_scratch_size = want;
+  return ctx->d_scratch;
+}
+
+void* ctx_pinned_scratch(prs_context* ctx, size_t bytes) {
+  if (bytes <= ctx->h_pinned_size) {
+    return ctx->h_pinned;
+  }
+  if (ctx->h_pinned) {
+    (void) hipStreamSynchronize(ctx->stream);
+    (void) hipHostFree(ctx->h_pinned);
+    ctx->h_pinned      = nullptr;
+    ctx->h_pinned_size = 0;
+  }
+  size_t want = bytes + bytes / 2 + 4096;
+  if (hipHostMalloc(&ctx->h_pinned, want, hipHostMallocDefault) != hipSuccess) {
+    ctx->h_pinned = nullptr;
+    return nullptr;
+  }
+  ctx->h_pinned_size = want;
+  return ctx->h_pinned;
+}
+
+static inline size_t align256(size_t v) {
+  return (v + 255) / 256 * 256;
+}
+
+} // namespace prs
+
+using namespace prs;
+
+extern "C" {
+
+int prs_version(void) {
+  return 100;  // 0.1.0
+}
+
+const char* prs_status_string(int status) {
+  switch (status) {
+    case PRS_OK: return "ok";
+    case PRS_ERR_NULL: return "required input/output buffer not set";
+    case PRS_ERR_CAPACITY: return "output capacity too small";
+    case PRS_ERR_HIP: return "HIP runtime error";
+    case PRS_ERR_RANGE: return "input outside the supported coordinate domain";
+    case PRS_ERR_UNSUPPORTED: return "size beyond kernel limits";
+    case PRS_ERR_NO_DEVICE: return "no HIP device";
+    default: return status > 0 ? "warning bits set" : "unknown error";
+  }
+}
+
+int prs_context_create(int device_id, prs_context** out) {
+  if (!out) {
+    return PRS_ERR_NULL;
+  }
+  *out      = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    return PRS_ERR_NO_DEVICE;  // loud: there is no CPU fallback behind this library
+  }
+  if (device_id < 0 || device_id >= count) {
+    return PRS_ERR_NO_DEVICE;
+  }
+  if (hipSetDevice(device_id) != hipSuccess) {
+    return PRS_ERR_HIP;
+  }
+  prs_context* ctx = new prs_context();
+  ctx->device      = device_id;
+  if (hipStreamCreateWithFlags(&ctx->own, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return PRS_ERR_HIP;
+  }
+  ctx->stream          = ctx->own;
+  const char* unstaged = getenv("PRS_FORCE_UNSTAGED");
+  ctx->force_unstaged  = unstaged && unstaged[0] == '1';
+  *out                 = ctx;
+  return PRS_OK;
+}
+
+int prs_context_destroy(prs_context* ctx) {
+  if (!ctx) {
+    return PRS_OK;
+  }
+  (void) hipSetDevice(ctx->device);
+  (void) hipStreamSynchronize(ctx->stream);
+  if (ctx->d_scratch) {
+    (void) hipFree(ctx->d_scratch);
+  }
+  if (ctx->h_pinned) {
+    (void) hipHostFree(ctx->h_pinned);
+  }
+  if (ctx->own) {
+    (void) hipStreamDestroy(ctx->own);
+  }
+  delete ctx;
+  return PRS_OK;
+}
+
+int prs_context_set_stream(prs_context* ctx, void* hip_stream) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own;
+  return PRS_OK;
+}
+
+int prs_context_synchronize(prs_context* ctx) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  return e == hipSuccess ? PRS_OK : ctx_fail_hip(ctx, e, "hipStreamSynchronize");
+}
+
+const char* prs_last_error(const prs_context* ctx) {
+  return ctx ? ctx->last_error.c_str() : "null context";
+}
+
+int prs_stereo_match_batch(prs_context* ctx, const prs_stereo_params* params, const prs_stereo_batch* batch) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  (void) hipSetDevice(ctx->device);
+  return stereo_match_batch_launch(ctx, params, batch);
+}
+
+int prs_stereo_match(prs_context* ctx,
+                     const prs_stereo_params* params,
+                     const prs_kp2* left,
+                     const uint8_t* desc_left,
+                     int32_t n_left,
+                     const prs_kp2* right,
+                     const uint8_t* desc_right,
+                     int32_t n_right,
+                     prs_corr* out,
+                     int32_t capacity,
+                     int32_t* n_out) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  // _preCompute contract (CF/..bruteforce_impl.cpp:203-216): unset buffers are hard errors
+  if (!params || !out || !n_out || n_left < 0 || n_right < 0 || (n_left > 0 && (!left || !desc_left)) ||
+      (n_right > 0 && (!right || !desc_right))) {
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_stereo_match: fixed, moving or correspondences not set");
+  }
+  if (capacity < n_left) {
+    return ctx_fail(ctx, PRS_ERR_CAPACITY, "prs_stereo_match: capacity < n_left");
+  }
+  (void) hipSetDevice(ctx->device);
+  *n_out           = 0;
+  const int stride = n_left > n_right ? (n_left > 0 ? n_left : 1) : (n_right > 0 ? n_right : 1);
+  // device scratch layout
+  const size_t sz_kp   = align256(sizeof(prs_kp2) * (size_t) stride);
+  const size_t sz_desc = align256((size_t) PRS_DESC_BYTES * (size_t) stride);
+  const size_t sz_corr = align256(sizeof(prs_corr) * (size_t) stride);
+  const size_t total   = 2 * sz_kp + 2 * sz_desc + sz_corr + 256;
+  unsigned char* d     = static_cast<unsigned char*>(ctx_device_scratch(ctx, total));
+  if (!d) {
+    return ctx_fail(ctx, PRS_ERR_HIP, "prs_stereo_match: device scratch allocation failed");
+  }
+  prs_kp2* d_kpl  = reinterpret_cast<prs_kp2*>(d);
+  prs_kp2* d_kpr  = reinterpret_cast<prs_kp2*>(d + sz_kp);
+  uint8_t* d_dl   = d + 2 * sz_kp;
+  uint8_t* d_dr   = d + 2 * sz_kp + sz_desc;
+  prs_corr* d_out = reinterpret_cast<prs_corr*>(d + 2 * sz_kp + 2 * sz_desc);
+  int32_t* d_meta = reinterpret_cast<int32_t*>(d + 2 * sz_kp + 2 * sz_desc + sz_corr);  // n_left, n_right, n_matches, status
+  hipStream_t s   = ctx->stream;
+  hipError_t e    = hipSuccess;
+  int32_t meta[4] = {n_left, n_right, 0, 0};
+#define PRS_TRY(x)                                  \
+  do {                                              \
+    e = (x);                                        \
+    if (e != hipSuccess) {                          \
+      return ctx_fail_hip(ctx, e, "prs_stereo_match"); \
+    }                                               \
+  } while (0)
+  if (n_left > 0) {
+    PRS_TRY(hipMemcpyAsync(d_kpl, left, sizeof(prs_kp2) * (size_t) n_left, hipMemcpyHostToDevice, s));
+    PRS_TRY(hipMemcpyAsync(d_dl, desc_left, (size_t) PRS_DESC_BYTES * (size_t) n_left, hipMemcpyHostToDevice, s));
+  }
+  if (n_right > 0) {
+    PRS_TRY(hipMemcpyAsync(d_kpr, right, sizeof(prs_kp2) * (size_t) n_right, hipMemcpyHostToDevice, s));
+    PRS_TRY(hipMemcpyAsync(d_dr, desc_right, (size_t) PRS_DESC_BYTES * (size_t) n_right, hipMemcpyHostToDevice, s));
+  }
+  PRS_TRY(hipMemcpyAsync(d_meta, meta, sizeof(meta), hipMemcpyHostToDevice, s));
+  prs_stereo_batch b;
+  memset(&b, 0, sizeof(b));
+  b.batch      = 1;
+  b.stride     = stride;
+  b.left_kp    = d_kpl;
+  b.left_desc  = d_dl;
+  b.n_left     = d_meta + 0;
+  b.right_kp   = d_kpr;
+  b.right_desc = d_dr;
+  b.n_right    = d_meta + 1;
+  b.matches    = d_out;
+  b.n_matches  = d_meta + 2;
+  b.status     = d_meta + 3;
+  const int rc = stereo_match_batch_launch(ctx, params, &b);
+  if (rc != PRS_OK) {
+    return rc;
+  }
+  PRS_TRY(hipMemcpyAsync(meta, d_meta, sizeof(meta), hipMemcpyDeviceToHost, s));
+  PRS_TRY(hipStreamSynchronize(s));
+  if (meta[3] < 0) {
+    return ctx_fail(ctx, meta[3], "prs_stereo_match: keypoint outside the supported domain (0<=u<32768, 0<=v<image_rows)");
+  }
+  if (meta[2] > 0) {
+    PRS_TRY(hipMemcpy(out, d_out, sizeof(prs_corr) * (size_t) meta[2], hipMemcpyDeviceToHost));
+  }
+#undef PRS_TRY
+  *n_out = meta[2];
+  return meta[3];
+}
+
+int prs_triangulate_dev(prs_context* ctx, const prs_triangulator_params* params, const float* d_uvuv, int64_t n, float* d_xyz4) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  (void) hipSetDevice(ctx->device);
+  return triangulate_launch(ctx, params, d_uvuv, n, d_xyz4);
+}
+
+int prs_triangulate(prs_context* ctx, const prs_triangulator_params* params, const float* uvuv, int32_t n, float* xyz, uint8_t* valid) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  // triangulator_rigid_stereo.cpp:9-16: unset buffers are reported, nothing is computed
+  if (!params || n < 0 || (n > 0 && (!uvuv || !xyz || !valid))) {
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_triangulate: input or result buffer not set");
+  }
+  if (n == 0) {
+    return PRS_WARN_EMPTY_INPUT;
+  }
+  (void) hipSetDevice(ctx->device);
+  const size_t bytes = sizeof(float) * 4 * (size_t) n;
+  unsigned char* d   = static_cast<unsigned char*>(ctx_device_scratch(ctx, 2 * align256(bytes)));
+  float* h           = static_cast<float*>(ctx_pinned_scratch(ctx, bytes));
+  if (!d || !h) {
+    return ctx_fail(ctx, PRS_ERR_HIP, "prs_triangulate: scratch allocation failed");
+  }
+  float* d_in   = reinterpret_cast<float*>(d);
+  float* d_out  = reinterpret_cast<float*>(d + align256(bytes));
+  hipStream_t s = ctx->stream;
+  hipError_t e  = hipMemcpyAsync(d_in, uvuv, bytes, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_triangulate upload");
+  }
+  const int rc = triangulate_launch(ctx, params, d_in, n, d_out);
+  if (rc != PRS_OK) {
+    return rc;
+  }
+  e = hipMemcpyAsync(h, d_out, bytes, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) {
+    e = hipStreamSynchronize(s);
+  }
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_triangulate download");
+  }
+  for (int32_t i = 0; i < n; ++i) {
+    xyz[3 * i + 0] = h[4 * i + 0];
+    xyz[3 * i + 1] = h[4 * i + 1];
+    xyz[3 * i + 2] = h[4 * i + 2];
+    valid[i]       = h[4 * i + 3] != 0.0f ? 1 : 0;
+  }
+  return PRS_OK;
+}
+
+}  // extern "C"

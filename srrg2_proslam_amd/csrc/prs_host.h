@@ -1,0 +1,41 @@
+// prs_host.h -- host-side context shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/proslam_hip.h"
+
+struct prs_context {
+  int device            = 0;
+  hipStream_t stream    = nullptr;  // stream work is enqueued on
+  hipStream_t own       = nullptr;  // stream created (and destroyed) by the context
+  std::string last_error;
+  bool force_unstaged   = false;    // test hook: PRS_FORCE_UNSTAGED=1 selects the no-LDS-staging variant
+  // reusable device scratch for the host-pointer entry points
+  void* d_scratch       = nullptr;
+  size_t d_scratch_size = 0;
+  void* h_pinned        = nullptr;
+  size_t h_pinned_size  = 0;
+};
+
+namespace prs {
+
+int ctx_fail(prs_context* ctx, int status, const char* what);
+int ctx_fail_hip(prs_context* ctx, hipError_t e, const char* what);
+inline hipStream_t ctx_stream(prs_context* ctx) {
+  return ctx->stream;
+}
+inline bool ctx_force_unstaged(const prs_context* ctx) {
+  return ctx->force_unstaged;
+}
+// grows (never shrinks) the context's device scratch; returns nullptr on failure
+void* ctx_device_scratch(prs_context* ctx, size_t bytes);
+void* ctx_pinned_scratch(prs_context* ctx, size_t bytes);
+
+int stereo_match_batch_launch(prs_context* ctx, const prs_stereo_params* params, const prs_stereo_batch* batch);
+int triangulate_launch(prs_context* ctx, const prs_triangulator_params* params, const float* d_uvuv, int64_t n, float* d_xyz4);
+
+} // namespace prs
