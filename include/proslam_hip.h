@@ -72,8 +72,10 @@ typedef struct {
 typedef struct prs_context prs_context;
 PRS_API int prs_context_create(int device_id, prs_context** ctx);
 PRS_API int prs_context_destroy(prs_context* ctx);
-/* enqueue on a caller-owned hipStream_t (e.g. torch's current stream); NULL = context's own */
+/* enqueue on a caller-owned hipStream_t (e.g. torch's current stream); NULL = HIP's default stream */
 PRS_API int prs_context_set_stream(prs_context* ctx, void* hip_stream);
+/* go back to the non-blocking stream the context created for itself (the initial state) */
+PRS_API int prs_context_use_own_stream(prs_context* ctx);
 PRS_API int prs_context_synchronize(prs_context* ctx);
 PRS_API const char* prs_last_error(const prs_context* ctx);
 PRS_API const char* prs_status_string(int status);

@@ -82,6 +82,7 @@ SYMBOLS = {
     "prs_context_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "prs_context_destroy": (C.c_int, [_vp]),
     "prs_context_set_stream": (C.c_int, [_vp, _vp]),
+    "prs_context_use_own_stream": (C.c_int, [_vp]),
     "prs_context_synchronize": (C.c_int, [_vp]),
     "prs_last_error": (C.c_char_p, [_vp]),
     "prs_stereo_match": (C.c_int, [_vp, C.POINTER(StereoParams), _vp, _vp, C.c_int32, _vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
@@ -110,6 +111,14 @@ def load():
         raise ImportError(
             "libproslam_hip.so is not built (%s). The HIP extension is mandatory: run "
             "`python -c 'import __graft_entry__ as g; g.build()'` -- there is no CPU fallback." % LIB_PATH)
+    # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Import it FIRST so the
+    # dynamic loader resolves our DT_NEEDED against the runtime torch already mapped: one HIP
+    # runtime per process, so torch tensors / streams and this library agree.  Two runtime
+    # copies in one process fail HSA initialisation for the second one.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

@@ -1,6 +1,9 @@
 // api.hip -- extern "C" boundary of libproslam_hip.so (declared in include/proslam_hip.h).
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include <vector>
 
 #include "prs_host.h"
 
@@ -58,6 +61,41 @@ void* ctx_pinned_scratch(prs_context* ctx, size_t bytes) {
   return ctx->h_pinned;
 }
 
+unsigned long long* ctx_stamps(prs_context* ctx, size_t bytes) {
+  if (!ctx->stamps_enabled) {
+    return nullptr;
+  }
+  if (bytes > ctx->d_stamps_size) {
+    if (ctx->d_stamps) {
+      (void) hipFree(ctx->d_stamps);
+    }
+    if (hipMalloc(reinterpret_cast<void**>(&ctx->d_stamps), bytes) != hipSuccess) {
+      ctx->d_stamps      = nullptr;
+      ctx->d_stamps_size = 0;
+      return nullptr;
+    }
+    ctx->d_stamps_size = bytes;
+  }
+  return ctx->d_stamps;
+}
+
+void ctx_report_stamps(prs_context* ctx, int blocks, int n_stamps, const char* legend) {
+  (void) hipStreamSynchronize(ctx->stream);
+  std::vector<unsigned long long> h((size_t) blocks * 16);
+  (void) hipMemcpy(h.data(), ctx->d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  fprintf(stderr, "[prs stamps] %s\n[prs stamps] mean cycles per phase over %d blocks:", legend, blocks);
+  double total = 0;
+  for (int i = 1; i < n_stamps; ++i) {
+    double acc = 0;
+    for (int b = 0; b < blocks; ++b) {
+      acc += (double) (h[(size_t) b * 16 + i] - h[(size_t) b * 16 + i - 1]);
+    }
+    fprintf(stderr, " %.0f", acc / blocks);
+    total += acc / blocks;
+  }
+  fprintf(stderr, " | total %.0f\n", total);
+}
+
 static inline size_t align256(size_t v) {
   return (v + 255) / 256 * 256;
 }
@@ -109,6 +147,8 @@ int prs_context_create(int device_id, prs_context** out) {
   ctx->stream          = ctx->own;
   const char* unstaged = getenv("PRS_FORCE_UNSTAGED");
   ctx->force_unstaged  = unstaged && unstaged[0] == '1';
+  const char* stamps   = getenv("PRS_STAMPS");
+  ctx->stamps_enabled  = stamps && stamps[0] == '1';
   *out                 = ctx;
   return PRS_OK;
 }
@@ -125,6 +165,9 @@ int prs_context_destroy(prs_context* ctx) {
   if (ctx->h_pinned) {
     (void) hipHostFree(ctx->h_pinned);
   }
+  if (ctx->d_stamps) {
+    (void) hipFree(ctx->d_stamps);
+  }
   if (ctx->own) {
     (void) hipStreamDestroy(ctx->own);
   }
@@ -136,7 +179,15 @@ int prs_context_set_stream(prs_context* ctx, void* hip_stream) {
   if (!ctx) {
     return PRS_ERR_NULL;
   }
-  ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own;
+  ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = HIP's default (null) stream
+  return PRS_OK;
+}
+
+int prs_context_use_own_stream(prs_context* ctx) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  ctx->stream = ctx->own;
   return PRS_OK;
 }
 

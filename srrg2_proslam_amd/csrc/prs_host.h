@@ -19,6 +19,10 @@ struct prs_context {
   size_t d_scratch_size = 0;
   void* h_pinned        = nullptr;
   size_t h_pinned_size  = 0;
+  // diagnostic phase stamps (PRS_STAMPS=1): never enabled in timed runs
+  bool stamps_enabled   = false;
+  unsigned long long* d_stamps = nullptr;
+  size_t d_stamps_size  = 0;
 };
 
 namespace prs {
@@ -34,6 +38,10 @@ inline bool ctx_force_unstaged(const prs_context* ctx) {
 // grows (never shrinks) the context's device scratch; returns nullptr on failure
 void* ctx_device_scratch(prs_context* ctx, size_t bytes);
 void* ctx_pinned_scratch(prs_context* ctx, size_t bytes);
+// diagnostic: device buffer for phase stamps when PRS_STAMPS=1, else nullptr
+unsigned long long* ctx_stamps(prs_context* ctx, size_t bytes);
+// synchronises and prints mean per-phase cycle counts (n_stamps consecutive stamps per block)
+void ctx_report_stamps(prs_context* ctx, int blocks, int n_stamps, const char* legend);
 
 int stereo_match_batch_launch(prs_context* ctx, const prs_stereo_params* params, const prs_stereo_batch* batch);
 int triangulate_launch(prs_context* ctx, const prs_triangulator_params* params, const float* d_uvuv, int64_t n, float* d_xyz4);

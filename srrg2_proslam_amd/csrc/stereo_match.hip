@@ -31,11 +31,19 @@ struct StereoArgs {
   int sort_cap;  // entries in each sorted/bucket array (>= stride, >= image_rows + 1)
   uint32_t off_desc_l, off_desc_r, off_sorted_l, off_sorted_r, off_bucket_l, off_bucket_r;
   uint32_t off_rowstart_l, off_rowstart_r, off_scratch;
+  unsigned long long* stamps;  // diagnostic: [batch][16] shader-clock stamps of thread 0 (NULL = off)
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kStereoThreads = 1024;
 constexpr float kFloatMax    = 3.402823466e+38f;
+
+#define PRS_STAMP(i)                                              \
+  do {                                                            \
+    if (a.stamps && tid == 0) {                                   \
+      a.stamps[(size_t) frame * 16 + (i)] = (unsigned long long) clock64(); \
+    }                                                             \
+  } while (0)
 
 template <int KPT, bool STAGE>
 __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const StereoArgs a) {
@@ -70,6 +78,7 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
   uint8_t* matchedL  = reinterpret_cast<uint8_t*>(bucketR);  // pass number + 1, 0 = unmatched
   uint8_t* matchedR  = matchedL + a.sort_cap;
 
+  PRS_STAMP(0);
   // ---- issue every global read of this frame up front ----------------------------------------
   prs_kp2 cL[KPT], cR[KPT];
 #pragma unroll
@@ -102,6 +111,7 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
   }
   __syncthreads();
 
+  PRS_STAMP(1);
   int rowL[KPT], rowR[KPT];
   uint32_t keyL[KPT], keyR[KPT], slotL[KPT], slotR[KPT];
   bool bad = false;
@@ -146,6 +156,7 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
     return;
   }
 
+  PRS_STAMP(2);
   // exclusive scan of both histograms at once (left in the low, right in the high word)
   {
     const int ipt   = (rows + 1 + kStereoThreads - 1) / kStereoThreads;
@@ -171,6 +182,7 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
   }
   __syncthreads();
 
+  PRS_STAMP(3);
   // scatter into row buckets (arbitrary order inside a row) ...
 #pragma unroll
   for (int k = 0; k < KPT; ++k) {
@@ -202,6 +214,7 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
       sortedR[s + rank] = keyR[k];
     }
   }
+  PRS_STAMP(4);
   // descriptor rows land in LDS (the loads were issued before the sort)
   if (STAGE) {
 #pragma unroll
@@ -224,6 +237,7 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
   }
   __syncthreads();
 
+  PRS_STAMP(5);
   // ---- a2: per-offset epipolar scan ----------------------------------------------------------
   const float max_dist  = a.p.maximum_descriptor_distance;
   const float max_ratio = a.p.maximum_distance_ratio_to_second_best;
@@ -244,6 +258,7 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
       const int ls = rsL[r], le = rsL[r + 1];
       int c        = rsR[rr];
       const int re = rsR[rr + 1];
+      int lo       = c;  // right features before lo are further than max_disp left of every remaining left feature
       for (int p = ls; p < le && c < re; ++p) {
         if (matchedL[p]) {
           continue;  // pruned by an earlier pass (epipolar_impl.cpp:188-196)
@@ -259,9 +274,15 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
           d0 = gdL[2 * idx_l];
           d1 = gdL[2 * idx_l + 1];
         }
+        // columns are non-decreasing along the row, so candidates skipped for exceeding the
+        // disparity range (epipolar_impl.cpp:146-149) stay skipped for all later left features:
+        // remember where the in-range window starts instead of rescanning from the cursor
+        while (lo < re && col_l - (int) (sortedR[lo] >> 16) > max_disp) {
+          ++lo;
+        }
         float best = kFloatMax, second = kFloatMax;
         int best_q = -1;
-        for (int q = c; q < re; ++q) {
+        for (int q = c > lo ? c : lo; q < re; ++q) {
           if (matchedR[q]) {
             continue;  // pruned (epipolar_impl.cpp:197-205)
           }
@@ -300,6 +321,7 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
       }
     }
     __syncthreads();
+    PRS_STAMP(6);
 
     // compaction in sorted-left traversal order (+ optional adaptor/triangulator epilogue)
     uint32_t m_rec[KPT];
@@ -373,6 +395,7 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
     fixed_base += (int) (total >> 32);
   }
 
+  PRS_STAMP(7);
   if (tid == 0) {
     int flags = PRS_OK;
     if (nL == 0 || nR == 0) {
@@ -455,6 +478,7 @@ int stereo_match_batch_launch(prs_context* ctx, const prs_stereo_params* params,
   } else {
     a.tri = prs_triangulator_params{1.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   }
+  a.stamps = ctx_stamps(ctx, (size_t) batch->batch * 16 * sizeof(unsigned long long));
   const int kpt        = stride <= 1024 ? 1 : (stride <= 2048 ? 2 : (stride <= 4096 ? 4 : 8));
   const uint32_t rows1 = (uint32_t) params->image_rows + 1;
   a.sort_cap           = (int) (((uint32_t) stride > rows1 ? (uint32_t) stride : rows1));
@@ -501,6 +525,9 @@ int stereo_match_batch_launch(prs_context* ctx, const prs_stereo_params* params,
   }
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_stereo_match_batch launch");
+  }
+  if (a.stamps) {
+    ctx_report_stamps(ctx, batch->batch, 8, "stereo_match: issue-loads | zero+barrier | coords+hist | scan | scatter+rank | stage-write+init | chain | compaction");
   }
   return PRS_OK;
 }
