@@ -2,7 +2,8 @@
 import sys, time
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from srrg2_proslam_amd import configs, ops, synthetic as syn
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
