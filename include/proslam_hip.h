@@ -169,6 +169,167 @@ PRS_API int prs_triangulate_dev(prs_context* ctx,
                                 int64_t n,
                                 float* d_xyz4);
 
+/* ================================================================================================
+ * Projective correspondence finder + reprojection-error Gauss-Newton aligner
+ * replaces CorrespondenceFinderProjectiveBase<..>::compute and its Square / Circle / Rhombus /
+ * KDTree search patterns (CF/correspondence_finder_projective_base_impl.cpp:105-293,
+ * CF/..square_impl.cpp:8-118, CF/..circle_impl.cpp:8-94, CF/..rhombus_impl.cpp:8-93,
+ * CF/..kdtree_impl.cpp:8-80), AlignerSliceProcessorProjective{,Depth,Stereo}::setupFactor
+ * (registration/aligner_slice_processor_projective.cpp:28-112) and the external arithmetic those
+ * configure (srrg2_solver SE3*ProjectiveErrorFactor::errorAndJacobian, RobustifierSaturated,
+ * H/b accumulation, damped GN step, MultiAligner3DQR iteration loop).
+ * ============================================================================================== */
+enum { PRS_SEARCH_KDTREE = 0, PRS_SEARCH_SQUARE = 1, PRS_SEARCH_CIRCLE = 2, PRS_SEARCH_RHOMBUS = 3 };
+enum { PRS_FACTOR_MONO = 2, PRS_FACTOR_DEPTH = 3, PRS_FACTOR_STEREO = 4 }; /* = fixed dimension */
+
+/* PointProjectorPinhole_ parameters reached through param_projector (CF/..projective_base.h:55-59) */
+typedef struct {
+  float fx, fy, cx, cy;
+  int32_t canvas_cols, canvas_rows;
+  float range_min, range_max;
+} prs_projector;
+
+typedef struct {
+  float maximum_descriptor_distance;           /* CF/..bruteforce.h:22-26 */
+  float maximum_distance_ratio_to_second_best; /* CF/..bruteforce.h:27-31 */
+  float minimum_matching_ratio;                /* CF/..bruteforce.h:32-36 */
+  float minimum_descriptor_distance;           /* CF/..projective_base.h:30-34 */
+  float descriptor_distance_step_size_pixels;  /* :35-39 */
+  uint64_t maximum_search_radius_pixels;       /* :40-44 */
+  uint64_t minimum_search_radius_pixels;       /* :45-49 */
+  uint64_t search_radius_step_size_pixels;     /* :50-54 */
+  uint64_t minimum_number_of_iterations;       /* :60-64 */
+  float maximum_estimate_change_norm_for_convergence; /* :65-69 */
+  uint64_t number_of_solver_iterations_per_projection; /* :70-74 */
+  int32_t search_type;                         /* which subclass: PRS_SEARCH_* */
+  prs_projector projector;
+} prs_pcf_params;
+
+/* the finder members that live across calls and frames (CF/..projective_base.h:132-154).  POD so
+ * it can sit in device memory for the batched path; zero-initialise, then set config_changed = 1. */
+typedef struct {
+  uint64_t search_radius_pixels;
+  uint64_t current_iteration;
+  float descriptor_distance;
+  int32_t has_converged;
+  int32_t config_changed;
+  int32_t num_recomputes; /* bookkeeping only: number of full searches so far */
+  float local_map_in_sensor[16];
+  float local_map_in_sensor_previous[16];
+} prs_pcf_state;
+
+typedef struct {
+  int32_t factor_type;                    /* PRS_FACTOR_*: which error factor / fixed dimension */
+  float fx, fy, cx, cy;                   /* factor->setCameraMatrix (aligner_slice_processor_projective.cpp:36-37) */
+  float image_cols, image_rows;           /* factor->setImageDim (:38-39) */
+  float baseline_left_in_right_px[3];     /* K * t_left_in_right (:98-104), stereo only */
+  float diagonal_info[3];                 /* param_diagonal_info_matrix (:47) */
+  float chi_threshold;                    /* RobustifierSaturated chi_threshold */
+  int32_t enable_inverse_depth_weighting; /* :107-112 */
+  float mean_disparity;                   /* bindFixed (:76-89); < 0 = compute it on the device */
+  float damping;                          /* IterationAlgorithmGN damping */
+  int32_t max_iterations;                 /* MultiAligner3DQR max_iterations */
+  int32_t min_num_inliers;
+  int32_t min_num_correspondences;
+  int32_t stop_at_fixed_point;            /* 1: leave the loop once the finder has converged and a GN
+                                             step reproduces the estimate bit-for-bit (every remaining
+                                             iteration would repeat it exactly); 0: always run all */
+} prs_aligner_params;
+
+typedef struct {
+  float H[36];          /* last linearisation, row-major, without prior */
+  float b[6];           /* sum J^T Omega e */
+  float chi_inliers;
+  float chi_total;
+  float mean_disparity; /* value used by the factor */
+  int32_t num_inliers;
+  int32_t num_outliers;
+  int32_t num_invalid;
+  int32_t num_correspondences;
+  int32_t status;       /* 1 Success, 0 Fail (tests/test_aligners.cpp:117-121) */
+  int32_t iterations;   /* aligner iterations accounted for (= max_iterations in align mode) */
+  int32_t iterations_executed; /* < iterations when stop_at_fixed_point cut the loop */
+  int32_t warnings;     /* OR of PRS_WARN_* over the call, or a PRS_ERR_* code */
+} prs_align_result;
+
+enum {
+  PRS_MODE_ALIGN     = 0, /* per iteration: finder.compute(); setupFactor; linearize; GN step */
+  PRS_MODE_FINDER    = 1, /* ONE CorrespondenceFinderProjective::compute() with local_map_in_sensor = X */
+  PRS_MODE_LINEARIZE = 2  /* ONE linearisation at X of the correspondences passed in */
+};
+
+/* device-resident batch of B independent frames (one per sequence).
+ * fixed:  [batch][fixed_stride][4] floats: (u,v,-,-) mono, (u,v,d,-) depth, (uL,vL,uR,vR) stereo
+ * moving: [batch][moving_stride][4] floats: (x,y,z, information scale of the point:
+ *         1 + log(numberOfOptimizations) if > 2 else 1, aligner_slice_processor_projective.cpp:46-52) */
+typedef struct {
+  int32_t batch;
+  int32_t fixed_stride;
+  int32_t moving_stride;
+  const float* fixed;
+  const uint8_t* fixed_desc;     /* [batch][fixed_stride][32] */
+  const int32_t* n_fixed;        /* [batch] */
+  const float* moving;
+  const uint8_t* moving_desc;    /* [batch][moving_stride][32] */
+  const int32_t* n_moving;       /* [batch] */
+  const uint8_t* inputs_changed; /* [batch] setFixed/setMoving since the last call; NULL = all changed */
+  prs_pcf_state* state;          /* [batch] in/out */
+  float* X;                      /* [batch][16] in: movingInFixed guess, out: estimate (row-major 4x4) */
+  prs_corr* corr;                /* [batch][fixed_stride] in/out: the caller-owned CorrespondenceVector */
+  int32_t* n_corr;               /* [batch] in/out */
+  prs_align_result* result;      /* [batch] */
+  const float* prior;            /* optional [batch][42]: additive H0 (36) and b0 (6) (motion-model slice) */
+} prs_align_batch;
+
+PRS_API int prs_align_batch_run(prs_context* ctx,
+                                const prs_pcf_params* finder,
+                                const prs_aligner_params* aligner,
+                                const prs_align_batch* batch,
+                                int32_t mode);
+
+/* ---- host, one frame: stateful finder handle mirroring the reference object -------------------
+ * setFixed / setMoving / setLocalMapInSensor / compute (tests/test_correspondence_finders.cpp:314,
+ * tests/test_aligners.cpp:658-666) */
+typedef struct prs_pcf prs_pcf;
+PRS_API int prs_pcf_create(prs_context* ctx, const prs_pcf_params* params, prs_pcf** out);
+PRS_API int prs_pcf_destroy(prs_pcf* h);
+PRS_API int prs_pcf_set_params(prs_pcf* h, const prs_pcf_params* params); /* flags a config change */
+/* coords: [n][fixed_dim] floats */
+PRS_API int prs_pcf_set_fixed(prs_pcf* h, const float* coords, int32_t fixed_dim, const uint8_t* desc, int32_t n);
+/* xyz [n][3]; info_scale [n] or NULL (= 1) */
+PRS_API int prs_pcf_set_moving(prs_pcf* h, const float* xyz, const float* info_scale, const uint8_t* desc, int32_t n);
+PRS_API int prs_pcf_set_local_map_in_sensor(prs_pcf* h, const float* T16);
+PRS_API int prs_pcf_set_search_radius(prs_pcf* h, uint64_t radius_pixels);      /* CF/..projective_base.h:82-85 */
+PRS_API int prs_pcf_set_descriptor_distance(prs_pcf* h, float distance);        /* CF/..projective_base.h:94-97 */
+PRS_API int prs_pcf_get_state(prs_pcf* h, prs_pcf_state* out);
+/* out capacity >= n_fixed; untouched calls ("nothing new", converged) return the previous vector */
+PRS_API int prs_pcf_compute(prs_pcf* h, prs_corr* out, int32_t capacity, int32_t* n_out);
+/* the full per-frame loop on the handle's fixed/moving clouds (MultiAligner3DQR::compute stand-in) */
+PRS_API int prs_pcf_align(prs_pcf* h,
+                          const prs_aligner_params* aligner,
+                          const float* X_init16,
+                          const float* prior42, /* optional */
+                          float* X_out16,
+                          prs_corr* corr_out,
+                          int32_t capacity,
+                          int32_t* n_corr_out,
+                          prs_align_result* result);
+/* one linearisation of given correspondences on the handle's clouds (factor-level use,
+ * tests/test_aligners.cpp:586-638) */
+PRS_API int prs_pcf_linearize(prs_pcf* h,
+                              const prs_aligner_params* aligner,
+                              const float* X16,
+                              const prs_corr* corr,
+                              int32_t n_corr,
+                              prs_align_result* result);
+
+/* (H + damping I) dx = -b, X <- X * exp(dx) on the device (same arithmetic as the fused loop) */
+PRS_API int prs_gn_step(prs_context* ctx, const float* H36, const float* b6, float damping, float* X16);
+
+/* host helper: information scale column from landmark ages
+ * (aligner_slice_processor_projective.cpp:46-52: n > 2 ? 1 + log(n) : 1) */
+PRS_API void prs_info_scale_from_nopt(const uint32_t* n_opt, int32_t n, float* scale);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,96 @@ class StereoBatch(C.Structure):
     ]
 
 
+class Projector(C.Structure):
+    """prs_projector"""
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("canvas_cols", C.c_int32), ("canvas_rows", C.c_int32), ("range_min", C.c_float), ("range_max", C.c_float)]
+
+
+class PcfParams(C.Structure):
+    """prs_pcf_params"""
+    _fields_ = [
+        ("maximum_descriptor_distance", C.c_float),
+        ("maximum_distance_ratio_to_second_best", C.c_float),
+        ("minimum_matching_ratio", C.c_float),
+        ("minimum_descriptor_distance", C.c_float),
+        ("descriptor_distance_step_size_pixels", C.c_float),
+        ("maximum_search_radius_pixels", C.c_uint64),
+        ("minimum_search_radius_pixels", C.c_uint64),
+        ("search_radius_step_size_pixels", C.c_uint64),
+        ("minimum_number_of_iterations", C.c_uint64),
+        ("maximum_estimate_change_norm_for_convergence", C.c_float),
+        ("number_of_solver_iterations_per_projection", C.c_uint64),
+        ("search_type", C.c_int32),
+        ("projector", Projector),
+    ]
+
+
+class PcfState(C.Structure):
+    """prs_pcf_state"""
+    _fields_ = [
+        ("search_radius_pixels", C.c_uint64),
+        ("current_iteration", C.c_uint64),
+        ("descriptor_distance", C.c_float),
+        ("has_converged", C.c_int32),
+        ("config_changed", C.c_int32),
+        ("num_recomputes", C.c_int32),
+        ("local_map_in_sensor", C.c_float * 16),
+        ("local_map_in_sensor_previous", C.c_float * 16),
+    ]
+
+
+class AlignerParams(C.Structure):
+    """prs_aligner_params"""
+    _fields_ = [
+        ("factor_type", C.c_int32),
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("image_cols", C.c_float), ("image_rows", C.c_float),
+        ("baseline_left_in_right_px", C.c_float * 3),
+        ("diagonal_info", C.c_float * 3),
+        ("chi_threshold", C.c_float),
+        ("enable_inverse_depth_weighting", C.c_int32),
+        ("mean_disparity", C.c_float),
+        ("damping", C.c_float),
+        ("max_iterations", C.c_int32),
+        ("min_num_inliers", C.c_int32),
+        ("min_num_correspondences", C.c_int32),
+        ("stop_at_fixed_point", C.c_int32),
+    ]
+
+
+class AlignResult(C.Structure):
+    """prs_align_result"""
+    _fields_ = [
+        ("H", C.c_float * 36),
+        ("b", C.c_float * 6),
+        ("chi_inliers", C.c_float),
+        ("chi_total", C.c_float),
+        ("mean_disparity", C.c_float),
+        ("num_inliers", C.c_int32),
+        ("num_outliers", C.c_int32),
+        ("num_invalid", C.c_int32),
+        ("num_correspondences", C.c_int32),
+        ("status", C.c_int32),
+        ("iterations", C.c_int32),
+        ("iterations_executed", C.c_int32),
+        ("warnings", C.c_int32),
+    ]
+
+
+class AlignBatch(C.Structure):
+    """prs_align_batch (device pointers)"""
+    _fields_ = [
+        ("batch", C.c_int32), ("fixed_stride", C.c_int32), ("moving_stride", C.c_int32),
+        ("fixed", C.c_void_p), ("fixed_desc", C.c_void_p), ("n_fixed", C.c_void_p),
+        ("moving", C.c_void_p), ("moving_desc", C.c_void_p), ("n_moving", C.c_void_p),
+        ("inputs_changed", C.c_void_p), ("state", C.c_void_p), ("X", C.c_void_p),
+        ("corr", C.c_void_p), ("n_corr", C.c_void_p), ("result", C.c_void_p), ("prior", C.c_void_p),
+    ]
+
+
+MODE_ALIGN, MODE_FINDER, MODE_LINEARIZE = 0, 1, 2
+
 # every symbol include/proslam_hip.h declares: (restype, argtypes)
 _vp = C.c_void_p
 _i32p = C.POINTER(C.c_int32)
@@ -87,6 +177,21 @@ SYMBOLS = {
     "prs_last_error": (C.c_char_p, [_vp]),
     "prs_stereo_match": (C.c_int, [_vp, C.POINTER(StereoParams), _vp, _vp, C.c_int32, _vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
     "prs_stereo_match_batch": (C.c_int, [_vp, C.POINTER(StereoParams), C.POINTER(StereoBatch)]),
+    "prs_align_batch_run": (C.c_int, [_vp, C.POINTER(PcfParams), C.POINTER(AlignerParams), C.POINTER(AlignBatch), C.c_int32]),
+    "prs_pcf_create": (C.c_int, [_vp, C.POINTER(PcfParams), C.POINTER(_vp)]),
+    "prs_pcf_destroy": (C.c_int, [_vp]),
+    "prs_pcf_set_params": (C.c_int, [_vp, C.POINTER(PcfParams)]),
+    "prs_pcf_set_fixed": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32]),
+    "prs_pcf_set_moving": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32]),
+    "prs_pcf_set_local_map_in_sensor": (C.c_int, [_vp, _vp]),
+    "prs_pcf_set_search_radius": (C.c_int, [_vp, C.c_uint64]),
+    "prs_pcf_set_descriptor_distance": (C.c_int, [_vp, C.c_float]),
+    "prs_pcf_get_state": (C.c_int, [_vp, C.POINTER(PcfState)]),
+    "prs_pcf_compute": (C.c_int, [_vp, _vp, C.c_int32, _i32p]),
+    "prs_pcf_align": (C.c_int, [_vp, C.POINTER(AlignerParams), _vp, _vp, _vp, _vp, C.c_int32, _i32p, C.POINTER(AlignResult)]),
+    "prs_pcf_linearize": (C.c_int, [_vp, C.POINTER(AlignerParams), _vp, _vp, C.c_int32, C.POINTER(AlignResult)]),
+    "prs_gn_step": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp]),
+    "prs_info_scale_from_nopt": (None, [_vp, C.c_int32, _vp]),
     "prs_triangulate": (C.c_int, [_vp, C.POINTER(TriangulatorParams), _vp, C.c_int32, _vp, _vp]),
     "prs_triangulate_dev": (C.c_int, [_vp, C.POINTER(TriangulatorParams), _vp, C.c_int64, _vp]),
 }

@@ -1,0 +1,981 @@
+// align.hip -- projective correspondence finder + reprojection-error Gauss-Newton aligner (gfx950).
+//
+// One 256-thread workgroup owns one frame (one sequence) for the WHOLE per-frame loop the external
+// MultiAligner3DQR drives in the reference: up to max_iterations of
+//     finder.setLocalMapInSensor(X); finder.compute(); slice.setupFactor(); linearize; GN step
+// so the ~100 dependent iterations cost no kernel launches and the frame's working set (lattice
+// database, per-correspondence operands, normal equations, pose, finder state) never leaves the CU.
+// Independent frames/sequences fill the chip: a launch covers `batch` of them.
+//
+// Reference code replaced (CF/ = registration/correspondence_finders/):
+//   CorrespondenceFinderProjectiveBase::compute        CF/correspondence_finder_projective_base_impl.cpp:105-293
+//   _addCorrespondenceCandidate / _filterCorrespondences                                   ...:8-37, 41-102
+//   Square/Circle/Rhombus _initializeDatabase, _findNearestNeighbors
+//        CF/..square_impl.cpp:8-118, CF/..circle_impl.cpp:8-94, CF/..rhombus_impl.cpp:8-93
+//   KDTree _findNearestNeighbors (exact radius query)  CF/..kdtree_impl.cpp:30-80
+//   AlignerSliceProcessorProjective{,Stereo}::setupFactor / bindFixed
+//        registration/aligner_slice_processor_projective.cpp:28-112
+//   + the un-vendored pinhole projector, error factors, saturated robustifier, H/b accumulation and
+//     damped GN step, restated per SURVEY.md Appendix A.
+//
+// Determinism / parity: candidates are reduced with order-independent LDS atomicMin on
+// (response, insertion order) keys, correspondences are emitted in ascending fixed index, and the
+// 21+6+2 normal-equation sums are accumulated in correspondence order by one lane each (the
+// upstream factor loop is sequential), so correspondences AND poses are bit-identical to the
+// sequential float evaluation.
+#include "prs_device.h"
+#include "prs_host.h"
+#include "prs_se3.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+namespace prs {
+
+constexpr int kAlignThreads = 256;
+constexpr int kTerms        = 29;  // 21 H (upper) + 6 b + chi_inliers + chi_total
+constexpr uint32_t kNoneU32 = 0xffffffffu;
+constexpr float kFltMax     = 3.402823466e+38f;
+
+typedef unsigned int au32x4 __attribute__((ext_vector_type(4)));
+
+struct AlignShared {
+  float X[16];
+  float T[16];      // finder's local_map_in_sensor
+  float Tprev[16];  // _local_map_in_sensor_previous
+  float W[16];      // points -> camera used by the projector
+  float H[36];
+  float b[6];
+  float chi_in, chi_tot, mean_disp, change_norm, dd;
+  unsigned long long radius, it;
+  int converged, config_changed, num_recomputes;
+  int n_corr, n_filtered, n_projected, decision, flags, error;
+  int n_inl, n_out, n_inv;
+  int corr_changed, have_terms;
+  int wave_tot[4];
+};
+
+struct AlignArgs {
+  prs_pcf_params f;
+  prs_aligner_params a;
+  prs_align_batch b;
+  int mode;
+  int rows_table;  // R = projector canvas rows (lattice row table extent)
+  int lut_cap;     // entries of the circle width table
+  uint2* cand;     // scratch [batch][moving_stride]
+  uint32_t off_db, off_fuv, off_rowfirst, off_best, off_second, off_lut, off_cfix, off_cmov, off_terms, off_sh;
+};
+
+enum { kDecisionCommit = 0, kDecisionRetry = 1, kDecisionReturn = 2 };
+
+// floor(sqrt(n)) for 0 <= n < 2^31, exact
+__device__ __forceinline__ int isqrt_exact(int n) {
+  int s = (int) sqrtf((float) n);
+  while (s * s > n) {
+    --s;
+  }
+  while ((s + 1) * (s + 1) <= n) {
+    ++s;
+  }
+  return s;
+}
+
+__device__ __forceinline__ int hamming_regs(const au32x4& a0, const au32x4& a1, const au32x4& b0, const au32x4& b1) {
+  int d = __popc(a0.x ^ b0.x);
+  d += __popc(a0.y ^ b0.y);
+  d += __popc(a0.z ^ b0.z);
+  d += __popc(a0.w ^ b0.w);
+  d += __popc(a1.x ^ b1.x);
+  d += __popc(a1.y ^ b1.y);
+  d += __popc(a1.z ^ b1.z);
+  d += __popc(a1.w ^ b1.w);
+  return d;
+}
+
+__global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid   = threadIdx.x;
+  const int lane  = tid & 63;
+  const int wave  = tid >> 6;
+  const int frame = blockIdx.x;
+
+  int nF = g.b.n_fixed[frame];
+  int nM = g.b.n_moving[frame];
+  nF     = nF < 0 ? 0 : (nF > g.b.fixed_stride ? g.b.fixed_stride : nF);
+  nM     = nM < 0 ? 0 : (nM > g.b.moving_stride ? g.b.moving_stride : nM);
+  const size_t fbase = (size_t) frame * (size_t) g.b.fixed_stride;
+  const size_t mbase = (size_t) frame * (size_t) g.b.moving_stride;
+  const float4* __restrict__ gfix = reinterpret_cast<const float4*>(g.b.fixed) + fbase;
+  const float4* __restrict__ gmov = reinterpret_cast<const float4*>(g.b.moving) + mbase;
+  const au32x4* __restrict__ gfd  = reinterpret_cast<const au32x4*>(g.b.fixed_desc + fbase * PRS_DESC_BYTES);
+  const au32x4* __restrict__ gmd  = reinterpret_cast<const au32x4*>(g.b.moving_desc + mbase * PRS_DESC_BYTES);
+  prs_corr* __restrict__ gcorr    = g.b.corr + fbase;
+  uint2* __restrict__ cand        = g.cand + mbase;
+  prs_pcf_state* gstate           = g.b.state + frame;
+  prs_align_result* gres          = g.b.result + frame;
+
+  uint2* db           = reinterpret_cast<uint2*>(smem + g.off_db);        // row-sorted lattice: x = row | col << 16, y = fixed index
+  float2* fuv         = reinterpret_cast<float2*>(smem + g.off_fuv);      // fixed (u,v) in index order (KD-tree variant)
+  uint16_t* rowfirst  = reinterpret_cast<uint16_t*>(smem + g.off_rowfirst);
+  uint32_t* bestkey   = reinterpret_cast<uint32_t*>(smem + g.off_best);
+  uint32_t* second    = reinterpret_cast<uint32_t*>(smem + g.off_second);
+  uint16_t* lut       = reinterpret_cast<uint16_t*>(smem + g.off_lut);
+  float4* cfix        = reinterpret_cast<float4*>(smem + g.off_cfix);
+  float4* cmov        = reinterpret_cast<float4*>(smem + g.off_cmov);
+  float* terms        = reinterpret_cast<float*>(smem + g.off_terms);
+  AlignShared& sh     = *reinterpret_cast<AlignShared*>(smem + g.off_sh);
+  const int R         = g.rows_table;
+  const int stype     = g.f.search_type;
+  const bool lattice  = stype != PRS_SEARCH_KDTREE;
+
+  // ---- load the persistent state ---------------------------------------------------------------
+  if (tid < 16) {
+    sh.X[tid]     = g.b.X[(size_t) frame * 16 + tid];
+    sh.T[tid]     = gstate->local_map_in_sensor[tid];
+    sh.Tprev[tid] = gstate->local_map_in_sensor_previous[tid];
+  }
+  if (tid == 0) {
+    sh.radius         = gstate->search_radius_pixels;
+    sh.it             = gstate->current_iteration;
+    sh.dd             = gstate->descriptor_distance;
+    sh.converged      = gstate->has_converged;
+    sh.config_changed = gstate->config_changed;
+    sh.num_recomputes = gstate->num_recomputes;
+    sh.n_corr         = g.b.n_corr[frame];
+    sh.flags          = 0;
+    sh.error          = 0;
+    sh.n_inl = sh.n_out = sh.n_inv = 0;
+    sh.chi_in = sh.chi_tot = 0.0f;
+    sh.mean_disp           = g.a.mean_disparity;
+    sh.corr_changed        = 1;
+    sh.have_terms          = 0;
+    if (sh.n_corr < 0 || sh.n_corr > nF) {
+      sh.n_corr = 0;
+    }
+  }
+  for (int i = tid; i < 36; i += kAlignThreads) {
+    sh.H[i] = 0.0f;
+  }
+  if (tid < 6) {
+    sh.b[tid] = 0.0f;
+  }
+  __syncthreads();
+
+  bool inputs_changed = g.b.inputs_changed ? (g.b.inputs_changed[frame] != 0) : true;
+  bool db_built       = false;
+  if (inputs_changed && g.mode != PRS_MODE_LINEARIZE) {
+    // a new fixed/moving cloud invalidates the previous frame's correspondence vector
+    if (tid == 0) {
+      sh.n_corr = 0;
+    }
+    __syncthreads();
+  }
+
+  // ---- bindFixed: mean disparity over ALL fixed points, sequential float sum -------------------
+  // (aligner_slice_processor_projective.cpp:80-88)
+  if (g.mode != PRS_MODE_FINDER && g.a.factor_type == PRS_FACTOR_STEREO && g.a.enable_inverse_depth_weighting &&
+      g.a.mean_disparity < 0.0f) {
+    for (int i = tid; i < nF; i += kAlignThreads) {
+      const float4 c = gfix[i];
+      terms[i]       = c.x - c.z;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float acc = 0.0f;
+      for (int i = 0; i < nF; ++i) {
+        acc += terms[i];
+      }
+      sh.mean_disp = nF > 0 ? acc / (float) (size_t) nF : 0.0f;
+    }
+    __syncthreads();
+  }
+
+  // the caller-owned correspondence vector persists across calls: "nothing new" finder calls keep
+  // using it, and linearize-only calls receive it as input
+  if (g.mode != PRS_MODE_FINDER) {
+    for (int c = tid; c < sh.n_corr; c += kAlignThreads) {
+      const prs_corr cr = gcorr[c];
+      if (cr.fixed_idx < 0 || cr.fixed_idx >= nF || cr.moving_idx < 0 || cr.moving_idx >= nM) {
+        sh.error = PRS_ERR_RANGE;
+      } else {
+        cfix[c] = gfix[cr.fixed_idx];
+        cmov[c] = gmov[cr.moving_idx];
+      }
+    }
+    __syncthreads();
+  }
+
+  const int max_it = (g.mode == PRS_MODE_ALIGN && !sh.error) ? g.a.max_iterations : (sh.error ? 0 : 1);
+  int executed     = 0;
+  int it_align     = 0;
+  for (; it_align < max_it; ++it_align) {
+    ++executed;
+    // ============================================================================================
+    // finder.setLocalMapInSensor(X); finder.compute()
+    // ============================================================================================
+    if (g.mode != PRS_MODE_LINEARIZE) {
+      if (tid < 16) {
+        sh.T[tid] = sh.X[tid];
+      }
+      __syncthreads();
+      for (;;) {  // the reference re-enters compute() recursively (projective_base_impl.cpp:262)
+        // -- new optimisation when fixed / moving / config changed (:109-134)
+        const bool reset = inputs_changed || sh.config_changed;
+        __syncthreads();
+        if (reset) {
+          if (tid == 0) {
+            if ((sh.radius == 0 && sh.dd == 0.0f) || sh.config_changed) {
+              sh.radius = g.f.maximum_search_radius_pixels;
+              sh.dd     = g.f.minimum_descriptor_distance;
+            }
+            sh.converged = 0;
+            sh.it        = 0;
+            se3_identity(sh.Tprev);
+            sh.config_changed = 0;
+          }
+          inputs_changed = false;
+          db_built       = false;  // _initializeDatabase() is part of the reset (:131)
+          __syncthreads();
+        }
+        if (sh.error) {
+          break;
+        }
+
+        // -- converged: correspondences are not touched (:138-142)
+        if (tid == 0) {
+          sh.decision = kDecisionCommit;
+          if (sh.converged) {
+            sh.decision = kDecisionReturn;
+          } else {
+            // setCameraPose(local_map_in_sensor^-1) (:158); reproject periodically, always for it 0 and 1 (:162-178)
+            float cam[16];
+            se3_inverse(sh.T, cam);
+            const unsigned long long k = g.f.number_of_solver_iterations_per_projection;
+            if (k == 0 || sh.it % k == 0 || sh.it == 1) {
+              se3_inverse(cam, sh.W);
+              float delta[16], v6[6];
+              se3_mul(cam, sh.Tprev, delta);
+              t2tnq(delta, v6);
+              sh.change_norm =
+                sqrtf(((((v6[0] * v6[0] + v6[1] * v6[1]) + v6[2] * v6[2]) + v6[3] * v6[3]) + v6[4] * v6[4]) + v6[5] * v6[5]);
+#pragma unroll
+              for (int i = 0; i < 16; ++i) {
+                sh.Tprev[i] = sh.T[i];
+              }
+              sh.n_projected = 0;
+              ++sh.num_recomputes;
+            } else {
+#pragma unroll
+              for (int i = 0; i < 16; ++i) {
+                sh.Tprev[i] = sh.T[i];
+              }
+              ++sh.it;
+              sh.decision = kDecisionReturn;
+            }
+          }
+        }
+        __syncthreads();
+        if (sh.decision == kDecisionReturn) {
+          break;
+        }
+
+        // -- the lattice lives in LDS: (re)build it on the first search of a launch and after every reset
+        if (!db_built) {
+        // _initializeDatabase (square_impl.cpp:8-31), stable by row: canonical tie order
+        uint32_t* hist   = reinterpret_cast<uint32_t*>(terms);
+        uint16_t* slot   = reinterpret_cast<uint16_t*>(hist + (R + 2));
+        uint16_t* bucket = slot + g.b.fixed_stride + 2;
+        for (int i = tid; i <= R; i += kAlignThreads) {
+          hist[i] = 0;
+        }
+        __syncthreads();
+        for (int i = tid; i < nF; i += kAlignThreads) {
+          const float4 c = gfix[i];
+          if (!lattice) {
+            fuv[i] = make_float2(c.x, c.y);
+          } else if (c.x >= 0.0f && c.x < 32767.0f && c.y >= 0.0f && c.y < (float) R) {
+            const int row = (int) (int16_t) c.y;  // Element(coordinates(1), coordinates(0), i)
+            slot[i]       = (uint16_t) atomicAdd(&hist[row], 1u);
+          } else {
+            sh.error = PRS_ERR_RANGE;
+          }
+        }
+        __syncthreads();
+        if (lattice && !sh.error) {
+          if (wave == 0) {
+            // exclusive scan of hist[0..R] into rowfirst[0..R]
+            const int n     = R + 1;
+            const int chunk = (n + 63) >> 6;
+            uint32_t sum    = 0;
+            for (int j = 0; j < chunk; ++j) {
+              const int r = lane * chunk + j;
+              sum += r < n ? hist[r] : 0u;
+            }
+            uint32_t incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+              const uint32_t o = __shfl_up(incl, d, 64);
+              if (lane >= d) {
+                incl += o;
+              }
+            }
+            uint32_t run = incl - sum;
+            for (int j = 0; j < chunk; ++j) {
+              const int r = lane * chunk + j;
+              if (r < n) {
+                rowfirst[r] = (uint16_t) run;
+                run += hist[r];
+              }
+            }
+          }
+          __syncthreads();
+          for (int i = tid; i < nF; i += kAlignThreads) {
+            const int row = (int) (int16_t) gfix[i].y;
+            bucket[rowfirst[row] + slot[i]] = (uint16_t) i;
+          }
+          __syncthreads();
+          for (int i = tid; i < nF; i += kAlignThreads) {
+            const float4 c = gfix[i];
+            const int row  = (int) (int16_t) c.y;
+            const int col  = (int) (int16_t) c.x;
+            const int s = rowfirst[row], e = rowfirst[row + 1];
+            int rank = 0;
+            for (int j = s; j < e; ++j) {
+              rank += bucket[j] < (uint16_t) i ? 1 : 0;
+            }
+            db[s + rank] = make_uint2(((uint32_t) row & 0xffffu) | ((uint32_t) col << 16), (uint32_t) i);
+          }
+        }
+          __syncthreads();
+          db_built = true;
+          if (sh.error) {
+            break;
+          }
+        }
+
+        // -- projection + candidate search (:165-166, :192-200)
+        const int rad = (int) sh.radius;
+        for (int i = tid; i < nF; i += kAlignThreads) {
+          bestkey[i] = kNoneU32;
+          second[i]  = kNoneU32;
+        }
+        if (stype == PRS_SEARCH_CIRCLE) {
+          // width = int(sqrt(r^2 - h^2) + 1) per row offset h (circle_impl.cpp:51-53), exact in integers
+          for (int i = tid; i < 2 * rad + 1 && i < g.lut_cap; i += kAlignThreads) {
+            const int h = i - rad;
+            lut[i]      = (uint16_t) (isqrt_exact(rad * rad - h * h) + 1);
+          }
+        }
+        __syncthreads();
+        {
+          const float W0 = sh.W[0], W1 = sh.W[1], W2 = sh.W[2], W3 = sh.W[3];
+          const float W4 = sh.W[4], W5 = sh.W[5], W6 = sh.W[6], W7 = sh.W[7];
+          const float W8 = sh.W[8], W9 = sh.W[9], W10 = sh.W[10], W11 = sh.W[11];
+          const float cols = (float) g.f.projector.canvas_cols, rows = (float) g.f.projector.canvas_rows;
+          const float max_dd = g.f.maximum_descriptor_distance;
+          const float r2f    = (float) (sh.radius * sh.radius);
+          int projected      = 0;
+          for (int m = tid; m < nM; m += kAlignThreads) {
+            const float4 p = gmov[m];
+            // PointProjectorPinhole_::compute (external)
+            const float x = ((W0 * p.x + W1 * p.y) + W2 * p.z) + W3;
+            const float y = ((W4 * p.x + W5 * p.y) + W6 * p.z) + W7;
+            const float z = ((W8 * p.x + W9 * p.y) + W10 * p.z) + W11;
+            uint2 cd      = make_uint2(kNoneU32, kNoneU32);
+            bool visible  = !(z < g.f.projector.range_min || z > g.f.projector.range_max);
+            float u = 0.0f, v = 0.0f;
+            if (visible) {
+              const float hx = g.f.projector.fx * x + g.f.projector.cx * z;
+              const float hy = g.f.projector.fy * y + g.f.projector.cy * z;
+              u              = hx / z;
+              v              = hy / z;
+              visible        = !(u < 0.0f || u >= cols || v < 0.0f || v >= rows);
+            }
+            if (visible) {
+              ++projected;
+              const au32x4 q0 = gmd[2 * m], q1 = gmd[2 * m + 1];
+              float best = kFltMax, sec = kFltMax;
+              int ibest = 0, isec = 0;
+              if (lattice) {
+                const int row   = (int) (int16_t) roundf(v);  // circle_impl.cpp:15-16
+                const int col   = (int) (int16_t) roundf(u);
+                const int rmin  = (int) (int16_t) (row - rad);      // :25
+                const int rmax  = (int) (int16_t) (row + rad + 1);  // :26
+                const int cmin  = (int) (int16_t) (col - rad - 1);  // square_impl.cpp:56
+                const int cmax  = (int) (int16_t) (col + rad + 1);  // square_impl.cpp:57
+                const int start = rowfirst[rmin < 0 ? 0 : (rmin > R ? R : rmin)];
+                const int end   = rowfirst[rmax < 0 ? 0 : (rmax > R ? R : rmax)];
+                for (int pos = start; pos < end; ++pos) {
+                  const uint2 e  = db[pos];
+                  const int drow = (int) (int16_t) (e.x & 0xffffu);
+                  const int dcol = (int) (int16_t) (e.x >> 16);
+                  bool accept;
+                  if (stype == PRS_SEARCH_SQUARE) {
+                    accept = dcol > cmin && dcol < cmax;  // square_impl.cpp:80
+                  } else if (stype == PRS_SEARCH_CIRCLE) {
+                    const int h     = drow - row;
+                    const int li    = h + rad;
+                    const int width = li < g.lut_cap ? (int) lut[li] : isqrt_exact(rad * rad - h * h) + 1;
+                    accept          = dcol > col - width && dcol < col + width;  // circle_impl.cpp:56
+                  } else {
+                    int width = (int) (int16_t) (drow - rmin + 1);  // rhombus_impl.cpp:49-52
+                    if (width > (int) (int16_t) rad) {
+                      width = (int) (int16_t) (rmax - drow);
+                    }
+                    accept = dcol > col - width && dcol < col + width;
+                  }
+                  if (accept) {
+                    const int fi  = (int) e.y;
+                    const float d = (float) hamming_regs(gfd[2 * fi], gfd[2 * fi + 1], q0, q1);
+                    if (d < best) {  // circle_impl.cpp:64-72
+                      sec   = best;
+                      isec  = ibest;
+                      best  = d;
+                      ibest = fi;
+                    } else if (d < sec) {
+                      sec  = d;
+                      isec = fi;
+                    }
+                  }
+                }
+                if (best < kFltMax) {  // circle_impl.cpp:78-92
+                  cd.x = (uint32_t) ibest | ((uint32_t) (int) best << 16);
+                  if (sec < kFltMax) {
+                    cd.y = (uint32_t) isec | ((uint32_t) (int) sec << 16);
+                  }
+                }
+              } else {
+                // exact radius query visited in ascending fixed index (kdtree_impl.cpp:39-50)
+                best = max_dd;  // :54
+                for (int fi = 0; fi < nF; ++fi) {
+                  const float2 c = fuv[fi];
+                  const float du = c.x - u, dv = c.y - v;
+                  if (du * du + dv * dv > r2f) {
+                    continue;
+                  }
+                  const float d = (float) hamming_regs(gfd[2 * fi], gfd[2 * fi + 1], q0, q1);
+                  if (d < best) {  // :62-68
+                    sec   = best;
+                    best  = d;
+                    ibest = fi;
+                  } else if (d < sec) {
+                    sec = d;
+                  }
+                }
+                if (best < max_dd) {  // :72-78
+                  cd.x = (uint32_t) ibest | ((uint32_t) (int) best << 16);
+                }
+              }
+              // _addCorrespondenceCandidate (:8-37): order-independent reduction on
+              // (response, insertion order = (moving index, best before second best))
+              if (cd.x != kNoneU32) {
+                atomicMin(&bestkey[cd.x & 0xffffu], ((cd.x >> 16) << 17) | ((uint32_t) m << 1));
+              }
+              if (cd.y != kNoneU32) {
+                atomicMin(&bestkey[cd.y & 0xffffu], ((cd.y >> 16) << 17) | ((uint32_t) m << 1) | 1u);
+              }
+            }
+            cand[m] = cd;
+          }
+          if (projected) {
+            atomicAdd(&sh.n_projected, projected);
+          }
+        }
+        __syncthreads();
+        // -- second lowest response per fixed index (:57-68): minimum over everything but the winner
+        for (int m = tid; m < nM; m += kAlignThreads) {
+          const uint2 cd = cand[m];
+          if (cd.x != kNoneU32) {
+            const uint32_t key = ((cd.x >> 16) << 17) | ((uint32_t) m << 1);
+            if (key != bestkey[cd.x & 0xffffu]) {
+              atomicMin(&second[cd.x & 0xffffu], cd.x >> 16);
+            }
+          }
+          if (cd.y != kNoneU32) {
+            const uint32_t key = ((cd.y >> 16) << 17) | ((uint32_t) m << 1) | 1u;
+            if (key != bestkey[cd.y & 0xffffu]) {
+              atomicMin(&second[cd.y & 0xffffu], cd.y >> 16);
+            }
+          }
+        }
+        __syncthreads();
+        // -- _filterCorrespondences (:41-102) in ascending fixed index; second[] is recycled to hold
+        //    the output slot of accepted entries
+        {
+          const float ratio = g.f.maximum_distance_ratio_to_second_best;
+          const float dd    = sh.dd;
+          int base          = 0;
+          for (int f0 = 0; f0 < nF; f0 += kAlignThreads) {
+            const int f = f0 + tid;
+            bool acc    = false;
+            if (f < nF) {
+              const uint32_t bk = bestkey[f];
+              if (bk != kNoneU32) {
+                const float resp = (float) (bk >> 17);
+                const uint32_t s = second[f];
+                const float fs   = s == kNoneU32 ? kFltMax : (float) s;
+                // bijection (:82-99): the winner must be the moving point's own best emission
+                acc = resp < dd && resp / fs < ratio && (bk & 1u) == 0u;
+              }
+            }
+            const unsigned long long bal = __ballot(acc);
+            const int pre                = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) {
+              sh.wave_tot[wave] = __popcll(bal);
+            }
+            __syncthreads();
+            int wbase = base;
+            for (int w = 0; w < wave; ++w) {
+              wbase += sh.wave_tot[w];
+            }
+            if (f < nF) {
+              second[f] = acc ? (uint32_t) (wbase + pre) : kNoneU32;
+            }
+            base += sh.wave_tot[0] + sh.wave_tot[1] + sh.wave_tot[2] + sh.wave_tot[3];
+            __syncthreads();
+          }
+          if (tid == 0) {
+            sh.n_filtered = base;
+          }
+        }
+        __syncthreads();
+        // -- matching ratio, reset + internal repeat, convergence latch (:215-291)
+        if (tid == 0) {
+          if (sh.n_projected == 0) {
+            sh.flags |= PRS_WARN_NO_PROJECTION;
+          }
+          const float matching_ratio = (float) sh.n_filtered / (float) (size_t) nF;
+          sh.decision                = kDecisionCommit;
+          if (matching_ratio < g.f.minimum_matching_ratio) {
+            sh.flags |= PRS_WARN_LOW_RATIO;
+            if (sh.radius < g.f.maximum_search_radius_pixels || sh.dd > g.f.minimum_descriptor_distance) {
+              sh.radius = g.f.maximum_search_radius_pixels;
+              sh.dd     = g.f.minimum_descriptor_distance;
+              sh.flags |= PRS_WARN_RETRIED;
+              if (matching_ratio == 0.0f) {
+                sh.flags |= PRS_WARN_TRACK_LOST;
+                se3_identity(sh.T);
+                sh.it = 0;
+              } else {
+                ++sh.it;
+              }
+              sh.decision = kDecisionRetry;
+            }
+          }
+          if (sh.decision == kDecisionCommit) {
+            sh.n_corr       = sh.n_filtered;
+            sh.corr_changed = 1;
+            if (sh.change_norm < g.f.maximum_estimate_change_norm_for_convergence &&
+                sh.it > g.f.minimum_number_of_iterations) {
+              sh.converged = 1;
+              if (matching_ratio > g.f.minimum_matching_ratio) {
+                const unsigned long long reduced = sh.radius - g.f.search_radius_step_size_pixels;  // may wrap like size_t
+                sh.radius = reduced > g.f.minimum_search_radius_pixels ? reduced : g.f.minimum_search_radius_pixels;
+                const float increased = sh.dd + g.f.descriptor_distance_step_size_pixels;
+                sh.dd = increased < g.f.maximum_descriptor_distance ? increased : g.f.maximum_descriptor_distance;
+              }
+            }
+            ++sh.it;
+          }
+        }
+        __syncthreads();
+        if (sh.decision == kDecisionRetry) {
+          continue;
+        }
+        // -- commit: correspondences->swap(filtered) (:268) + per-correspondence operands for the factor
+        for (int f = tid; f < nF; f += kAlignThreads) {
+          const uint32_t slot = second[f];
+          if (slot != kNoneU32) {
+            const uint32_t bk = bestkey[f];
+            const int m       = (int) ((bk >> 1) & 0xffffu);
+            prs_corr cr;
+            cr.fixed_idx  = f;
+            cr.moving_idx = m;
+            cr.response   = (float) (bk >> 17);
+            gcorr[slot]   = cr;
+            if (g.mode == PRS_MODE_ALIGN) {
+              cfix[slot] = gfix[f];
+              cmov[slot] = gmov[m];
+            }
+          }
+        }
+        __syncthreads();
+        break;
+      }  // finder compute()
+      if (sh.error) {
+        break;
+      }
+      // _postCompute (bruteforce_impl.cpp:231-243)
+      if (tid == 0 && sh.n_corr == 0) {
+        sh.flags |= PRS_WARN_NO_MATCHES;
+      }
+      __syncthreads();
+    }
+    if (g.mode == PRS_MODE_FINDER) {
+      break;
+    }
+
+    // ==============================================================================================
+    // setupFactor + errorAndJacobian + robustifier + H/b (aligner_slice_processor_projective.cpp:28-112
+    // and the restated srrg2_solver arithmetic)
+    // ==============================================================================================
+    const int nc = sh.n_corr;
+    __syncthreads();
+    if (g.mode == PRS_MODE_ALIGN && nc < g.a.min_num_correspondences) {
+      if (tid == 0) {
+        sh.n_inl = sh.n_out = sh.n_inv = 0;
+        sh.chi_in = sh.chi_tot = 0.0f;
+      }
+      for (int i = tid; i < 36; i += kAlignThreads) {
+        sh.H[i] = 0.0f;
+      }
+      if (tid < 6) {
+        sh.b[tid] = 0.0f;
+      }
+      __syncthreads();
+      if (g.a.stop_at_fixed_point && sh.converged) {
+        break;  // nothing can change any more
+      }
+      continue;  // slice has too few correspondences: no update this iteration
+    }
+    {
+      const float R00 = sh.X[0], R01 = sh.X[1], R02 = sh.X[2], t0 = sh.X[3];
+      const float R10 = sh.X[4], R11 = sh.X[5], R12 = sh.X[6], t1 = sh.X[7];
+      const float R20 = sh.X[8], R21 = sh.X[9], R22 = sh.X[10], t2 = sh.X[11];
+      const float fx = g.a.fx, fy = g.a.fy, cx = g.a.cx, cy = g.a.cy;
+      const int dim        = g.a.factor_type;
+      const float mean_dsp = sh.mean_disp;
+      if (tid == 0) {
+        sh.n_inl = sh.n_out = sh.n_inv = 0;
+      }
+      float run = 0.0f;  // lanes 0..28 of wave 0: running sum of their term in correspondence order
+      __syncthreads();
+      for (int c0 = 0; c0 < nc; c0 += kAlignThreads) {
+        const int c = c0 + tid;
+        float tv[kTerms];
+#pragma unroll
+        for (int t = 0; t < kTerms; ++t) {
+          tv[t] = 0.0f;
+        }
+        if (c < nc) {
+          const float4 z = cfix[c];
+          const float4 p = cmov[c];
+          const float px = p.x, py = p.y, pz = p.z;
+          const float pcx = ((R00 * px + R01 * py) + R02 * pz) + t0;
+          const float pcy = ((R10 * px + R11 * py) + R12 * pz) + t1;
+          const float pcz = ((R20 * px + R21 * py) + R22 * pz) + t2;
+          const float hx  = fx * pcx + cx * pcz;
+          const float hy  = fy * pcy + cy * pcz;
+          const float hz  = pcz;
+          bool valid      = hz > 0.0f;
+          float iz = 0.0f, u_pred = 0.0f, v_pred = 0.0f;
+          if (valid) {
+            iz     = 1.0f / hz;
+            u_pred = hx * iz;
+            v_pred = hy * iz;
+            valid  = !(u_pred < 0.0f || u_pred > g.a.image_cols || v_pred < 0.0f || v_pred > g.a.image_rows);
+          }
+          if (!valid) {
+            atomicAdd(&sh.n_inv, 1);
+          } else {
+            float e0 = u_pred - z.x, e1 = v_pred - z.y, e2 = 0.0f;
+            float hrx = hx;
+            if (dim == PRS_FACTOR_STEREO) {
+              hrx = hx + g.a.baseline_left_in_right_px[0];
+              e2  = hrx * iz - z.z;
+            } else if (dim == PRS_FACTOR_DEPTH) {
+              e2 = hz - z.z;
+            }
+            float wt = 1.0f;
+            if (dim == PRS_FACTOR_STEREO && g.a.enable_inverse_depth_weighting) {
+              wt = (z.x - z.z) / mean_dsp;
+              if (wt < 0.01f) {
+                wt = 0.01f;
+              }
+              if (wt > 1.0f) {
+                wt = 1.0f;
+              }
+            }
+            const float ax = 2.0f * px, ay = 2.0f * py, az = 2.0f * pz;
+            const float Rm[3][3] = {{R00, R01, R02}, {R10, R11, R12}, {R20, R21, R22}};
+            float Jp[3][6];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+              Jp[r][0] = Rm[r][0] * wt;
+              Jp[r][1] = Rm[r][1] * wt;
+              Jp[r][2] = Rm[r][2] * wt;
+              Jp[r][3] = Rm[r][2] * ay - Rm[r][1] * az;
+              Jp[r][4] = Rm[r][0] * az - Rm[r][2] * ax;
+              Jp[r][5] = Rm[r][1] * ax - Rm[r][0] * ay;
+            }
+            const float hx_iz2 = (hx * iz) * iz;
+            const float hy_iz2 = (hy * iz) * iz;
+            const float hr_iz2 = (hrx * iz) * iz;
+            float J0[6], J1[6], J2[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              const float a0 = fx * Jp[0][k] + cx * Jp[2][k];
+              const float a1 = fy * Jp[1][k] + cy * Jp[2][k];
+              const float a2 = Jp[2][k];
+              J0[k]          = a0 * iz - hx_iz2 * a2;
+              J1[k]          = a1 * iz - hy_iz2 * a2;
+              J2[k]          = dim == PRS_FACTOR_STEREO ? a0 * iz - hr_iz2 * a2 : (dim == PRS_FACTOR_DEPTH ? a2 : 0.0f);
+            }
+            // Omega = diag(info) * scale(moving point) (aligner_slice_processor_projective.cpp:46-56)
+            const float s = p.w;
+            float o0 = g.a.diagonal_info[0] * s;
+            float o1 = g.a.diagonal_info[1] * s;
+            float o2 = dim == PRS_FACTOR_MONO ? 0.0f : g.a.diagonal_info[2] * s;
+            float chi = ((o0 * e0) * e0 + (o1 * e1) * e1) + (o2 * e2) * e2;
+            if (chi > g.a.chi_threshold) {  // saturated kernel
+              const float scale = g.a.chi_threshold / chi;
+              o0 *= scale;
+              o1 *= scale;
+              o2 *= scale;
+              chi = g.a.chi_threshold;
+              atomicAdd(&sh.n_out, 1);
+            } else {
+              atomicAdd(&sh.n_inl, 1);
+              tv[27] = chi;
+            }
+            tv[28] = chi;
+            int t  = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+              const float j0 = J0[r] * o0, j1 = J1[r] * o1, j2 = J2[r] * o2;
+#pragma unroll
+              for (int k = r; k < 6; ++k) {
+                tv[t++] = (j0 * J0[k] + j1 * J1[k]) + j2 * J2[k];
+              }
+              tv[21 + r] = (j0 * e0 + j1 * e1) + j2 * e2;
+            }
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < kTerms; ++t) {
+          terms[t * kAlignThreads + tid] = tv[t];
+        }
+        __syncthreads();
+        // sequential accumulation in correspondence order, one lane per normal-equation entry
+        if (tid < kTerms) {
+          const int cnt     = nc - c0 < kAlignThreads ? nc - c0 : kAlignThreads;
+          const float* row  = terms + tid * kAlignThreads;
+          for (int j = 0; j < cnt; ++j) {
+            run += row[j];
+          }
+        }
+        __syncthreads();
+      }
+      if (tid < kTerms) {
+        if (tid < 21) {
+          // upper-triangle index -> (r, k)
+          int r = 0, first = 0;
+          while (tid >= first + (6 - r)) {
+            first += 6 - r;
+            ++r;
+          }
+          const int k       = r + (tid - first);
+          sh.H[6 * r + k]   = run;
+          sh.H[6 * k + r]   = run;
+        } else if (tid < 27) {
+          sh.b[tid - 21] = run;
+        } else if (tid == 27) {
+          sh.chi_in = run;
+        } else {
+          sh.chi_tot = run;
+        }
+      }
+      __syncthreads();
+    }
+    if (g.mode == PRS_MODE_LINEARIZE) {
+      break;
+    }
+    // ---- damped GN step on one lane (IterationAlgorithmGN + dense Cholesky + X <- X * exp(dx)) ---
+    if (tid == 0) {
+      float H[36], b[6], X[16];
+#pragma unroll
+      for (int i = 0; i < 36; ++i) {
+        H[i] = sh.H[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        b[i] = sh.b[i];
+      }
+      if (g.b.prior) {
+        const float* pr = g.b.prior + (size_t) frame * 42;
+#pragma unroll
+        for (int i = 0; i < 36; ++i) {
+          H[i] += pr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          b[i] += pr[36 + i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        X[i] = sh.X[i];
+      }
+      gn_step(H, b, g.a.damping, X);
+      bool same = true;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        same    = same && (__float_as_uint(X[i]) == __float_as_uint(sh.X[i]));
+        sh.X[i] = X[i];
+      }
+      // fixed point: finder latched + pose reproduced bit-for-bit => every later iteration repeats this one
+      sh.decision = (g.a.stop_at_fixed_point && same && sh.converged) ? 1 : 0;
+    }
+    __syncthreads();
+    if (sh.decision) {
+      ++it_align;
+      break;
+    }
+  }
+
+  // ---- write back --------------------------------------------------------------------------------
+  __syncthreads();
+  if (tid < 16) {
+    g.b.X[(size_t) frame * 16 + tid]           = sh.X[tid];
+    gstate->local_map_in_sensor[tid]          = sh.T[tid];
+    gstate->local_map_in_sensor_previous[tid] = sh.Tprev[tid];
+  }
+  for (int i = tid; i < 36; i += kAlignThreads) {
+    gres->H[i] = sh.H[i];
+  }
+  if (tid < 6) {
+    gres->b[tid] = sh.b[tid];
+  }
+  if (tid == 0) {
+    gstate->search_radius_pixels = sh.radius;
+    gstate->current_iteration    = sh.it;
+    gstate->descriptor_distance  = sh.dd;
+    gstate->has_converged        = sh.converged;
+    gstate->config_changed       = sh.config_changed;
+    gstate->num_recomputes       = sh.num_recomputes;
+    g.b.n_corr[frame]            = sh.n_corr;
+    gres->chi_inliers            = sh.chi_in;
+    gres->chi_total              = sh.chi_tot;
+    gres->mean_disparity         = sh.mean_disp;
+    gres->num_inliers            = sh.n_inl;
+    gres->num_outliers           = sh.n_out;
+    gres->num_invalid            = sh.n_inv;
+    gres->num_correspondences    = sh.n_corr;
+    gres->status                 = sh.n_inl >= g.a.min_num_inliers ? 1 : 0;
+    gres->iterations             = g.mode == PRS_MODE_ALIGN ? g.a.max_iterations : 1;
+    gres->iterations_executed    = executed;
+    gres->warnings               = sh.error ? sh.error : sh.flags;
+  }
+}
+
+__global__ void gn_step_kernel(const float* H, const float* b, float damping, float* X, int* ok) {
+  float h[36], bb[6], x[16];
+  for (int i = 0; i < 36; ++i) {
+    h[i] = H[i];
+  }
+  for (int i = 0; i < 6; ++i) {
+    bb[i] = b[i];
+  }
+  for (int i = 0; i < 16; ++i) {
+    x[i] = X[i];
+  }
+  const bool r = gn_step(h, bb, damping, x);
+  for (int i = 0; i < 16; ++i) {
+    X[i] = x[i];
+  }
+  *ok = r ? 1 : 0;
+}
+
+static inline uint32_t align_up16(uint32_t v) {
+  return (v + 15u) / 16u * 16u;
+}
+
+int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs_aligner_params* aligner, const prs_align_batch* batch, int mode) {
+  if (!finder || !aligner || !batch || !batch->fixed || !batch->fixed_desc || !batch->n_fixed || !batch->moving ||
+      !batch->moving_desc || !batch->n_moving || !batch->state || !batch->X || !batch->corr || !batch->n_corr || !batch->result) {
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_align_batch_run: fixed, moving, correspondences, state or result not set");
+  }
+  if (mode < PRS_MODE_ALIGN || mode > PRS_MODE_LINEARIZE) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_run: unknown mode");
+  }
+  if (batch->batch <= 0) {
+    return PRS_OK;
+  }
+  if (batch->fixed_stride <= 0 || batch->fixed_stride > 32767 || batch->moving_stride <= 0 || batch->moving_stride > 65535) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_run: fixed_stride must be in [1,32767], moving_stride in [1,65535]");
+  }
+  if (finder->projector.canvas_rows <= 0 || finder->projector.canvas_rows > 8192 || finder->projector.canvas_cols <= 0 ||
+      finder->projector.canvas_cols > 32767) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_run: projector canvas must be within 32767 x 8192");
+  }
+  if (finder->maximum_search_radius_pixels > 16383 || finder->search_type < PRS_SEARCH_KDTREE || finder->search_type > PRS_SEARCH_RHOMBUS) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_run: search radius > 16383 px or unknown search type");
+  }
+  if (aligner->factor_type != PRS_FACTOR_MONO && aligner->factor_type != PRS_FACTOR_DEPTH && aligner->factor_type != PRS_FACTOR_STEREO) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_run: factor_type must be 2, 3 or 4");
+  }
+  AlignArgs g;
+  g.f          = *finder;
+  g.a          = *aligner;
+  g.b          = *batch;
+  g.mode       = mode;
+  g.rows_table = finder->projector.canvas_rows;
+  const uint32_t nf = (uint32_t) batch->fixed_stride;
+  const uint32_t R  = (uint32_t) g.rows_table;
+  uint32_t lut_cap  = 2u * (uint32_t) finder->maximum_search_radius_pixels + 1u;
+  if (lut_cap > 2048u) {
+    lut_cap = 2048u;
+  }
+  g.lut_cap = (int) lut_cap;
+  uint32_t off = 0;
+  g.off_db       = off; off = align_up16(off + nf * 8);
+  g.off_fuv      = off; off = align_up16(off + (finder->search_type == PRS_SEARCH_KDTREE ? nf * 8 : 0));
+  g.off_rowfirst = off; off = align_up16(off + (R + 2) * 2);
+  g.off_best     = off; off = align_up16(off + nf * 4);
+  g.off_second   = off; off = align_up16(off + nf * 4);
+  g.off_lut      = off; off = align_up16(off + lut_cap * 2);
+  g.off_cfix     = off; off = align_up16(off + nf * 16);
+  g.off_cmov     = off; off = align_up16(off + nf * 16);
+  // terms region doubles as the database-build scratch (hist + slot + bucket) and the disparity column
+  uint32_t terms_bytes = kTerms * kAlignThreads * 4;
+  const uint32_t build_bytes = (R + 2) * 4 + (nf + 2) * 2 * 2 + 16;
+  if (build_bytes > terms_bytes) {
+    terms_bytes = build_bytes;
+  }
+  if (nf * 4 > terms_bytes) {
+    terms_bytes = nf * 4;
+  }
+  g.off_terms = off; off = align_up16(off + terms_bytes);
+  g.off_sh    = off; off = align_up16(off + (uint32_t) sizeof(AlignShared));
+  const size_t lds = off;
+  if (lds > 160 * 1024) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_run: fixed cloud does not fit the 160 KiB LDS");
+  }
+  g.cand = static_cast<uint2*>(ctx_device_scratch_slot(ctx, 1, (size_t) batch->batch * (size_t) batch->moving_stride * sizeof(uint2)));
+  if (!g.cand) {
+    return ctx_fail(ctx, PRS_ERR_HIP, "prs_align_batch_run: candidate scratch allocation failed");
+  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_align_batch_run attribute");
+  }
+  hipLaunchKernelGGL(align_kernel, dim3(batch->batch), dim3(kAlignThreads), lds, ctx_stream(ctx), g);
+  e = hipGetLastError();
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_align_batch_run launch");
+  }
+  return PRS_OK;
+}
+
+int gn_step_launch(prs_context* ctx, const float* dH, const float* db, float damping, float* dX, int* dok) {
+  hipLaunchKernelGGL(gn_step_kernel, dim3(1), dim3(1), 0, ctx_stream(ctx), dH, db, damping, dX, dok);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_gn_step launch");
+  }
+  return PRS_OK;
+}
+
+}  // namespace prs

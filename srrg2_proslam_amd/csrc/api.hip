@@ -42,6 +42,25 @@ void* ctx_device_scratch(prs_context* ctx, size_t bytes) {
   return ctx->d_scratch;
 }
 
+void* ctx_device_scratch_slot(prs_context* ctx, int slot, size_t bytes) {
+  if (bytes <= ctx->d_slot_size[slot]) {
+    return ctx->d_slot[slot];
+  }
+  if (ctx->d_slot[slot]) {
+    (void) hipStreamSynchronize(ctx->stream);
+    (void) hipFree(ctx->d_slot[slot]);
+    ctx->d_slot[slot]      = nullptr;
+    ctx->d_slot_size[slot] = 0;
+  }
+  size_t want = bytes + bytes / 4 + 4096;
+  if (hipMalloc(&ctx->d_slot[slot], want) != hipSuccess) {
+    ctx->d_slot[slot] = nullptr;
+    return nullptr;
+  }
+  ctx->d_slot_size[slot] = want;
+  return ctx->d_slot[slot];
+}
+
 void* ctx_pinned_scratch(prs_context* ctx, size_t bytes) {
   if (bytes <= ctx->h_pinned_size) {
     return ctx->h_pinned;
@@ -167,6 +186,11 @@ int prs_context_destroy(prs_context* ctx) {
   }
   if (ctx->d_stamps) {
     (void) hipFree(ctx->d_stamps);
+  }
+  for (int i = 0; i < 4; ++i) {
+    if (ctx->d_slot[i]) {
+      (void) hipFree(ctx->d_slot[i]);
+    }
   }
   if (ctx->own) {
     (void) hipStreamDestroy(ctx->own);
@@ -298,6 +322,14 @@ int prs_stereo_match(prs_context* ctx,
 #undef PRS_TRY
   *n_out = meta[2];
   return meta[3];
+}
+
+int prs_align_batch_run(prs_context* ctx, const prs_pcf_params* finder, const prs_aligner_params* aligner, const prs_align_batch* batch, int32_t mode) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  (void) hipSetDevice(ctx->device);
+  return align_batch_launch(ctx, finder, aligner, batch, mode);
 }
 
 int prs_triangulate_dev(prs_context* ctx, const prs_triangulator_params* params, const float* d_uvuv, int64_t n, float* d_xyz4) {

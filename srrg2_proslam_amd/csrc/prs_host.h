@@ -17,6 +17,8 @@ struct prs_context {
   // reusable device scratch for the host-pointer entry points
   void* d_scratch       = nullptr;
   size_t d_scratch_size = 0;
+  void* d_slot[4]       = {nullptr, nullptr, nullptr, nullptr};  // kernel-owned scratch (candidates, ...)
+  size_t d_slot_size[4] = {0, 0, 0, 0};
   void* h_pinned        = nullptr;
   size_t h_pinned_size  = 0;
   // diagnostic phase stamps (PRS_STAMPS=1): never enabled in timed runs
@@ -38,12 +40,15 @@ inline bool ctx_force_unstaged(const prs_context* ctx) {
 // grows (never shrinks) the context's device scratch; returns nullptr on failure
 void* ctx_device_scratch(prs_context* ctx, size_t bytes);
 void* ctx_pinned_scratch(prs_context* ctx, size_t bytes);
+void* ctx_device_scratch_slot(prs_context* ctx, int slot, size_t bytes);
 // diagnostic: device buffer for phase stamps when PRS_STAMPS=1, else nullptr
 unsigned long long* ctx_stamps(prs_context* ctx, size_t bytes);
 // synchronises and prints mean per-phase cycle counts (n_stamps consecutive stamps per block)
 void ctx_report_stamps(prs_context* ctx, int blocks, int n_stamps, const char* legend);
 
 int stereo_match_batch_launch(prs_context* ctx, const prs_stereo_params* params, const prs_stereo_batch* batch);
+int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs_aligner_params* aligner, const prs_align_batch* batch, int mode);
+int gn_step_launch(prs_context* ctx, const float* dH, const float* db, float damping, float* dX, int* dok);
 int triangulate_launch(prs_context* ctx, const prs_triangulator_params* params, const float* d_uvuv, int64_t n, float* d_xyz4);
 
 } // namespace prs

@@ -1,0 +1,210 @@
+// prs_se3.h -- exact float SE(3) / 6x6 solver helpers for the aligner kernels.
+// Every expression is written as explicit two-operand operations in a fixed order and the library
+// is compiled with -ffp-contract=off; division and sqrt are IEEE correctly rounded (hipcc default),
+// so results are reproducible bit-for-bit against a plain sequential float evaluation.
+// 4x4 transforms are row-major float[16].
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace prs {
+
+__device__ __forceinline__ void se3_identity(float* T) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    T[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+  }
+}
+
+// Isometry inverse [R^T | -R^T t]
+__device__ __forceinline__ void se3_inverse(const float* T, float* Ti) {
+  const float tx = T[3], ty = T[7], tz = T[11];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float r0 = T[0 + i], r1 = T[4 + i], r2 = T[8 + i];  // row i of R^T
+    Ti[4 * i + 0]  = r0;
+    Ti[4 * i + 1]  = r1;
+    Ti[4 * i + 2]  = r2;
+    Ti[4 * i + 3]  = -((r0 * tx + r1 * ty) + r2 * tz);
+  }
+  Ti[12] = 0.0f;
+  Ti[13] = 0.0f;
+  Ti[14] = 0.0f;
+  Ti[15] = 1.0f;
+}
+
+// C = A * B (C must not alias A or B)
+__device__ __forceinline__ void se3_mul(const float* A, const float* B, float* C) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      C[4 * i + j] = (A[4 * i + 0] * B[0 + j] + A[4 * i + 1] * B[4 + j]) + A[4 * i + 2] * B[8 + j];
+    }
+    C[4 * i + 3] = ((A[4 * i + 0] * B[3] + A[4 * i + 1] * B[7]) + A[4 * i + 2] * B[11]) + A[4 * i + 3];
+  }
+  C[12] = 0.0f;
+  C[13] = 0.0f;
+  C[14] = 0.0f;
+  C[15] = 1.0f;
+}
+
+// geometry3d::t2tnq (srrg2_core): translation + imaginary part of the normalised quaternion, w >= 0
+// (used at CF/correspondence_finder_projective_base_impl.cpp:182)
+__device__ __forceinline__ void t2tnq(const float* T, float* v6) {
+  const float m00 = T[0], m01 = T[1], m02 = T[2];
+  const float m10 = T[4], m11 = T[5], m12 = T[6];
+  const float m20 = T[8], m21 = T[9], m22 = T[10];
+  float q0, q1, q2, q3;  // w x y z
+  float t = (m00 + m11) + m22;
+  if (t > 0.0f) {
+    t  = sqrtf(t + 1.0f);
+    q0 = 0.5f * t;
+    t  = 0.5f / t;
+    q1 = (m21 - m12) * t;
+    q2 = (m02 - m20) * t;
+    q3 = (m10 - m01) * t;
+  } else {
+    int i = 0;
+    if (m11 > m00) {
+      i = 1;
+    }
+    if (m22 > (i == 0 ? m00 : m11)) {
+      i = 2;
+    }
+    if (i == 0) {  // j = 1, k = 2
+      t  = sqrtf(((m00 - m11) - m22) + 1.0f);
+      q1 = 0.5f * t;
+      t  = 0.5f / t;
+      q0 = (m21 - m12) * t;
+      q2 = (m10 + m01) * t;
+      q3 = (m20 + m02) * t;
+    } else if (i == 1) {  // j = 2, k = 0
+      t  = sqrtf(((m11 - m22) - m00) + 1.0f);
+      q2 = 0.5f * t;
+      t  = 0.5f / t;
+      q0 = (m02 - m20) * t;
+      q3 = (m21 + m12) * t;
+      q1 = (m01 + m10) * t;
+    } else {  // j = 0, k = 1
+      t  = sqrtf(((m22 - m00) - m11) + 1.0f);
+      q3 = 0.5f * t;
+      t  = 0.5f / t;
+      q0 = (m10 - m01) * t;
+      q1 = (m02 + m20) * t;
+      q2 = (m12 + m21) * t;
+    }
+  }
+  const float n = sqrtf(((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3);
+  float s       = 1.0f / n;
+  if (q0 < 0.0f) {
+    s = -s;
+  }
+  v6[0] = T[3];
+  v6[1] = T[7];
+  v6[2] = T[11];
+  v6[3] = q1 * s;
+  v6[4] = q2 * s;
+  v6[5] = q3 * s;
+}
+
+// perturbation [dt; dq] -> isometry, q = (sqrt(1 - |dq|^2), dq) (VariableSE3QuaternionRight)
+__device__ __forceinline__ void tnq2t(const float* v6, float* T) {
+  float x = v6[3], y = v6[4], z = v6[5];
+  const float n2 = (x * x + y * y) + z * z;
+  float w;
+  if (n2 < 1.0f) {
+    w = sqrtf(1.0f - n2);
+  } else {
+    const float s = 1.0f / sqrtf(n2);
+    x *= s;
+    y *= s;
+    z *= s;
+    w = 0.0f;
+  }
+  const float tx = 2.0f * x, ty = 2.0f * y, tz = 2.0f * z;
+  const float twx = tx * w, twy = ty * w, twz = tz * w;
+  const float txx = tx * x, txy = ty * x, txz = tz * x;
+  const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  T[0]  = 1.0f - (tyy + tzz);
+  T[1]  = txy - twz;
+  T[2]  = txz + twy;
+  T[3]  = v6[0];
+  T[4]  = txy + twz;
+  T[5]  = 1.0f - (txx + tzz);
+  T[6]  = tyz - twx;
+  T[7]  = v6[1];
+  T[8]  = txz - twy;
+  T[9]  = tyz + twx;
+  T[10] = 1.0f - (txx + tyy);
+  T[11] = v6[2];
+  T[12] = 0.0f;
+  T[13] = 0.0f;
+  T[14] = 0.0f;
+  T[15] = 1.0f;
+}
+
+// (H + damping I) dx = -b by dense Cholesky; X <- X * exp(dx).  H: full 6x6 row-major (lower part
+// read), returns false (X untouched) when the system is not positive definite.
+__device__ __forceinline__ bool gn_step(const float* H, const float* b, float damping, float* X) {
+  float L[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float s = H[6 * j + j] + damping;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      if (k < j) {
+        s -= L[j][k] * L[j][k];
+      }
+    }
+    if (!(s > 0.0f)) {
+      return false;
+    }
+    L[j][j] = sqrtf(s);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (i > j) {
+        float v = H[6 * i + j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          if (k < j) {
+            v -= L[i][k] * L[j][k];
+          }
+        }
+        L[i][j] = v / L[j][j];
+      }
+    }
+  }
+  float y[6], dx[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float v = -b[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      if (k < i) {
+        v -= L[i][k] * y[k];
+      }
+    }
+    y[i] = v / L[i][i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    float v = y[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      if (k > i) {
+        v -= L[k][i] * dx[k];
+      }
+    }
+    dx[i] = v / L[i][i];
+  }
+  float D[16], Xn[16];
+  tnq2t(dx, D);
+  se3_mul(X, D, Xn);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    X[i] = Xn[i];
+  }
+  return true;
+}
+
+}  // namespace prs

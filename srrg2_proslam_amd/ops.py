@@ -170,3 +170,256 @@ def stereo_match_batch(ctx, params, frames, tri_params=None):
     rc = _lib.load().prs_stereo_match_batch(ctx._h, C.byref(params), C.byref(d))
     _check(ctx, rc, "prs_stereo_match_batch")
     return rc
+
+
+# =================================================================================================
+# projective correspondence finder + Gauss-Newton aligner
+# =================================================================================================
+from ._lib import AlignBatch, AlignerParams, AlignResult, PcfParams, PcfState, Projector  # noqa: E402
+
+
+def pcf_params(cfg, **overrides):
+    """prs_pcf_params from a configs.* dictionary (projective_finder + projector + camera)"""
+    cam, pr = cfg["camera"], cfg["projector"]
+    f = dict(cfg["projective_finder"])
+    f.update(overrides)
+    proj = Projector(cam["fx"], cam["fy"], cam["cx"], cam["cy"], int(cam["cols"]), int(cam["rows"]),
+                     pr["range_min"], pr["range_max"])
+    return PcfParams(f["maximum_descriptor_distance"], f["maximum_distance_ratio_to_second_best"],
+                     f["minimum_matching_ratio"], f["minimum_descriptor_distance"],
+                     f["descriptor_distance_step_size_pixels"], int(f["maximum_search_radius_pixels"]),
+                     int(f["minimum_search_radius_pixels"]), int(f["search_radius_step_size_pixels"]),
+                     int(f["minimum_number_of_iterations"]), f["maximum_estimate_change_norm_for_convergence"],
+                     int(f["number_of_solver_iterations_per_projection"]), int(f["search_type"]), proj)
+
+
+def aligner_params(cfg, mean_disparity=-1.0, stop_at_fixed_point=1, **overrides):
+    """prs_aligner_params from a configs.* dictionary; mean_disparity < 0 = computed on the device"""
+    cam, al = cfg["camera"], dict(cfg["aligner"])
+    al.update(overrides)
+    p = AlignerParams()
+    p.factor_type = int(al["factor_type"])
+    p.fx, p.fy, p.cx, p.cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+    p.image_cols, p.image_rows = cam["cols"], cam["rows"]
+    p.baseline_left_in_right_px[0] = -cam["fx"] * cam.get("baseline_m", 0.0)  # K * t_left_in_right
+    for i in range(3):
+        p.diagonal_info[i] = al["diagonal_info"][i]
+    p.chi_threshold = al["chi_threshold"]
+    p.enable_inverse_depth_weighting = int(al["enable_inverse_depth_weighting"])
+    p.mean_disparity = mean_disparity
+    p.damping = al["damping"]
+    p.max_iterations = int(al["max_iterations"])
+    p.min_num_inliers = int(al["min_num_inliers"])
+    p.min_num_correspondences = int(al["min_num_correspondences"])
+    p.stop_at_fixed_point = int(stop_at_fixed_point)
+    return p
+
+
+def info_scale_from_nopt(n_opt):
+    n_opt = np.ascontiguousarray(n_opt, dtype=np.uint32)
+    out = np.zeros(max(len(n_opt), 1), dtype=np.float32)
+    _lib.load().prs_info_scale_from_nopt(_p(n_opt), len(n_opt), _p(out))
+    return out[: len(n_opt)].copy()
+
+
+def gn_step(ctx, H, b, damping, X):
+    H, b = _np(H, np.float32, (36,)), _np(b, np.float32, (6,))
+    X = _np(X, np.float32, (16,)).copy()
+    rc = _lib.load().prs_gn_step(ctx._h, _p(H), _p(b), float(damping), _p(X))
+    _check(ctx, rc, "prs_gn_step")
+    return X.reshape(4, 4), rc
+
+
+class ProjectiveFinder:
+    """host-array handle mirroring CorrespondenceFinderProjective{KDTree,Square,Circle,Rhombus}:
+    set_fixed / set_moving / set_local_map_in_sensor / compute, state carried across calls"""
+
+    def __init__(self, ctx, params):
+        self.ctx = ctx
+        h = C.c_void_p()
+        _check(ctx, _lib.load().prs_pcf_create(ctx._h, C.byref(params), C.byref(h)), "prs_pcf_create")
+        self._h = h
+        self._n_fixed = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().prs_pcf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, params):
+        _check(self.ctx, _lib.load().prs_pcf_set_params(self._h, C.byref(params)), "prs_pcf_set_params")
+
+    def set_fixed(self, coords, desc):
+        coords = np.ascontiguousarray(coords, dtype=np.float32)
+        if coords.ndim != 2:
+            coords = coords.reshape(-1, 2)
+        d = _np(desc, np.uint8, (-1, 32))
+        self._n_fixed = coords.shape[0]
+        _check(self.ctx, _lib.load().prs_pcf_set_fixed(self._h, _p(coords), coords.shape[1], _p(d), coords.shape[0]), "prs_pcf_set_fixed")
+
+    def set_moving(self, xyz, desc, info_scale=None):
+        xyz = _np(xyz, np.float32, (-1, 3))
+        d = _np(desc, np.uint8, (-1, 32))
+        sc = None if info_scale is None else _np(info_scale, np.float32, (-1,))
+        _check(self.ctx, _lib.load().prs_pcf_set_moving(self._h, _p(xyz), None if sc is None else _p(sc), _p(d), xyz.shape[0]), "prs_pcf_set_moving")
+
+    def set_local_map_in_sensor(self, T):
+        T = _np(T, np.float32, (16,))
+        _check(self.ctx, _lib.load().prs_pcf_set_local_map_in_sensor(self._h, _p(T)), "prs_pcf_set_local_map_in_sensor")
+
+    def set_search_radius(self, r):
+        _check(self.ctx, _lib.load().prs_pcf_set_search_radius(self._h, int(r)), "prs_pcf_set_search_radius")
+
+    def set_descriptor_distance(self, d):
+        _check(self.ctx, _lib.load().prs_pcf_set_descriptor_distance(self._h, float(d)), "prs_pcf_set_descriptor_distance")
+
+    def state(self):
+        st = PcfState()
+        _check(self.ctx, _lib.load().prs_pcf_get_state(self._h, C.byref(st)), "prs_pcf_get_state")
+        return st
+
+    @property
+    def search_radius(self):
+        return int(self.state().search_radius_pixels)
+
+    @property
+    def descriptor_distance(self):
+        return float(self.state().descriptor_distance)
+
+    @property
+    def iteration(self):
+        return int(self.state().current_iteration)
+
+    @property
+    def has_converged(self):
+        return bool(self.state().has_converged)
+
+    @property
+    def num_recomputes(self):
+        return int(self.state().num_recomputes)
+
+    def local_map_in_sensor(self):
+        return np.array(self.state().local_map_in_sensor, dtype=np.float32).reshape(4, 4)
+
+    def compute(self):
+        out = np.zeros(max(self._n_fixed, 1), dtype=CORR_DTYPE)
+        n = C.c_int32(0)
+        rc = _lib.load().prs_pcf_compute(self._h, _p(out), out.shape[0], C.byref(n))
+        _check(self.ctx, rc, "prs_pcf_compute")
+        return out[: n.value].copy(), rc
+
+    def align(self, params, X_init, prior=None):
+        """the whole per-frame loop; returns (X [4,4], correspondences, prs_align_result, warnings)"""
+        X0 = _np(X_init, np.float32, (16,))
+        X = np.zeros(16, dtype=np.float32)
+        out = np.zeros(max(self._n_fixed, 1), dtype=CORR_DTYPE)
+        n = C.c_int32(0)
+        res = AlignResult()
+        pr = None if prior is None else _np(np.concatenate([np.ravel(prior[0]), np.ravel(prior[1])]), np.float32, (42,))
+        rc = _lib.load().prs_pcf_align(self._h, C.byref(params), _p(X0), None if pr is None else _p(pr), _p(X), _p(out), out.shape[0], C.byref(n), C.byref(res))
+        _check(self.ctx, rc, "prs_pcf_align")
+        return X.reshape(4, 4), out[: n.value].copy(), res, rc
+
+    def linearize(self, params, X, corr):
+        X = _np(X, np.float32, (16,))
+        corr = np.ascontiguousarray(corr, dtype=CORR_DTYPE)
+        res = AlignResult()
+        rc = _lib.load().prs_pcf_linearize(self._h, C.byref(params), _p(X), _p(corr), len(corr), C.byref(res))
+        _check(self.ctx, rc, "prs_pcf_linearize")
+        return res
+
+
+class AlignFrames:
+    """B independent frames (sequences) resident in HBM for the fused finder + aligner kernel"""
+
+    def __init__(self, device, batch, fixed_stride, moving_stride, with_prior=False):
+        import torch
+        dev = torch.device("cuda", device)
+        self.batch, self.fixed_stride, self.moving_stride = int(batch), int(fixed_stride), int(moving_stride)
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+        self.fixed = z((batch, fixed_stride, 4), torch.float32)
+        self.fixed_desc = z((batch, fixed_stride, 32), torch.uint8)
+        self.n_fixed = z((batch,), torch.int32)
+        self.moving = z((batch, moving_stride, 4), torch.float32)
+        self.moving_desc = z((batch, moving_stride, 32), torch.uint8)
+        self.n_moving = z((batch,), torch.int32)
+        self.inputs_changed = torch.ones((batch,), dtype=torch.uint8, device=dev)
+        self.state = z((batch, C.sizeof(PcfState)), torch.uint8)
+        self.X = z((batch, 16), torch.float32)
+        self.corr = z((batch, fixed_stride, 3), torch.int32)
+        self.n_corr = z((batch,), torch.int32)
+        self.result = z((batch, C.sizeof(AlignResult)), torch.uint8)
+        self.prior = z((batch, 42), torch.float32) if with_prior else None
+        self.reset_state()
+
+    def reset_state(self):
+        """fresh finder objects: zeroed dynamic thresholds, config_changed = 1, identity transforms"""
+        import torch
+        st = PcfState()
+        st.config_changed = 1
+        for i in (0, 5, 10, 15):
+            st.local_map_in_sensor[i] = 1.0
+            st.local_map_in_sensor_previous[i] = 1.0
+        raw = np.frombuffer(bytes(st), dtype=np.uint8)
+        self.state[:] = torch.from_numpy(raw.copy()).to(self.state.device)
+        self.n_corr.zero_()
+
+    def upload(self, b, fixed, fixed_desc, moving_xyz, info_scale, moving_desc, X_init):
+        import torch
+        fixed = np.ascontiguousarray(fixed, dtype=np.float32)
+        nf, nm = fixed.shape[0], len(moving_xyz)
+        f4 = np.zeros((nf, 4), dtype=np.float32)
+        f4[:, : fixed.shape[1]] = fixed
+        m4 = np.ones((nm, 4), dtype=np.float32)
+        m4[:, :3] = moving_xyz
+        if info_scale is not None:
+            m4[:, 3] = info_scale
+        if nf:
+            self.fixed[b, :nf] = torch.from_numpy(f4)
+            self.fixed_desc[b, :nf] = torch.from_numpy(np.ascontiguousarray(fixed_desc, dtype=np.uint8))
+        if nm:
+            self.moving[b, :nm] = torch.from_numpy(m4)
+            self.moving_desc[b, :nm] = torch.from_numpy(np.ascontiguousarray(moving_desc, dtype=np.uint8))
+        self.n_fixed[b] = nf
+        self.n_moving[b] = nm
+        self.X[b] = torch.from_numpy(np.ascontiguousarray(X_init, dtype=np.float32).reshape(16))
+
+    def descriptor(self):
+        d = AlignBatch()
+        d.batch, d.fixed_stride, d.moving_stride = self.batch, self.fixed_stride, self.moving_stride
+        d.fixed, d.fixed_desc, d.n_fixed = self.fixed.data_ptr(), self.fixed_desc.data_ptr(), self.n_fixed.data_ptr()
+        d.moving, d.moving_desc, d.n_moving = self.moving.data_ptr(), self.moving_desc.data_ptr(), self.n_moving.data_ptr()
+        d.inputs_changed, d.state, d.X = self.inputs_changed.data_ptr(), self.state.data_ptr(), self.X.data_ptr()
+        d.corr, d.n_corr, d.result = self.corr.data_ptr(), self.n_corr.data_ptr(), self.result.data_ptr()
+        d.prior = self.prior.data_ptr() if self.prior is not None else None
+        return d
+
+    def result_of(self, b):
+        raw = self.result[b].cpu().numpy().tobytes()
+        return AlignResult.from_buffer_copy(raw)
+
+    def state_of(self, b):
+        raw = self.state[b].cpu().numpy().tobytes()
+        return PcfState.from_buffer_copy(raw)
+
+    def corr_of(self, b):
+        n = int(self.n_corr[b].item())
+        raw = self.corr[b, :n].cpu().numpy()
+        out = np.zeros(n, dtype=CORR_DTYPE)
+        out["fixed_idx"], out["moving_idx"] = raw[:, 0], raw[:, 1]
+        out["response"] = raw[:, 2].view(np.float32)
+        return out
+
+
+def align_batch(ctx, finder_params, aligner_params_, frames, mode=_lib.MODE_ALIGN):
+    """enqueue the fused finder + aligner kernel on the context stream (asynchronous)"""
+    d = frames.descriptor()
+    rc = _lib.load().prs_align_batch_run(ctx._h, C.byref(finder_params), C.byref(aligner_params_), C.byref(d), int(mode))
+    _check(ctx, rc, "prs_align_batch_run")
+    return rc

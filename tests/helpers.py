@@ -31,3 +31,102 @@ def oracle_tri_params(ob, cfg):
     cam, tri = cfg["camera"], cfg["triangulator"]
     return ob.TriangulatorParams(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["fx"] * cam["baseline_m"],
                                  tri["minimum_disparity_pixels"], tri["infinity_depth_meters"])
+
+
+# ---- SyntheticWorld restatement (srrg_test/synthetic_world.hpp, used at tests/test_correspondence_finders.cpp:690-739)
+def synthetic_world(seed=0, n=100, mean=(10, 10, 10), dev=(5, 5, 5)):
+    """100 world points ~ N(mean, dev) with unique random descriptors; K=(200,200,100,100), canvas 1000x1000"""
+    rng = np.random.default_rng(seed)
+    pts = rng.normal(mean, dev, (n, 3)).astype(np.float32)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    K = {"fx": 200.0, "fy": 200.0, "cx": 100.0, "cy": 100.0, "cols": 1000, "rows": 1000}
+    return pts, desc, K
+
+
+def project_points(K, pts_cam, range_min=0.1, range_max=1000.0):
+    """pinhole projection + visibility; returns (uvz of visible, indices)"""
+    z = pts_cam[:, 2]
+    u = K["fx"] * pts_cam[:, 0] / z + K["cx"]
+    v = K["fy"] * pts_cam[:, 1] / z + K["cy"]
+    ok = (z >= range_min) & (z <= range_max) & (u >= 0) & (u < K["cols"]) & (v >= 0) & (v < K["rows"])
+    idx = np.nonzero(ok)[0]
+    return np.stack([u[idx], v[idx], z[idx]], axis=1).astype(np.float32), idx
+
+
+def pcf_params(ob, K, search_type, range_min=0.1, range_max=1000.0, **kw):
+    d = dict(maximum_descriptor_distance=75.0, maximum_distance_ratio_to_second_best=0.5, minimum_matching_ratio=0.25,
+             minimum_descriptor_distance=25.0, descriptor_distance_step_size_pixels=5.0,
+             maximum_search_radius_pixels=100, minimum_search_radius_pixels=10, search_radius_step_size_pixels=5,
+             minimum_number_of_iterations=10, maximum_estimate_change_norm_for_convergence=1e-5,
+             number_of_solver_iterations_per_projection=25)  # defaults of projective_base.h:30-74 / bruteforce.h:22-36
+    d.update(kw)
+    proj = ob.Projector(K["fx"], K["fy"], K["cx"], K["cy"], int(K["cols"]), int(K["rows"]), range_min, range_max)
+    return ob.PcfParams(d["maximum_descriptor_distance"], d["maximum_distance_ratio_to_second_best"],
+                        d["minimum_matching_ratio"], d["minimum_descriptor_distance"],
+                        d["descriptor_distance_step_size_pixels"], d["maximum_search_radius_pixels"],
+                        d["minimum_search_radius_pixels"], d["search_radius_step_size_pixels"],
+                        d["minimum_number_of_iterations"], d["maximum_estimate_change_norm_for_convergence"],
+                        d["number_of_solver_iterations_per_projection"], search_type, proj)
+
+
+def pcf_params_from_cfg(ob, cfg, **kw):
+    cam = cfg["camera"]
+    K = {"fx": cam["fx"], "fy": cam["fy"], "cx": cam["cx"], "cy": cam["cy"], "cols": cam["cols"], "rows": cam["rows"]}
+    f = dict(cfg["projective_finder"])
+    st = f.pop("search_type")
+    f.update(kw)
+    st = f.pop("search_type", st)
+    return pcf_params(ob, K, st, cfg["projector"]["range_min"], cfg["projector"]["range_max"], **f)
+
+
+def aligner_params(ob, cfg, mean_disparity=0.0, **kw):
+    cam, al = cfg["camera"], dict(cfg["aligner"])
+    al.update(kw)
+    p = ob.AlignerParams()
+    p.factor_type = al["factor_type"]
+    p.fx, p.fy, p.cx, p.cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+    p.image_cols, p.image_rows = cam["cols"], cam["rows"]
+    p.baseline_left_in_right_px[0] = -cam["fx"] * cam.get("baseline_m", 0.0)  # K * t_left_in_right
+    p.baseline_left_in_right_px[1] = 0.0
+    p.baseline_left_in_right_px[2] = 0.0
+    for i in range(3):
+        p.diagonal_info[i] = al["diagonal_info"][i]
+    p.chi_threshold = al["chi_threshold"]
+    p.enable_inverse_depth_weighting = al["enable_inverse_depth_weighting"]
+    p.mean_disparity = mean_disparity
+    p.damping = al["damping"]
+    p.max_iterations = al["max_iterations"]
+    p.min_num_inliers = al["min_num_inliers"]
+    p.min_num_correspondences = al["min_num_correspondences"]
+    return p
+
+
+def rel_frobenius(A, B):
+    A, B = np.asarray(A, np.float64), np.asarray(B, np.float64)
+    return np.linalg.norm(A - B) / np.linalg.norm(B)
+
+
+def make_align_case(cfg_name, seed, n_kp=600, n_moving=600, sigma_t=0.05, sigma_r=0.003):
+    """fixed cloud + local map + truth + initial guess for one frame of config cfg_name"""
+    cfg = configs.get(cfg_name)
+    rng = np.random.default_rng(seed)
+    if cfg["aligner"]["factor_type"] == 4:
+        fr = syn.stereo_frame(rng, cfg, n_kp, visible_fraction=0.6)
+        lm_l = {int(l): i for i, l in enumerate(fr["lm_of_left"]) if l >= 0}
+        lm_r = {int(l): i for i, l in enumerate(fr["lm_of_right"]) if l >= 0}
+        common = sorted(set(lm_l) & set(lm_r))
+        fixed = np.array([[*fr["uv_left"][lm_l[l]], *fr["uv_right"][lm_r[l]]] for l in common], np.float32)
+        dfix = np.array([fr["desc_left"][lm_l[l]] for l in common], np.uint8)
+        # a few outlier measurements
+        n_out = max(len(common) // 8, 1)
+        fo = np.stack([rng.integers(100, cfg["camera"]["cols"], n_out), rng.integers(0, cfg["camera"]["rows"], n_out)], axis=1).astype(np.float32)
+        fixed = np.concatenate([fixed, np.concatenate([fo, fo - np.array([[rng.integers(1, 60), 0]])], axis=1).astype(np.float32)])
+        dfix = np.concatenate([dfix, syn.random_descriptors(rng, n_out)])
+        frame = fr
+    else:
+        fr = syn.rgbd_frame(rng, cfg, n_kp)
+        fixed, dfix, frame = fr["fixed"], fr["desc_fixed"], fr
+    T = syn.default_motion(rng, cfg)
+    mp = syn.local_map(rng, cfg, frame, T, n_moving=n_moving)
+    X0 = syn.perturb(rng, T, sigma_t, sigma_r)
+    return cfg, fixed, dfix, mp, T.astype(np.float32), X0
