@@ -279,6 +279,9 @@ typedef struct {
   int32_t* n_corr;               /* [batch] in/out */
   prs_align_result* result;      /* [batch] */
   const float* prior;            /* optional [batch][42]: additive H0 (36) and b0 (6) (motion-model slice) */
+  int32_t max_fixed;             /* 0 = fixed_stride; else an upper bound on n_fixed[] the kernel sizes its LDS
+                                    for (fewer bytes per frame = more frames per CU); a frame exceeding it
+                                    gets PRS_ERR_CAPACITY in result[].warnings */
 } prs_align_batch;
 
 PRS_API int prs_align_batch_run(prs_context* ctx,

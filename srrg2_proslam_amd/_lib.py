@@ -158,6 +158,7 @@ class AlignBatch(C.Structure):
         ("moving", C.c_void_p), ("moving_desc", C.c_void_p), ("n_moving", C.c_void_p),
         ("inputs_changed", C.c_void_p), ("state", C.c_void_p), ("X", C.c_void_p),
         ("corr", C.c_void_p), ("n_corr", C.c_void_p), ("result", C.c_void_p), ("prior", C.c_void_p),
+        ("max_fixed", C.c_int32),
     ]
 
 

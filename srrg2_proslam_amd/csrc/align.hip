@@ -65,7 +65,12 @@ struct AlignArgs {
   int rows_table;  // R = projector canvas rows (lattice row table extent)
   int lut_cap;     // entries of the circle width table
   uint2* cand;     // scratch [batch][moving_stride]
-  uint32_t off_db, off_fuv, off_rowfirst, off_best, off_second, off_lut, off_cfix, off_cmov, off_terms, off_sh;
+  unsigned long long* stamps;  // diagnostic: [batch][16] accumulated shader clocks per phase (NULL = off)
+  int max_fixed;   // LDS capacity in fixed points (frames with more are rejected loudly)
+  uint32_t off_db, off_rowfirst, off_cfix, off_cmov, off_sh;  // persistent for the whole frame loop
+  uint32_t off_u;                                              // phase-exclusive union region:
+  uint32_t off_fdesc, off_fuv, off_best, off_second, off_lut;  //   search phase (relative to the LDS base)
+  uint32_t off_terms;                                          //   GN phase / database build / disparity column
 };
 
 enum { kDecisionCommit = 0, kDecisionRetry = 1, kDecisionReturn = 2 };
@@ -117,14 +122,15 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
   prs_align_result* gres          = g.b.result + frame;
 
   uint2* db           = reinterpret_cast<uint2*>(smem + g.off_db);        // row-sorted lattice: x = row | col << 16, y = fixed index
-  float2* fuv         = reinterpret_cast<float2*>(smem + g.off_fuv);      // fixed (u,v) in index order (KD-tree variant)
   uint16_t* rowfirst  = reinterpret_cast<uint16_t*>(smem + g.off_rowfirst);
+  float4* cfix        = reinterpret_cast<float4*>(smem + g.off_cfix);      // per-correspondence fixed measurement
+  float4* cmov        = reinterpret_cast<float4*>(smem + g.off_cmov);      // per-correspondence moving point + information scale
+  au32x4* fdesc       = reinterpret_cast<au32x4*>(smem + g.off_fdesc);    // fixed descriptor rows (search phase only)
+  float2* fuv         = reinterpret_cast<float2*>(smem + g.off_fuv);      // fixed (u,v) in index order (KD-tree variant)
   uint32_t* bestkey   = reinterpret_cast<uint32_t*>(smem + g.off_best);
   uint32_t* second    = reinterpret_cast<uint32_t*>(smem + g.off_second);
   uint16_t* lut       = reinterpret_cast<uint16_t*>(smem + g.off_lut);
-  float4* cfix        = reinterpret_cast<float4*>(smem + g.off_cfix);
-  float4* cmov        = reinterpret_cast<float4*>(smem + g.off_cmov);
-  float* terms        = reinterpret_cast<float*>(smem + g.off_terms);
+  float* terms        = reinterpret_cast<float*>(smem + g.off_terms);     // aliases the search-phase arrays
   AlignShared& sh     = *reinterpret_cast<AlignShared*>(smem + g.off_sh);
   const int R         = g.rows_table;
   const int stype     = g.f.search_type;
@@ -154,6 +160,9 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
     if (sh.n_corr < 0 || sh.n_corr > nF) {
       sh.n_corr = 0;
     }
+    if (nF > g.max_fixed) {
+      sh.error = PRS_ERR_CAPACITY;  // the caller's max_fixed hint was too small for this frame
+    }
   }
   for (int i = tid; i < 36; i += kAlignThreads) {
     sh.H[i] = 0.0f;
@@ -176,7 +185,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
   // ---- bindFixed: mean disparity over ALL fixed points, sequential float sum -------------------
   // (aligner_slice_processor_projective.cpp:80-88)
   if (g.mode != PRS_MODE_FINDER && g.a.factor_type == PRS_FACTOR_STEREO && g.a.enable_inverse_depth_weighting &&
-      g.a.mean_disparity < 0.0f) {
+      g.a.mean_disparity < 0.0f && !sh.error) {
     for (int i = tid; i < nF; i += kAlignThreads) {
       const float4 c = gfix[i];
       terms[i]       = c.x - c.z;
@@ -184,7 +193,15 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
     __syncthreads();
     if (tid == 0) {
       float acc = 0.0f;
-      for (int i = 0; i < nF; ++i) {
+      int i     = 0;
+      for (; i + 4 <= nF; i += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(terms + i);
+        acc += q.x;
+        acc += q.y;
+        acc += q.z;
+        acc += q.w;
+      }
+      for (; i < nF; ++i) {
         acc += terms[i];
       }
       sh.mean_disp = nF > 0 ? acc / (float) (size_t) nF : 0.0f;
@@ -194,7 +211,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
 
   // the caller-owned correspondence vector persists across calls: "nothing new" finder calls keep
   // using it, and linearize-only calls receive it as input
-  if (g.mode != PRS_MODE_FINDER) {
+  if (g.mode != PRS_MODE_FINDER && !sh.error) {
     for (int c = tid; c < sh.n_corr; c += kAlignThreads) {
       const prs_corr cr = gcorr[c];
       if (cr.fixed_idx < 0 || cr.fixed_idx >= nF || cr.moving_idx < 0 || cr.moving_idx >= nM) {
@@ -207,6 +224,9 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
     __syncthreads();
   }
 
+  unsigned long long acc_finder = 0, acc_lin = 0, acc_sum = 0, acc_solve = 0, t_mark = 0;
+#define ALIGN_MARK() (t_mark = (g.stamps && tid == 0) ? (unsigned long long) clock64() : 0ull)
+#define ALIGN_ACC(v) do { if (g.stamps && tid == 0) { v += (unsigned long long) clock64() - t_mark; } } while (0)
   const int max_it = (g.mode == PRS_MODE_ALIGN && !sh.error) ? g.a.max_iterations : (sh.error ? 0 : 1);
   int executed     = 0;
   int it_align     = 0;
@@ -215,6 +235,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
     // ============================================================================================
     // finder.setLocalMapInSensor(X); finder.compute()
     // ============================================================================================
+    ALIGN_MARK();
     if (g.mode != PRS_MODE_LINEARIZE) {
       if (tid < 16) {
         sh.T[tid] = sh.X[tid];
@@ -286,7 +307,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
         // _initializeDatabase (square_impl.cpp:8-31), stable by row: canonical tie order
         uint32_t* hist   = reinterpret_cast<uint32_t*>(terms);
         uint16_t* slot   = reinterpret_cast<uint16_t*>(hist + (R + 2));
-        uint16_t* bucket = slot + g.b.fixed_stride + 2;
+        uint16_t* bucket = slot + g.max_fixed + 2;
         for (int i = tid; i <= R; i += kAlignThreads) {
           hist[i] = 0;
         }
@@ -294,7 +315,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
         for (int i = tid; i < nF; i += kAlignThreads) {
           const float4 c = gfix[i];
           if (!lattice) {
-            fuv[i] = make_float2(c.x, c.y);
+            // KD-tree variant: nothing to sort, (u,v) are loaded with the descriptors before every search
           } else if (c.x >= 0.0f && c.x < 32767.0f && c.y >= 0.0f && c.y < (float) R) {
             const int row = (int) (int16_t) c.y;  // Element(coordinates(1), coordinates(0), i)
             slot[i]       = (uint16_t) atomicAdd(&hist[row], 1u);
@@ -361,6 +382,15 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
           bestkey[i] = kNoneU32;
           second[i]  = kNoneU32;
         }
+        for (int i = tid; i < 2 * nF; i += kAlignThreads) {
+          fdesc[i] = gfd[i];  // coalesced 16 B/lane; the rows are re-read ~10x per query from LDS
+        }
+        if (!lattice) {
+          for (int i = tid; i < nF; i += kAlignThreads) {
+            const float4 c = gfix[i];
+            fuv[i]         = make_float2(c.x, c.y);
+          }
+        }
         if (stype == PRS_SEARCH_CIRCLE) {
           // width = int(sqrt(r^2 - h^2) + 1) per row offset h (circle_impl.cpp:51-53), exact in integers
           for (int i = tid; i < 2 * rad + 1 && i < g.lut_cap; i += kAlignThreads) {
@@ -407,28 +437,41 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
                 const int cmax  = (int) (int16_t) (col + rad + 1);  // square_impl.cpp:57
                 const int start = rowfirst[rmin < 0 ? 0 : (rmin > R ? R : rmin)];
                 const int end   = rowfirst[rmax < 0 ? 0 : (rmax > R ? R : rmax)];
-                for (int pos = start; pos < end; ++pos) {
-                  const uint2 e  = db[pos];
-                  const int drow = (int) (int16_t) (e.x & 0xffffu);
-                  const int dcol = (int) (int16_t) (e.x >> 16);
-                  bool accept;
-                  if (stype == PRS_SEARCH_SQUARE) {
-                    accept = dcol > cmin && dcol < cmax;  // square_impl.cpp:80
-                  } else if (stype == PRS_SEARCH_CIRCLE) {
-                    const int h     = drow - row;
-                    const int li    = h + rad;
-                    const int width = li < g.lut_cap ? (int) lut[li] : isqrt_exact(rad * rad - h * h) + 1;
-                    accept          = dcol > col - width && dcol < col + width;  // circle_impl.cpp:56
-                  } else {
-                    int width = (int) (int16_t) (drow - rmin + 1);  // rhombus_impl.cpp:49-52
-                    if (width > (int) (int16_t) rad) {
-                      width = (int) (int16_t) (rmax - drow);
-                    }
-                    accept = dcol > col - width && dcol < col + width;
+                // the lattice is scanned four entries at a time: the four LDS reads (and the four
+                // width-table reads) are independent, and the descriptor scoring below runs once per
+                // group for each lane's pending candidate instead of once per entry
+                for (int pos = start; pos < end; pos += 4) {
+                  uint2 e[4];
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) {
+                    e[k] = db[pos + k < end ? pos + k : end - 1];
                   }
-                  if (accept) {
-                    const int fi  = (int) e.y;
-                    const float d = (float) hamming_regs(gfd[2 * fi], gfd[2 * fi + 1], q0, q1);
+                  uint32_t mask = 0;
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) {
+                    const int drow = (int) (int16_t) (e[k].x & 0xffffu);
+                    const int dcol = (int) (int16_t) (e[k].x >> 16);
+                    bool accept;
+                    if (stype == PRS_SEARCH_SQUARE) {
+                      accept = dcol > cmin && dcol < cmax;  // square_impl.cpp:80
+                    } else if (stype == PRS_SEARCH_CIRCLE) {
+                      const int h     = drow - row;
+                      const int li    = h + rad;
+                      const int width = li < g.lut_cap ? (int) lut[li] : isqrt_exact(rad * rad - h * h) + 1;
+                      accept          = dcol > col - width && dcol < col + width;  // circle_impl.cpp:56
+                    } else {
+                      int width = (int) (int16_t) (drow - rmin + 1);  // rhombus_impl.cpp:49-52
+                      if (width > (int) (int16_t) rad) {
+                        width = (int) (int16_t) (rmax - drow);
+                      }
+                      accept = dcol > col - width && dcol < col + width;
+                    }
+                    mask |= (accept && pos + k < end) ? (1u << k) : 0u;
+                  }
+                  while (mask) {  // ascending k = lattice order: first-wins tie-breaks are preserved
+                    const int fi = (mask & 1u) ? (int) e[0].y : ((mask & 2u) ? (int) e[1].y : ((mask & 4u) ? (int) e[2].y : (int) e[3].y));
+                    mask &= mask - 1u;
+                    const float d = (float) hamming_regs(fdesc[2 * fi], fdesc[2 * fi + 1], q0, q1);
                     if (d < best) {  // circle_impl.cpp:64-72
                       sec   = best;
                       isec  = ibest;
@@ -455,7 +498,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
                   if (du * du + dv * dv > r2f) {
                     continue;
                   }
-                  const float d = (float) hamming_regs(gfd[2 * fi], gfd[2 * fi + 1], q0, q1);
+                  const float d = (float) hamming_regs(fdesc[2 * fi], fdesc[2 * fi + 1], q0, q1);
                   if (d < best) {  // :62-68
                     sec   = best;
                     best  = d;
@@ -613,6 +656,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
       }
       __syncthreads();
     }
+    ALIGN_ACC(acc_finder);
     if (g.mode == PRS_MODE_FINDER) {
       break;
     }
@@ -653,6 +697,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
       float run = 0.0f;  // lanes 0..28 of wave 0: running sum of their term in correspondence order
       __syncthreads();
       for (int c0 = 0; c0 < nc; c0 += kAlignThreads) {
+        ALIGN_MARK();
         const int c = c0 + tid;
         float tv[kTerms];
 #pragma unroll
@@ -758,15 +803,33 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
           terms[t * kAlignThreads + tid] = tv[t];
         }
         __syncthreads();
+        ALIGN_ACC(acc_lin);
+        ALIGN_MARK();
         // sequential accumulation in correspondence order, one lane per normal-equation entry
         if (tid < kTerms) {
-          const int cnt     = nc - c0 < kAlignThreads ? nc - c0 : kAlignThreads;
-          const float* row  = terms + tid * kAlignThreads;
-          for (int j = 0; j < cnt; ++j) {
-            run += row[j];
+          // entries past the last correspondence hold +0.0f and x + 0.0f == x bit-for-bit (the running
+          // sums are never -0.0f), so whole 16-entry groups are added: 4 x 16-byte LDS reads in
+          // flight, then 16 dependent adds in correspondence order
+          const int cnt      = nc - c0 < kAlignThreads ? nc - c0 : kAlignThreads;
+          const float4* row4 = reinterpret_cast<const float4*>(terms + tid * kAlignThreads);
+          float4 n0 = row4[0], n1 = row4[1], n2 = row4[2], n3 = row4[3];
+          for (int j = 0; j < cnt; j += 16) {
+            const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
+            if (j + 16 < cnt) {  // next group's reads fly while this group's dependent adds retire
+              const int k = (j >> 2) + 4;
+              n0 = row4[k];
+              n1 = row4[k + 1];
+              n2 = row4[k + 2];
+              n3 = row4[k + 3];
+            }
+            run += q0.x; run += q0.y; run += q0.z; run += q0.w;
+            run += q1.x; run += q1.y; run += q1.z; run += q1.w;
+            run += q2.x; run += q2.y; run += q2.z; run += q2.w;
+            run += q3.x; run += q3.y; run += q3.z; run += q3.w;
           }
         }
         __syncthreads();
+        ALIGN_ACC(acc_sum);
       }
       if (tid < kTerms) {
         if (tid < 21) {
@@ -793,6 +856,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
       break;
     }
     // ---- damped GN step on one lane (IterationAlgorithmGN + dense Cholesky + X <- X * exp(dx)) ---
+    ALIGN_MARK();
     if (tid == 0) {
       float H[36], b[6], X[16];
 #pragma unroll
@@ -829,6 +893,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
       sh.decision = (g.a.stop_at_fixed_point && same && sh.converged) ? 1 : 0;
     }
     __syncthreads();
+    ALIGN_ACC(acc_solve);
     if (sh.decision) {
       ++it_align;
       break;
@@ -867,6 +932,14 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
     gres->iterations             = g.mode == PRS_MODE_ALIGN ? g.a.max_iterations : 1;
     gres->iterations_executed    = executed;
     gres->warnings               = sh.error ? sh.error : sh.flags;
+    if (g.stamps) {
+      unsigned long long* st = g.stamps + (size_t) frame * 16;
+      st[0] = 0;
+      st[1] = acc_finder;
+      st[2] = acc_finder + acc_lin;
+      st[3] = acc_finder + acc_lin + acc_sum;
+      st[4] = acc_finder + acc_lin + acc_sum + acc_solve;
+    }
   }
 }
 
@@ -922,7 +995,9 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   g.b          = *batch;
   g.mode       = mode;
   g.rows_table = finder->projector.canvas_rows;
-  const uint32_t nf = (uint32_t) batch->fixed_stride;
+  const int max_fixed = batch->max_fixed > 0 && batch->max_fixed < batch->fixed_stride ? batch->max_fixed : batch->fixed_stride;
+  g.max_fixed       = max_fixed;
+  const uint32_t nf = (uint32_t) max_fixed;
   const uint32_t R  = (uint32_t) g.rows_table;
   uint32_t lut_cap  = 2u * (uint32_t) finder->maximum_search_radius_pixels + 1u;
   if (lut_cap > 2048u) {
@@ -931,28 +1006,34 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   g.lut_cap = (int) lut_cap;
   uint32_t off = 0;
   g.off_db       = off; off = align_up16(off + nf * 8);
-  g.off_fuv      = off; off = align_up16(off + (finder->search_type == PRS_SEARCH_KDTREE ? nf * 8 : 0));
   g.off_rowfirst = off; off = align_up16(off + (R + 2) * 2);
-  g.off_best     = off; off = align_up16(off + nf * 4);
-  g.off_second   = off; off = align_up16(off + nf * 4);
-  g.off_lut      = off; off = align_up16(off + lut_cap * 2);
   g.off_cfix     = off; off = align_up16(off + nf * 16);
   g.off_cmov     = off; off = align_up16(off + nf * 16);
-  // terms region doubles as the database-build scratch (hist + slot + bucket) and the disparity column
-  uint32_t terms_bytes = kTerms * kAlignThreads * 4;
+  g.off_sh       = off; off = align_up16(off + (uint32_t) sizeof(AlignShared));
+  g.off_u        = off;
+  // search-phase arrays
+  uint32_t u = off;
+  g.off_fdesc  = u; u = align_up16(u + nf * 32);
+  g.off_fuv    = u; u = align_up16(u + (finder->search_type == PRS_SEARCH_KDTREE ? nf * 8 : 0));
+  g.off_best   = u; u = align_up16(u + nf * 4);
+  g.off_second = u; u = align_up16(u + nf * 4);
+  g.off_lut    = u; u = align_up16(u + lut_cap * 2);
+  // GN-phase terms; the region also serves the database build (hist + slot + bucket) and the disparity column
+  g.off_terms = off;
+  uint32_t terms_bytes       = kTerms * kAlignThreads * 4;
   const uint32_t build_bytes = (R + 2) * 4 + (nf + 2) * 2 * 2 + 16;
   if (build_bytes > terms_bytes) {
     terms_bytes = build_bytes;
   }
-  if (nf * 4 > terms_bytes) {
-    terms_bytes = nf * 4;
+  if (nf * 4 + 16 > terms_bytes) {
+    terms_bytes = nf * 4 + 16;
   }
-  g.off_terms = off; off = align_up16(off + terms_bytes);
-  g.off_sh    = off; off = align_up16(off + (uint32_t) sizeof(AlignShared));
-  const size_t lds = off;
+  const uint32_t t_end = align_up16(off + terms_bytes);
+  const size_t lds     = u > t_end ? u : t_end;
   if (lds > 160 * 1024) {
-    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_run: fixed cloud does not fit the 160 KiB LDS");
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_run: fixed cloud does not fit the 160 KiB LDS (lower max_fixed)");
   }
+  g.stamps = ctx_stamps(ctx, (size_t) batch->batch * 16 * sizeof(unsigned long long));
   g.cand = static_cast<uint2*>(ctx_device_scratch_slot(ctx, 1, (size_t) batch->batch * (size_t) batch->moving_stride * sizeof(uint2)));
   if (!g.cand) {
     return ctx_fail(ctx, PRS_ERR_HIP, "prs_align_batch_run: candidate scratch allocation failed");
@@ -965,6 +1046,9 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   e = hipGetLastError();
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_align_batch_run launch");
+  }
+  if (g.stamps) {
+    ctx_report_stamps(ctx, batch->batch, 5, "align: finder | linearize | sequential sums | GN solve  (cycles accumulated over the frame loop)");
   }
   return PRS_OK;
 }

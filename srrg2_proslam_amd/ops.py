@@ -5,6 +5,7 @@ call into libproslam_hip.so.  Host-array entry points mirror what a srrg2 plugin
 once per compute(); `*_batch` entry points keep B independent frames resident in HBM.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -33,9 +34,12 @@ class Context:
             raise ProslamHipError(rc, "prs_context_create(device=%d): %s" % (device, lib.prs_status_string(rc).decode()))
         self._h = h
         self.device = int(device)
+        self._children = weakref.WeakSet()  # handles that hold a pointer to this context
 
     def close(self):
         if getattr(self, "_h", None):
+            for child in list(self._children):  # a finder handle must never outlive its context
+                child.close()
             _lib.load().prs_context_destroy(self._h)
             self._h = None
 
@@ -240,10 +244,12 @@ class ProjectiveFinder:
         _check(ctx, _lib.load().prs_pcf_create(ctx._h, C.byref(params), C.byref(h)), "prs_pcf_create")
         self._h = h
         self._n_fixed = 0
+        ctx._children.add(self)
 
     def close(self):
         if getattr(self, "_h", None):
-            _lib.load().prs_pcf_destroy(self._h)
+            if getattr(self.ctx, "_h", None):
+                _lib.load().prs_pcf_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -356,6 +362,7 @@ class AlignFrames:
         self.n_corr = z((batch,), torch.int32)
         self.result = z((batch, C.sizeof(AlignResult)), torch.uint8)
         self.prior = z((batch, 42), torch.float32) if with_prior else None
+        self.max_fixed = 0  # 0 = fixed_stride; smaller bound = less LDS per frame = more frames per CU
         self.reset_state()
 
     def reset_state(self):
@@ -398,6 +405,7 @@ class AlignFrames:
         d.inputs_changed, d.state, d.X = self.inputs_changed.data_ptr(), self.state.data_ptr(), self.X.data_ptr()
         d.corr, d.n_corr, d.result = self.corr.data_ptr(), self.n_corr.data_ptr(), self.result.data_ptr()
         d.prior = self.prior.data_ptr() if self.prior is not None else None
+        d.max_fixed = int(self.max_fixed)
         return d
 
     def result_of(self, b):
