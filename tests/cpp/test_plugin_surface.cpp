@@ -1,0 +1,242 @@
+// test_plugin_surface.cpp -- the reference's own test shapes driven through the C++ plugin surface
+// (plugin/proslam_hip_plugin.hpp) on a real GPU.  Each case names the reference test it restates.
+// Built by __graft_entry__.build() with g++, run by tests/test_plugin_surface_gpu.py.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "proslam_hip_plugin.hpp"
+
+using namespace proslam_hip;
+
+static int g_failures = 0;
+#define ASSERT_TRUE(cond)                                                    \
+  do {                                                                       \
+    if (!(cond)) {                                                           \
+      std::printf("  FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);        \
+      ++g_failures;                                                          \
+      return;                                                                \
+    }                                                                        \
+  } while (0)
+#define ASSERT_EQ(a, b) ASSERT_TRUE((a) == (b))
+#define ASSERT_LT_ABS(a, b) ASSERT_TRUE(std::fabs(a) < (b))
+
+static void randomDescriptor(std::mt19937& rng, uint8_t* d) {
+  for (int i = 0; i < PRS_DESC_BYTES; ++i) d[i] = (uint8_t) (rng() & 0xff);
+}
+
+// KITTI.00To00_CorrespondenceFinderEpipolar (tests/test_correspondence_finders.cpp:152-181)
+static void test_Epipolar_CloudVersusItself(ContextPtr ctx) {
+  std::mt19937 rng(0);
+  PointIntensityDescriptorVectorCloud<3> features(446);
+  for (auto& p : features) {
+    p.coords[0] = (float) (rng() % 1241);
+    p.coords[1] = (float) (rng() % 376);
+    p.coords[2] = 0;
+    randomDescriptor(rng, p.descriptor_row);
+  }
+  CorrespondenceFinderDescriptorBasedEpipolarHIP3D3D finder(ctx);
+  finder.param_maximum_descriptor_distance.setValue(50);
+  finder.param_maximum_distance_ratio_to_second_best.setValue(0.8f);
+  finder.param_image_rows.setValue(376);
+  CorrespondenceVector correspondences;
+  finder.setFixed(&features);
+  finder.setMoving(&features);
+  finder.setCorrespondences(&correspondences);
+  finder.compute();
+  ASSERT_EQ(correspondences.size(), features.size());
+  for (const Correspondence& c : correspondences) {
+    ASSERT_EQ(c.fixed_idx, c.moving_idx);
+    ASSERT_EQ(c.response, 0.0f);
+  }
+  // unchanged inputs keep the last computation state (epipolar_impl.cpp:50-52)
+  correspondences.pop_back();
+  finder.compute();
+  ASSERT_EQ(correspondences.size(), features.size() - 1);
+}
+
+// error contract (CF/correspondence_finder_descriptor_based_bruteforce_impl.cpp:203-216)
+static void test_Epipolar_ThrowsWhenUnset(ContextPtr ctx) {
+  CorrespondenceFinderDescriptorBasedEpipolarHIP3D3D finder(ctx);
+  bool thrown = false;
+  try {
+    finder.compute();
+  } catch (const std::runtime_error& e) {
+    thrown = std::string(e.what()).find("fixed not set") != std::string::npos;
+  }
+  ASSERT_TRUE(thrown);
+}
+
+struct SyntheticWorld {
+  // SyntheticWorld<3,float,...>::generateMap(100, mean(10,10,10), dev(5,5,5), Camera), K = (200,200,100,100), canvas 1000x1000
+  PointIntensityDescriptorVectorCloud<3> points_in_world;
+  float K[9] = {200, 0, 100, 0, 200, 100, 0, 0, 1};
+  explicit SyntheticWorld(unsigned seed) {
+    std::mt19937 rng(seed);
+    std::normal_distribution<float> n(10.0f, 5.0f);
+    points_in_world.resize(100);
+    for (auto& p : points_in_world) {
+      p.coords[0] = n(rng);
+      p.coords[1] = n(rng);
+      p.coords[2] = n(rng);
+      randomDescriptor(rng, p.descriptor_row);
+    }
+  }
+  // project world points seen from a camera at `cam_in_world` = (R | t), rows of R given
+  template <int Dim>
+  void project(const float* R9, const float* t3, PointIntensityDescriptorVectorCloud<Dim>& out, std::vector<int>& truth) const {
+    out.clear();
+    truth.clear();
+    for (size_t i = 0; i < points_in_world.size(); ++i) {
+      const float* w = points_in_world[i].coords;
+      const float d[3] = {w[0] - t3[0], w[1] - t3[1], w[2] - t3[2]};
+      float c[3];
+      for (int r = 0; r < 3; ++r) c[r] = R9[r] * d[0] + R9[3 + r] * d[1] + R9[6 + r] * d[2];  // R^T d
+      if (c[2] < 0.1f || c[2] > 1000.0f) continue;
+      const float u = K[0] * c[0] / c[2] + K[2], v = K[4] * c[1] / c[2] + K[5];
+      if (u < 0 || u >= 1000 || v < 0 || v >= 1000) continue;
+      PointIntensityDescriptor_<Dim> p;
+      p.coords[0] = u;
+      p.coords[1] = v;
+      if (Dim > 2) p.coords[2] = c[2];
+      std::memcpy(p.descriptor_row, points_in_world[i].descriptor_row, PRS_DESC_BYTES);
+      out.push_back(p);
+      truth.push_back((int) i);
+    }
+  }
+};
+
+// SyntheticWorldWithDescriptorsSE3.ProjectiveCircle_NoMotionNoNoise (tests/test_correspondence_finders.cpp:1024-1080)
+static void test_ProjectiveCircle_NoMotionNoNoise(ContextPtr ctx) {
+  SyntheticWorld world(1);
+  const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, zero[3] = {0, 0, 0};
+  PointIntensityDescriptorVectorCloud<2> points_in_canvas;
+  std::vector<int> truth;
+  world.project<2>(I9, zero, points_in_canvas, truth);
+  CorrespondenceFinderProjectiveCircleHIP2D3D finder(ctx);
+  finder.param_minimum_descriptor_distance.setValue(25);
+  finder.param_maximum_descriptor_distance.setValue(75);
+  finder.param_maximum_distance_ratio_to_second_best.setValue(0.5f);
+  finder.param_minimum_search_radius_pixels.setValue(1);
+  finder.param_projector->param_canvas_cols.setValue(1000);
+  finder.param_projector->param_canvas_rows.setValue(1000);
+  finder.param_projector->param_range_min.setValue(0.1f);
+  finder.param_projector->param_range_max.setValue(1000);
+  finder.param_projector->setCameraMatrix(world.K);
+  const float T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  finder.setLocalMapInSensor(T);
+  CorrespondenceVector correspondences;
+  finder.setFixed(&points_in_canvas);
+  finder.setMoving(&world.points_in_world);
+  finder.setCorrespondences(&correspondences);
+  finder.compute();
+  ASSERT_TRUE(points_in_canvas.size() > 40);
+  ASSERT_EQ(correspondences.size(), points_in_canvas.size());
+  for (const Correspondence& c : correspondences) ASSERT_EQ(c.moving_idx, truth[(size_t) c.fixed_idx]);
+  // the object is stateful across calls (CF/..projective_base.h:132-154)
+  ASSERT_EQ(finder.state().current_iteration, (uint64_t) 1);
+}
+
+// SyntheticWorldWithDescriptorsSE3.AlignerSliceProcessorProjective (tests/test_aligners.cpp:15-140)
+static void test_AlignerSliceProcessorProjective(ContextPtr ctx) {
+  SyntheticWorld world(2);
+  // sensor pose 1: translation (0,0,-1), rotation a2r(0.001, 0.001, -0.001) ~ I + [w]x
+  const float a = 0.001f, b = 0.001f, c = -0.001f;
+  const float R9[9] = {1, -c, b, c, 1, -a, -b, a, 1};  // first-order a2r, rows
+  const float t3[3] = {0, 0, -1};
+  PointIntensityDescriptorVectorCloud<2> points_in_camera_fixed;
+  std::vector<int> truth;
+  world.project<2>(R9, t3, points_in_camera_fixed, truth);
+  using Finder = CorrespondenceFinderProjectiveKDTreeHIP<PointIntensityDescriptorVectorCloud<2>, PointIntensityDescriptorVectorCloud<3>>;
+  AlignerProjectiveHIP<Finder> aligner(ctx);
+  Finder& finder = *aligner.param_finder;
+  finder.param_maximum_descriptor_distance.setValue(75);
+  finder.param_minimum_descriptor_distance.setValue(25);
+  finder.param_maximum_distance_ratio_to_second_best.setValue(0.5f);
+  finder.param_maximum_search_radius_pixels.setValue(50);
+  finder.param_projector->param_canvas_cols.setValue(1000);
+  finder.param_projector->param_canvas_rows.setValue(1000);
+  finder.param_projector->param_range_min.setValue(0.1f);
+  finder.param_projector->param_range_max.setValue(1000);
+  finder.param_projector->setCameraMatrix(world.K);
+  aligner.param_max_iterations.setValue(10);
+  aligner.setFixed(&points_in_camera_fixed);
+  aligner.setMoving(&world.points_in_world);
+  const float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  aligner.setMovingInFixed(I16);
+  ASSERT_EQ(aligner.status(), AlignerProjectiveHIP<Finder>::Fail);
+  aligner.compute();
+  ASSERT_EQ(aligner.status(), AlignerProjectiveHIP<Finder>::Success);
+  // error = t2tnq(movingInFixed * pose) (test_aligners.cpp:132): translation part and rotation residual
+  const float* X = aligner.movingInFixed();
+  float E[9], et[3];
+  for (int r = 0; r < 3; ++r) {
+    for (int k = 0; k < 3; ++k) E[3 * r + k] = X[4 * r] * R9[k] + X[4 * r + 1] * R9[3 + k] + X[4 * r + 2] * R9[6 + k];
+    et[r] = X[4 * r] * t3[0] + X[4 * r + 1] * t3[1] + X[4 * r + 2] * t3[2] + X[4 * r + 3];
+  }
+  ASSERT_LT_ABS(et[0], 0.15f);
+  ASSERT_LT_ABS(et[1], 0.15f);
+  ASSERT_LT_ABS(et[2], 0.15f);
+  // quaternion imaginary part ~ half the skew part of the residual rotation
+  ASSERT_LT_ABS(0.25f * (E[7] - E[5]), 0.005f);
+  ASSERT_LT_ABS(0.25f * (E[2] - E[6]), 0.005f);
+  ASSERT_LT_ABS(0.25f * (E[3] - E[1]), 0.005f);
+  ASSERT_TRUE(aligner.correspondences().size() > 40);
+}
+
+// triangulate(project(p)) = p and size preservation (tests/fixtures.hpp:939-944, triangulator_rigid_stereo.cpp:39-55)
+static void test_TriangulatorRigidStereo(ContextPtr ctx) {
+  TriangulatorRigidStereoHIP triangulator(ctx);
+  triangulator.param_projector.reset(new ProjectorPinholeHIP());
+  const float K[9] = {718.856f, 0, 607.193f, 0, 718.856f, 185.216f, 0, 0, 1};  // tests/fixtures.hpp:810
+  triangulator.param_projector->setCameraMatrix(K);
+  triangulator.setBaselineRightInLeftMeters(0.537166f, 0, 0);  // tests/fixtures.hpp:816
+  PointIntensityDescriptorVectorCloud<4> matches(3);
+  const float P[2][3] = {{1.0f, -0.5f, 10.0f}, {-3.0f, 0.7f, 25.0f}};
+  for (int i = 0; i < 2; ++i) {
+    matches[i].coords[0] = K[0] * P[i][0] / P[i][2] + K[2];
+    matches[i].coords[1] = K[4] * P[i][1] / P[i][2] + K[5];
+    matches[i].coords[2] = matches[i].coords[0] - K[0] * 0.537166f / P[i][2];
+    matches[i].coords[3] = matches[i].coords[1];
+  }
+  matches[2].coords[0] = 100;
+  matches[2].coords[1] = 50;
+  matches[2].coords[2] = 99.5f;  // disparity below the 1 px minimum -> Invalid, slot kept
+  matches[2].coords[3] = 50;
+  PointIntensityDescriptorVectorCloud<3> points;
+  triangulator.setMoving(&matches);
+  triangulator.setDest(&points);
+  triangulator.compute();
+  ASSERT_EQ(points.size(), matches.size());
+  ASSERT_LT_ABS(triangulator.baselineRigthInLeft()[0] - 386.1448f, 1e-2f);  // tests/fixtures.hpp:811
+  for (int i = 0; i < 2; ++i) {
+    ASSERT_TRUE(points[i].valid);
+    for (int k = 0; k < 3; ++k) ASSERT_LT_ABS(points[i].coords[k] - P[i][k], 2e-3f * P[i][2]);
+  }
+  ASSERT_TRUE(!points[2].valid);
+  ASSERT_EQ(triangulator.indicesInvalidated().size(), (size_t) 1);
+}
+
+int main() {
+  ContextPtr ctx;
+  try {
+    ctx.reset(new Context(0));
+  } catch (const std::exception& e) {
+    std::printf("no device: %s\n", e.what());
+    return 2;
+  }
+#define RUN(t)                                     \
+  do {                                             \
+    const int before = g_failures;                 \
+    t(ctx);                                        \
+    std::printf("[%s] %s\n", g_failures == before ? "  OK  " : "FAILED", #t); \
+  } while (0)
+  RUN(test_Epipolar_CloudVersusItself);
+  RUN(test_Epipolar_ThrowsWhenUnset);
+  RUN(test_ProjectiveCircle_NoMotionNoNoise);
+  RUN(test_AlignerSliceProcessorProjective);
+  RUN(test_TriangulatorRigidStereo);
+  std::printf("%d failure(s)\n", g_failures);
+  return g_failures ? 1 : 0;
+}
