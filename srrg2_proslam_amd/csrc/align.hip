@@ -54,8 +54,20 @@ struct AlignShared {
   int n_corr, n_filtered, n_projected, decision, flags, error;
   int n_inl, n_out, n_inv;
   int corr_changed, have_terms;
-  int wave_tot[4];
+  int wave_tot[16];
 };
+
+// split pipeline (search kernel + GN kernel alternate until every frame is done): per-frame control word
+struct FrameCtl {
+  int it_align;     // aligner iterations whose GN step has been applied
+  int need_search;  // 1: the finder.compute() of iteration it_align needs a projective search (search kernel's turn)
+  int done;
+  int executed;
+  int flags;        // OR of finder warnings over the frame loop
+  int n_inl, n_out, n_inv;
+};
+constexpr int kModeSplitSearch = 100;  // internal: align_kernel<512> performing ONE finder.compute() for frames that wait for it
+constexpr int kSearchThreads   = 512;
 
 struct AlignArgs {
   prs_pcf_params f;
@@ -64,16 +76,22 @@ struct AlignArgs {
   int mode;
   int rows_table;  // R = projector canvas rows (lattice row table extent)
   int lut_cap;     // entries of the circle width table
+  int cell_sy, cell_sx, cell_ncx, cell_ncy, ncells;  // 2-D cell grid over the canvas (cells of 2^sy rows x 2^sx cols)
   uint2* cand;     // scratch [batch][moving_stride]
+  float4* ops;     // split pipeline: [batch][max_fixed][2] per-correspondence operands (fixed measurement, moving point)
+  FrameCtl* ctl;   // split pipeline: [batch]
+  int* pending;    // split pipeline: number of frames the last GN launch left unfinished
   unsigned long long* stamps;  // diagnostic: [batch][16] accumulated shader clocks per phase (NULL = off)
   int max_fixed;   // LDS capacity in fixed points (frames with more are rejected loudly)
-  uint32_t off_db, off_rowfirst, off_cfix, off_cmov, off_sh;  // persistent for the whole frame loop
+  uint32_t off_db, off_cellstart, off_cfix, off_cmov, off_sh;  // persistent for the whole frame loop
   uint32_t off_u;                                              // phase-exclusive union region:
   uint32_t off_fdesc, off_fuv, off_best, off_second, off_lut;  //   search phase (relative to the LDS base)
   uint32_t off_terms;                                          //   GN phase / database build / disparity column
 };
 
 enum { kDecisionCommit = 0, kDecisionRetry = 1, kDecisionReturn = 2 };
+
+
 
 // floor(sqrt(n)) for 0 <= n < 2^31, exact
 __device__ __forceinline__ int isqrt_exact(int n) {
@@ -99,7 +117,116 @@ __device__ __forceinline__ int hamming_regs(const au32x4& a0, const au32x4& a1, 
   return d;
 }
 
-__global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g) {
+// One correspondence of SE3{,Depth,RectifiedStereo}ProjectiveErrorFactor::errorAndJacobian + saturated
+// robustifier: the 21 upper-triangle entries of J^T Omega J, the 6 of J^T Omega e, chi (inliers only) and
+// chi (kernelised).  z = fixed measurement, p = moving point (w = information scale).
+// cls: 0 inlier, 1 outlier (kernelised), 2 invalid (behind the camera / outside the image: all terms +0).
+struct PoseRegs {
+  float R00, R01, R02, t0, R10, R11, R12, t1, R20, R21, R22, t2;
+};
+__device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const PoseRegs& X, const float4 z, const float4 p,
+                                             const float mean_dsp, float* tv, int& cls) {
+  const float R00 = X.R00, R01 = X.R01, R02 = X.R02, t0 = X.t0;
+  const float R10 = X.R10, R11 = X.R11, R12 = X.R12, t1 = X.t1;
+  const float R20 = X.R20, R21 = X.R21, R22 = X.R22, t2 = X.t2;
+  const float fx = a.fx, fy = a.fy, cx = a.cx, cy = a.cy;
+  const int dim = a.factor_type;
+  cls = 0;
+    const float px = p.x, py = p.y, pz = p.z;
+    const float pcx = ((R00 * px + R01 * py) + R02 * pz) + t0;
+    const float pcy = ((R10 * px + R11 * py) + R12 * pz) + t1;
+    const float pcz = ((R20 * px + R21 * py) + R22 * pz) + t2;
+    const float hx  = fx * pcx + cx * pcz;
+    const float hy  = fy * pcy + cy * pcz;
+    const float hz  = pcz;
+    bool valid      = hz > 0.0f;
+    float iz = 0.0f, u_pred = 0.0f, v_pred = 0.0f;
+    if (valid) {
+      iz     = 1.0f / hz;
+      u_pred = hx * iz;
+      v_pred = hy * iz;
+      valid  = !(u_pred < 0.0f || u_pred > a.image_cols || v_pred < 0.0f || v_pred > a.image_rows);
+    }
+    if (!valid) {
+      cls = 2;
+    } else {
+      float e0 = u_pred - z.x, e1 = v_pred - z.y, e2 = 0.0f;
+      float hrx = hx;
+      if (dim == PRS_FACTOR_STEREO) {
+        hrx = hx + a.baseline_left_in_right_px[0];
+        e2  = hrx * iz - z.z;
+      } else if (dim == PRS_FACTOR_DEPTH) {
+        e2 = hz - z.z;
+      }
+      float wt = 1.0f;
+      if (dim == PRS_FACTOR_STEREO && a.enable_inverse_depth_weighting) {
+        wt = (z.x - z.z) / mean_dsp;
+        if (wt < 0.01f) {
+          wt = 0.01f;
+        }
+        if (wt > 1.0f) {
+          wt = 1.0f;
+        }
+      }
+      const float ax = 2.0f * px, ay = 2.0f * py, az = 2.0f * pz;
+      const float Rm[3][3] = {{R00, R01, R02}, {R10, R11, R12}, {R20, R21, R22}};
+      float Jp[3][6];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        Jp[r][0] = Rm[r][0] * wt;
+        Jp[r][1] = Rm[r][1] * wt;
+        Jp[r][2] = Rm[r][2] * wt;
+        Jp[r][3] = Rm[r][2] * ay - Rm[r][1] * az;
+        Jp[r][4] = Rm[r][0] * az - Rm[r][2] * ax;
+        Jp[r][5] = Rm[r][1] * ax - Rm[r][0] * ay;
+      }
+      const float hx_iz2 = (hx * iz) * iz;
+      const float hy_iz2 = (hy * iz) * iz;
+      const float hr_iz2 = (hrx * iz) * iz;
+      float J0[6], J1[6], J2[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const float a0 = fx * Jp[0][k] + cx * Jp[2][k];
+        const float a1 = fy * Jp[1][k] + cy * Jp[2][k];
+        const float a2 = Jp[2][k];
+        J0[k]          = a0 * iz - hx_iz2 * a2;
+        J1[k]          = a1 * iz - hy_iz2 * a2;
+        J2[k]          = dim == PRS_FACTOR_STEREO ? a0 * iz - hr_iz2 * a2 : (dim == PRS_FACTOR_DEPTH ? a2 : 0.0f);
+      }
+      // Omega = diag(info) * scale(moving point) (aligner_slice_processor_projective.cpp:46-56)
+      const float s = p.w;
+      float o0 = a.diagonal_info[0] * s;
+      float o1 = a.diagonal_info[1] * s;
+      float o2 = dim == PRS_FACTOR_MONO ? 0.0f : a.diagonal_info[2] * s;
+      float chi = ((o0 * e0) * e0 + (o1 * e1) * e1) + (o2 * e2) * e2;
+      if (chi > a.chi_threshold) {  // saturated kernel
+        const float scale = a.chi_threshold / chi;
+        o0 *= scale;
+        o1 *= scale;
+        o2 *= scale;
+        chi = a.chi_threshold;
+        cls = 1;
+      } else {
+        cls = 0;
+        tv[27] = chi;
+      }
+      tv[28] = chi;
+      int t  = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const float j0 = J0[r] * o0, j1 = J1[r] * o1, j2 = J2[r] * o2;
+#pragma unroll
+        for (int k = r; k < 6; ++k) {
+          tv[t++] = (j0 * J0[k] + j1 * J1[k]) + j2 * J2[k];
+        }
+        tv[21 + r] = (j0 * e0 + j1 * e1) + j2 * e2;
+      }
+    }
+
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid   = threadIdx.x;
   const int lane  = tid & 63;
@@ -121,8 +248,8 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
   prs_pcf_state* gstate           = g.b.state + frame;
   prs_align_result* gres          = g.b.result + frame;
 
-  uint2* db           = reinterpret_cast<uint2*>(smem + g.off_db);        // row-sorted lattice: x = row | col << 16, y = fixed index
-  uint16_t* rowfirst  = reinterpret_cast<uint16_t*>(smem + g.off_rowfirst);
+  uint2* db           = reinterpret_cast<uint2*>(smem + g.off_db);        // cell-sorted lattice: x = row | col << 16, y = fixed index | canonical position << 16
+  uint16_t* cellstart = reinterpret_cast<uint16_t*>(smem + g.off_cellstart);
   float4* cfix        = reinterpret_cast<float4*>(smem + g.off_cfix);      // per-correspondence fixed measurement
   float4* cmov        = reinterpret_cast<float4*>(smem + g.off_cmov);      // per-correspondence moving point + information scale
   au32x4* fdesc       = reinterpret_cast<au32x4*>(smem + g.off_fdesc);    // fixed descriptor rows (search phase only)
@@ -135,6 +262,13 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
   const int R         = g.rows_table;
   const int stype     = g.f.search_type;
   const bool lattice  = stype != PRS_SEARCH_KDTREE;
+
+  const bool split_search = g.mode == kModeSplitSearch;
+  FrameCtl* ctl           = split_search ? g.ctl + frame : nullptr;
+  if (split_search && (ctl->done || !ctl->need_search)) {
+    return;  // this frame does not wait for a search (block-uniform)
+  }
+  float4* gops = split_search ? g.ops + (size_t) frame * (size_t) g.max_fixed * 2 : nullptr;
 
   // ---- load the persistent state ---------------------------------------------------------------
   if (tid < 16) {
@@ -154,7 +288,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
     sh.error          = 0;
     sh.n_inl = sh.n_out = sh.n_inv = 0;
     sh.chi_in = sh.chi_tot = 0.0f;
-    sh.mean_disp           = g.a.mean_disparity;
+    sh.mean_disp           = (split_search && ctl->it_align != 0) ? gres->mean_disparity : g.a.mean_disparity;
     sh.corr_changed        = 1;
     sh.have_terms          = 0;
     if (sh.n_corr < 0 || sh.n_corr > nF) {
@@ -164,7 +298,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
       sh.error = PRS_ERR_CAPACITY;  // the caller's max_fixed hint was too small for this frame
     }
   }
-  for (int i = tid; i < 36; i += kAlignThreads) {
+  for (int i = tid; i < 36; i += T) {
     sh.H[i] = 0.0f;
   }
   if (tid < 6) {
@@ -173,6 +307,9 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
   __syncthreads();
 
   bool inputs_changed = g.b.inputs_changed ? (g.b.inputs_changed[frame] != 0) : true;
+  if (split_search && ctl->it_align != 0) {
+    inputs_changed = false;  // later searches of the same frame loop
+  }
   bool db_built       = false;
   if (inputs_changed && g.mode != PRS_MODE_LINEARIZE) {
     // a new fixed/moving cloud invalidates the previous frame's correspondence vector
@@ -184,9 +321,9 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
 
   // ---- bindFixed: mean disparity over ALL fixed points, sequential float sum -------------------
   // (aligner_slice_processor_projective.cpp:80-88)
-  if (g.mode != PRS_MODE_FINDER && g.a.factor_type == PRS_FACTOR_STEREO && g.a.enable_inverse_depth_weighting &&
-      g.a.mean_disparity < 0.0f && !sh.error) {
-    for (int i = tid; i < nF; i += kAlignThreads) {
+  if (g.mode != PRS_MODE_FINDER && (!split_search || ctl->it_align == 0) && g.a.factor_type == PRS_FACTOR_STEREO &&
+      g.a.enable_inverse_depth_weighting && g.a.mean_disparity < 0.0f && !sh.error) {
+    for (int i = tid; i < nF; i += T) {
       const float4 c = gfix[i];
       terms[i]       = c.x - c.z;
     }
@@ -211,8 +348,8 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
 
   // the caller-owned correspondence vector persists across calls: "nothing new" finder calls keep
   // using it, and linearize-only calls receive it as input
-  if (g.mode != PRS_MODE_FINDER && !sh.error) {
-    for (int c = tid; c < sh.n_corr; c += kAlignThreads) {
+  if (g.mode != PRS_MODE_FINDER && !split_search && !sh.error) {
+    for (int c = tid; c < sh.n_corr; c += T) {
       const prs_corr cr = gcorr[c];
       if (cr.fixed_idx < 0 || cr.fixed_idx >= nF || cr.moving_idx < 0 || cr.moving_idx >= nM) {
         sh.error = PRS_ERR_RANGE;
@@ -228,6 +365,9 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
 #define ALIGN_MARK() (t_mark = (g.stamps && tid == 0) ? (unsigned long long) clock64() : 0ull)
 #define ALIGN_ACC(v) do { if (g.stamps && tid == 0) { v += (unsigned long long) clock64() - t_mark; } } while (0)
   const int max_it = (g.mode == PRS_MODE_ALIGN && !sh.error) ? g.a.max_iterations : (sh.error ? 0 : 1);
+  if (split_search && sh.error && tid == 0) {
+    ctl->done = 1;  // loud per-frame error, the GN kernel never touches this frame
+  }
   int executed     = 0;
   int it_align     = 0;
   for (; it_align < max_it; ++it_align) {
@@ -304,30 +444,96 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
 
         // -- the lattice lives in LDS: (re)build it on the first search of a launch and after every reset
         if (!db_built) {
-        // _initializeDatabase (square_impl.cpp:8-31), stable by row: canonical tie order
-        uint32_t* hist   = reinterpret_cast<uint32_t*>(terms);
-        uint16_t* slot   = reinterpret_cast<uint16_t*>(hist + (R + 2));
-        uint16_t* bucket = slot + g.max_fixed + 2;
-        for (int i = tid; i <= R; i += kAlignThreads) {
-          hist[i] = 0;
-        }
-        __syncthreads();
-        for (int i = tid; i < nF; i += kAlignThreads) {
-          const float4 c = gfix[i];
-          if (!lattice) {
-            // KD-tree variant: nothing to sort, (u,v) are loaded with the descriptors before every search
-          } else if (c.x >= 0.0f && c.x < 32767.0f && c.y >= 0.0f && c.y < (float) R) {
-            const int row = (int) (int16_t) c.y;  // Element(coordinates(1), coordinates(0), i)
-            slot[i]       = (uint16_t) atomicAdd(&hist[row], 1u);
-          } else {
-            sh.error = PRS_ERR_RANGE;
+          // _initializeDatabase (square_impl.cpp:8-31).  The reference scans a row-sorted vector; its
+          // scan position only matters for tie-breaks ("first wins"), so every fixed point gets its
+          // CANONICAL position (stable row sort, ascending index inside a row) and the lattice itself
+          // is bucketed into a 2-D cell grid: a query visits the cells under its search region
+          // instead of every entry of ~2r+1 rows.
+          const int histcap  = (R > g.ncells ? R : g.ncells) + 2;
+          uint32_t* hist     = reinterpret_cast<uint32_t*>(terms);
+          uint16_t* slot     = reinterpret_cast<uint16_t*>(hist + histcap);
+          uint16_t* bucket   = slot + g.max_fixed + 2;
+          uint16_t* canon    = bucket + g.max_fixed + 2;
+          uint16_t* rowfirst = canon + g.max_fixed + 2;
+          for (int i = tid; i <= R; i += T) {
+            hist[i] = 0;
           }
-        }
-        __syncthreads();
-        if (lattice && !sh.error) {
+          __syncthreads();
+          for (int i = tid; i < nF; i += T) {
+            const float4 c = gfix[i];
+            if (c.x >= 0.0f && c.x < 32767.0f && c.y >= 0.0f && c.y < (float) R) {
+              const int row = (int) (int16_t) c.y;  // Element(coordinates(1), coordinates(0), i)
+              slot[i]       = (uint16_t) atomicAdd(&hist[row], 1u);
+            } else {
+              sh.error = PRS_ERR_RANGE;
+            }
+          }
+          __syncthreads();
+          if (sh.error) {
+            break;
+          }
+          if (lattice) {
+            if (wave == 0) {
+              const int n     = R + 1;
+              const int chunk = (n + 63) >> 6;
+              uint32_t sum    = 0;
+              for (int j = 0; j < chunk; ++j) {
+                const int r = lane * chunk + j;
+                sum += r < n ? hist[r] : 0u;
+              }
+              uint32_t incl = sum;
+#pragma unroll
+              for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d, 64);
+                if (lane >= d) {
+                  incl += o;
+                }
+              }
+              uint32_t run = incl - sum;
+              for (int j = 0; j < chunk; ++j) {
+                const int r = lane * chunk + j;
+                if (r < n) {
+                  rowfirst[r] = (uint16_t) run;
+                  run += hist[r];
+                }
+              }
+            }
+            __syncthreads();
+            for (int i = tid; i < nF; i += T) {
+              const int row = (int) (int16_t) gfix[i].y;
+              bucket[rowfirst[row] + slot[i]] = (uint16_t) i;
+            }
+            __syncthreads();
+            for (int i = tid; i < nF; i += T) {
+              const int row = (int) (int16_t) gfix[i].y;
+              const int s = rowfirst[row], e = rowfirst[row + 1];
+              int rank = 0;
+              for (int j = s; j < e; ++j) {
+                rank += bucket[j] < (uint16_t) i ? 1 : 0;
+              }
+              canon[i] = (uint16_t) (s + rank);
+            }
+          } else {
+            for (int i = tid; i < nF; i += T) {
+              canon[i] = (uint16_t) i;  // KD-tree variant: candidates are visited in ascending fixed index
+            }
+          }
+          __syncthreads();
+          // bucket by cell (order inside a cell is irrelevant: ties are resolved on the canonical position)
+          for (int i = tid; i <= g.ncells; i += T) {
+            hist[i] = 0;
+          }
+          __syncthreads();
+          for (int i = tid; i < nF; i += T) {
+            const float4 c = gfix[i];
+            const int row  = (int) (int16_t) c.y;
+            int cxi        = ((int) (int16_t) c.x) >> g.cell_sx;
+            cxi            = cxi < g.cell_ncx ? cxi : g.cell_ncx - 1;
+            slot[i]        = (uint16_t) atomicAdd(&hist[(row >> g.cell_sy) * g.cell_ncx + cxi], 1u);
+          }
+          __syncthreads();
           if (wave == 0) {
-            // exclusive scan of hist[0..R] into rowfirst[0..R]
-            const int n     = R + 1;
+            const int n     = g.ncells + 1;
             const int chunk = (n + 63) >> 6;
             uint32_t sum    = 0;
             for (int j = 0; j < chunk; ++j) {
@@ -346,54 +552,43 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
             for (int j = 0; j < chunk; ++j) {
               const int r = lane * chunk + j;
               if (r < n) {
-                rowfirst[r] = (uint16_t) run;
+                cellstart[r] = (uint16_t) run;
                 run += hist[r];
               }
             }
           }
           __syncthreads();
-          for (int i = tid; i < nF; i += kAlignThreads) {
-            const int row = (int) (int16_t) gfix[i].y;
-            bucket[rowfirst[row] + slot[i]] = (uint16_t) i;
-          }
-          __syncthreads();
-          for (int i = tid; i < nF; i += kAlignThreads) {
+          for (int i = tid; i < nF; i += T) {
             const float4 c = gfix[i];
             const int row  = (int) (int16_t) c.y;
             const int col  = (int) (int16_t) c.x;
-            const int s = rowfirst[row], e = rowfirst[row + 1];
-            int rank = 0;
-            for (int j = s; j < e; ++j) {
-              rank += bucket[j] < (uint16_t) i ? 1 : 0;
-            }
-            db[s + rank] = make_uint2(((uint32_t) row & 0xffffu) | ((uint32_t) col << 16), (uint32_t) i);
+            int cxi        = col >> g.cell_sx;
+            cxi            = cxi < g.cell_ncx ? cxi : g.cell_ncx - 1;
+            db[cellstart[(row >> g.cell_sy) * g.cell_ncx + cxi] + slot[i]] =
+              make_uint2(((uint32_t) row & 0xffffu) | ((uint32_t) col << 16), (uint32_t) i | ((uint32_t) canon[i] << 16));
           }
-        }
           __syncthreads();
           db_built = true;
-          if (sh.error) {
-            break;
-          }
         }
 
         // -- projection + candidate search (:165-166, :192-200)
         const int rad = (int) sh.radius;
-        for (int i = tid; i < nF; i += kAlignThreads) {
+        for (int i = tid; i < nF; i += T) {
           bestkey[i] = kNoneU32;
           second[i]  = kNoneU32;
         }
-        for (int i = tid; i < 2 * nF; i += kAlignThreads) {
+        for (int i = tid; i < 2 * nF; i += T) {
           fdesc[i] = gfd[i];  // coalesced 16 B/lane; the rows are re-read ~10x per query from LDS
         }
         if (!lattice) {
-          for (int i = tid; i < nF; i += kAlignThreads) {
+          for (int i = tid; i < nF; i += T) {
             const float4 c = gfix[i];
             fuv[i]         = make_float2(c.x, c.y);
           }
         }
         if (stype == PRS_SEARCH_CIRCLE) {
           // width = int(sqrt(r^2 - h^2) + 1) per row offset h (circle_impl.cpp:51-53), exact in integers
-          for (int i = tid; i < 2 * rad + 1 && i < g.lut_cap; i += kAlignThreads) {
+          for (int i = tid; i < 2 * rad + 1 && i < g.lut_cap; i += T) {
             const int h = i - rad;
             lut[i]      = (uint16_t) (isqrt_exact(rad * rad - h * h) + 1);
           }
@@ -407,7 +602,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
           const float max_dd = g.f.maximum_descriptor_distance;
           const float r2f    = (float) (sh.radius * sh.radius);
           int projected      = 0;
-          for (int m = tid; m < nM; m += kAlignThreads) {
+          for (int m = tid; m < nM; m += T) {
             const float4 p = gmov[m];
             // PointProjectorPinhole_::compute (external)
             const float x = ((W0 * p.x + W1 * p.y) + W2 * p.z) + W3;
@@ -426,33 +621,53 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
             if (visible) {
               ++projected;
               const au32x4 q0 = gmd[2 * m], q1 = gmd[2 * m + 1];
-              float best = kFltMax, sec = kFltMax;
+              // top-2 on (distance, canonical lattice position) keys: identical to the reference's
+              // sequential "strictly smaller wins" scan, but independent of the visiting order
+              uint32_t bestk = kNoneU32, seck = kNoneU32;
               int ibest = 0, isec = 0;
+              int row = 0, col = 0, rmin = 0, rmax = 0, cmin = 0, cmax = 0;
+              int r0, r1, cb0, cb1;
               if (lattice) {
-                const int row   = (int) (int16_t) roundf(v);  // circle_impl.cpp:15-16
-                const int col   = (int) (int16_t) roundf(u);
-                const int rmin  = (int) (int16_t) (row - rad);      // :25
-                const int rmax  = (int) (int16_t) (row + rad + 1);  // :26
-                const int cmin  = (int) (int16_t) (col - rad - 1);  // square_impl.cpp:56
-                const int cmax  = (int) (int16_t) (col + rad + 1);  // square_impl.cpp:57
-                const int start = rowfirst[rmin < 0 ? 0 : (rmin > R ? R : rmin)];
-                const int end   = rowfirst[rmax < 0 ? 0 : (rmax > R ? R : rmax)];
-                // the lattice is scanned four entries at a time: the four LDS reads (and the four
-                // width-table reads) are independent, and the descriptor scoring below runs once per
-                // group for each lane's pending candidate instead of once per entry
-                for (int pos = start; pos < end; pos += 4) {
-                  uint2 e[4];
-#pragma unroll
-                  for (int k = 0; k < 4; ++k) {
-                    e[k] = db[pos + k < end ? pos + k : end - 1];
-                  }
-                  uint32_t mask = 0;
-#pragma unroll
-                  for (int k = 0; k < 4; ++k) {
-                    const int drow = (int) (int16_t) (e[k].x & 0xffffu);
-                    const int dcol = (int) (int16_t) (e[k].x >> 16);
+                row  = (int) (int16_t) roundf(v);           // circle_impl.cpp:15-16
+                col  = (int) (int16_t) roundf(u);
+                rmin = (int) (int16_t) (row - rad);         // :25
+                rmax = (int) (int16_t) (row + rad + 1);     // :26
+                cmin = (int) (int16_t) (col - rad - 1);     // square_impl.cpp:56
+                cmax = (int) (int16_t) (col + rad + 1);     // square_impl.cpp:57
+                r0   = rmin;
+                r1   = rmax - 1;
+                cb0  = col - rad;                           // every pattern accepts only |dcol - col| <= rad
+                cb1  = col + rad;
+              } else {
+                r0  = (int) floorf(v) - rad - 1;            // bounding box of the radius query (+1 px margin)
+                r1  = (int) floorf(v) + rad + 1;
+                cb0 = (int) floorf(u) - rad - 1;
+                cb1 = (int) floorf(u) + rad + 1;
+              }
+              r0  = r0 < 0 ? 0 : r0;
+              r1  = r1 > R - 1 ? R - 1 : r1;
+              cb0 = cb0 < 0 ? 0 : cb0;
+              const int colmax = (g.cell_ncx << g.cell_sx) - 1;
+              cb1 = cb1 > colmax ? colmax : cb1;
+              if (r0 <= r1 && cb0 <= cb1) {
+                const int cx0 = cb0 >> g.cell_sx, cx1 = cb1 >> g.cell_sx;
+                for (int cy = r0 >> g.cell_sy; cy <= (r1 >> g.cell_sy); ++cy) {
+                  const int seg0 = cellstart[cy * g.cell_ncx + cx0];
+                  const int seg1 = cellstart[cy * g.cell_ncx + cx1 + 1];
+                  for (int pos = seg0; pos < seg1; ++pos) {
+                    const uint2 e  = db[pos];
+                    const int drow = (int) (int16_t) (e.x & 0xffffu);
+                    const int dcol = (int) (int16_t) (e.x >> 16);
+                    const int fi   = (int) (e.y & 0xffffu);
                     bool accept;
-                    if (stype == PRS_SEARCH_SQUARE) {
+                    if (!lattice) {
+                      // exact radius query (kdtree_impl.cpp:39-50)
+                      const float2 c = fuv[fi];
+                      const float du = c.x - u, dv = c.y - v;
+                      accept = !(du * du + dv * dv > r2f);
+                    } else if (drow < rmin || drow >= rmax) {
+                      accept = false;  // outside the scanned rows (circle_impl.cpp:40-47)
+                    } else if (stype == PRS_SEARCH_SQUARE) {
                       accept = dcol > cmin && dcol < cmax;  // square_impl.cpp:80
                     } else if (stype == PRS_SEARCH_CIRCLE) {
                       const int h     = drow - row;
@@ -466,49 +681,29 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
                       }
                       accept = dcol > col - width && dcol < col + width;
                     }
-                    mask |= (accept && pos + k < end) ? (1u << k) : 0u;
-                  }
-                  while (mask) {  // ascending k = lattice order: first-wins tie-breaks are preserved
-                    const int fi = (mask & 1u) ? (int) e[0].y : ((mask & 2u) ? (int) e[1].y : ((mask & 4u) ? (int) e[2].y : (int) e[3].y));
-                    mask &= mask - 1u;
-                    const float d = (float) hamming_regs(fdesc[2 * fi], fdesc[2 * fi + 1], q0, q1);
-                    if (d < best) {  // circle_impl.cpp:64-72
-                      sec   = best;
-                      isec  = ibest;
-                      best  = d;
-                      ibest = fi;
-                    } else if (d < sec) {
-                      sec  = d;
-                      isec = fi;
+                    if (accept) {
+                      const uint32_t d = (uint32_t) hamming_regs(fdesc[2 * fi], fdesc[2 * fi + 1], q0, q1);
+                      // kdtree_impl.cpp:54: the best is initialised to maximum_descriptor_distance
+                      if (lattice || (float) d < max_dd) {
+                        const uint32_t key = (d << 16) | (e.y >> 16);
+                        if (key < bestk) {  // circle_impl.cpp:64-72
+                          seck  = bestk;
+                          isec  = ibest;
+                          bestk = key;
+                          ibest = fi;
+                        } else if (key < seck) {
+                          seck = key;
+                          isec = fi;
+                        }
+                      }
                     }
                   }
                 }
-                if (best < kFltMax) {  // circle_impl.cpp:78-92
-                  cd.x = (uint32_t) ibest | ((uint32_t) (int) best << 16);
-                  if (sec < kFltMax) {
-                    cd.y = (uint32_t) isec | ((uint32_t) (int) sec << 16);
-                  }
-                }
-              } else {
-                // exact radius query visited in ascending fixed index (kdtree_impl.cpp:39-50)
-                best = max_dd;  // :54
-                for (int fi = 0; fi < nF; ++fi) {
-                  const float2 c = fuv[fi];
-                  const float du = c.x - u, dv = c.y - v;
-                  if (du * du + dv * dv > r2f) {
-                    continue;
-                  }
-                  const float d = (float) hamming_regs(fdesc[2 * fi], fdesc[2 * fi + 1], q0, q1);
-                  if (d < best) {  // :62-68
-                    sec   = best;
-                    best  = d;
-                    ibest = fi;
-                  } else if (d < sec) {
-                    sec = d;
-                  }
-                }
-                if (best < max_dd) {  // :72-78
-                  cd.x = (uint32_t) ibest | ((uint32_t) (int) best << 16);
+              }
+              if (bestk != kNoneU32) {  // circle_impl.cpp:78-92 / kdtree_impl.cpp:72-78 (best only)
+                cd.x = (uint32_t) ibest | ((bestk >> 16) << 16);
+                if (lattice && seck != kNoneU32) {
+                  cd.y = (uint32_t) isec | ((seck >> 16) << 16);
                 }
               }
               // _addCorrespondenceCandidate (:8-37): order-independent reduction on
@@ -528,7 +723,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
         }
         __syncthreads();
         // -- second lowest response per fixed index (:57-68): minimum over everything but the winner
-        for (int m = tid; m < nM; m += kAlignThreads) {
+        for (int m = tid; m < nM; m += T) {
           const uint2 cd = cand[m];
           if (cd.x != kNoneU32) {
             const uint32_t key = ((cd.x >> 16) << 17) | ((uint32_t) m << 1);
@@ -550,7 +745,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
           const float ratio = g.f.maximum_distance_ratio_to_second_best;
           const float dd    = sh.dd;
           int base          = 0;
-          for (int f0 = 0; f0 < nF; f0 += kAlignThreads) {
+          for (int f0 = 0; f0 < nF; f0 += T) {
             const int f = f0 + tid;
             bool acc    = false;
             if (f < nF) {
@@ -576,7 +771,9 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
             if (f < nF) {
               second[f] = acc ? (uint32_t) (wbase + pre) : kNoneU32;
             }
-            base += sh.wave_tot[0] + sh.wave_tot[1] + sh.wave_tot[2] + sh.wave_tot[3];
+            for (int w = 0; w < T / 64; ++w) {
+              base += sh.wave_tot[w];
+            }
             __syncthreads();
           }
           if (tid == 0) {
@@ -628,7 +825,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
           continue;
         }
         // -- commit: correspondences->swap(filtered) (:268) + per-correspondence operands for the factor
-        for (int f = tid; f < nF; f += kAlignThreads) {
+        for (int f = tid; f < nF; f += T) {
           const uint32_t slot = second[f];
           if (slot != kNoneU32) {
             const uint32_t bk = bestkey[f];
@@ -641,6 +838,9 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
             if (g.mode == PRS_MODE_ALIGN) {
               cfix[slot] = gfix[f];
               cmov[slot] = gmov[m];
+            } else if (split_search) {
+              gops[2 * slot]     = gfix[f];
+              gops[2 * slot + 1] = gmov[m];
             }
           }
         }
@@ -657,7 +857,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
       __syncthreads();
     }
     ALIGN_ACC(acc_finder);
-    if (g.mode == PRS_MODE_FINDER) {
+    if (g.mode == PRS_MODE_FINDER || split_search) {
       break;
     }
 
@@ -672,7 +872,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
         sh.n_inl = sh.n_out = sh.n_inv = 0;
         sh.chi_in = sh.chi_tot = 0.0f;
       }
-      for (int i = tid; i < 36; i += kAlignThreads) {
+      for (int i = tid; i < 36; i += T) {
         sh.H[i] = 0.0f;
       }
       if (tid < 6) {
@@ -685,18 +885,14 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
       continue;  // slice has too few correspondences: no update this iteration
     }
     {
-      const float R00 = sh.X[0], R01 = sh.X[1], R02 = sh.X[2], t0 = sh.X[3];
-      const float R10 = sh.X[4], R11 = sh.X[5], R12 = sh.X[6], t1 = sh.X[7];
-      const float R20 = sh.X[8], R21 = sh.X[9], R22 = sh.X[10], t2 = sh.X[11];
-      const float fx = g.a.fx, fy = g.a.fy, cx = g.a.cx, cy = g.a.cy;
-      const int dim        = g.a.factor_type;
+      const PoseRegs pose  = {sh.X[0], sh.X[1], sh.X[2], sh.X[3], sh.X[4], sh.X[5], sh.X[6], sh.X[7], sh.X[8], sh.X[9], sh.X[10], sh.X[11]};
       const float mean_dsp = sh.mean_disp;
       if (tid == 0) {
         sh.n_inl = sh.n_out = sh.n_inv = 0;
       }
       float run = 0.0f;  // lanes 0..28 of wave 0: running sum of their term in correspondence order
       __syncthreads();
-      for (int c0 = 0; c0 < nc; c0 += kAlignThreads) {
+      for (int c0 = 0; c0 < nc; c0 += T) {
         ALIGN_MARK();
         const int c = c0 + tid;
         float tv[kTerms];
@@ -705,102 +901,13 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
           tv[t] = 0.0f;
         }
         if (c < nc) {
-          const float4 z = cfix[c];
-          const float4 p = cmov[c];
-          const float px = p.x, py = p.y, pz = p.z;
-          const float pcx = ((R00 * px + R01 * py) + R02 * pz) + t0;
-          const float pcy = ((R10 * px + R11 * py) + R12 * pz) + t1;
-          const float pcz = ((R20 * px + R21 * py) + R22 * pz) + t2;
-          const float hx  = fx * pcx + cx * pcz;
-          const float hy  = fy * pcy + cy * pcz;
-          const float hz  = pcz;
-          bool valid      = hz > 0.0f;
-          float iz = 0.0f, u_pred = 0.0f, v_pred = 0.0f;
-          if (valid) {
-            iz     = 1.0f / hz;
-            u_pred = hx * iz;
-            v_pred = hy * iz;
-            valid  = !(u_pred < 0.0f || u_pred > g.a.image_cols || v_pred < 0.0f || v_pred > g.a.image_rows);
-          }
-          if (!valid) {
-            atomicAdd(&sh.n_inv, 1);
-          } else {
-            float e0 = u_pred - z.x, e1 = v_pred - z.y, e2 = 0.0f;
-            float hrx = hx;
-            if (dim == PRS_FACTOR_STEREO) {
-              hrx = hx + g.a.baseline_left_in_right_px[0];
-              e2  = hrx * iz - z.z;
-            } else if (dim == PRS_FACTOR_DEPTH) {
-              e2 = hz - z.z;
-            }
-            float wt = 1.0f;
-            if (dim == PRS_FACTOR_STEREO && g.a.enable_inverse_depth_weighting) {
-              wt = (z.x - z.z) / mean_dsp;
-              if (wt < 0.01f) {
-                wt = 0.01f;
-              }
-              if (wt > 1.0f) {
-                wt = 1.0f;
-              }
-            }
-            const float ax = 2.0f * px, ay = 2.0f * py, az = 2.0f * pz;
-            const float Rm[3][3] = {{R00, R01, R02}, {R10, R11, R12}, {R20, R21, R22}};
-            float Jp[3][6];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-              Jp[r][0] = Rm[r][0] * wt;
-              Jp[r][1] = Rm[r][1] * wt;
-              Jp[r][2] = Rm[r][2] * wt;
-              Jp[r][3] = Rm[r][2] * ay - Rm[r][1] * az;
-              Jp[r][4] = Rm[r][0] * az - Rm[r][2] * ax;
-              Jp[r][5] = Rm[r][1] * ax - Rm[r][0] * ay;
-            }
-            const float hx_iz2 = (hx * iz) * iz;
-            const float hy_iz2 = (hy * iz) * iz;
-            const float hr_iz2 = (hrx * iz) * iz;
-            float J0[6], J1[6], J2[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-              const float a0 = fx * Jp[0][k] + cx * Jp[2][k];
-              const float a1 = fy * Jp[1][k] + cy * Jp[2][k];
-              const float a2 = Jp[2][k];
-              J0[k]          = a0 * iz - hx_iz2 * a2;
-              J1[k]          = a1 * iz - hy_iz2 * a2;
-              J2[k]          = dim == PRS_FACTOR_STEREO ? a0 * iz - hr_iz2 * a2 : (dim == PRS_FACTOR_DEPTH ? a2 : 0.0f);
-            }
-            // Omega = diag(info) * scale(moving point) (aligner_slice_processor_projective.cpp:46-56)
-            const float s = p.w;
-            float o0 = g.a.diagonal_info[0] * s;
-            float o1 = g.a.diagonal_info[1] * s;
-            float o2 = dim == PRS_FACTOR_MONO ? 0.0f : g.a.diagonal_info[2] * s;
-            float chi = ((o0 * e0) * e0 + (o1 * e1) * e1) + (o2 * e2) * e2;
-            if (chi > g.a.chi_threshold) {  // saturated kernel
-              const float scale = g.a.chi_threshold / chi;
-              o0 *= scale;
-              o1 *= scale;
-              o2 *= scale;
-              chi = g.a.chi_threshold;
-              atomicAdd(&sh.n_out, 1);
-            } else {
-              atomicAdd(&sh.n_inl, 1);
-              tv[27] = chi;
-            }
-            tv[28] = chi;
-            int t  = 0;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-              const float j0 = J0[r] * o0, j1 = J1[r] * o1, j2 = J2[r] * o2;
-#pragma unroll
-              for (int k = r; k < 6; ++k) {
-                tv[t++] = (j0 * J0[k] + j1 * J1[k]) + j2 * J2[k];
-              }
-              tv[21 + r] = (j0 * e0 + j1 * e1) + j2 * e2;
-            }
-          }
+          int cls;
+          factor_terms(g.a, pose, cfix[c], cmov[c], mean_dsp, tv, cls);
+          atomicAdd(cls == 0 ? &sh.n_inl : (cls == 1 ? &sh.n_out : &sh.n_inv), 1);
         }
 #pragma unroll
         for (int t = 0; t < kTerms; ++t) {
-          terms[t * kAlignThreads + tid] = tv[t];
+          terms[t * T + tid] = tv[t];
         }
         __syncthreads();
         ALIGN_ACC(acc_lin);
@@ -810,8 +917,8 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
           // entries past the last correspondence hold +0.0f and x + 0.0f == x bit-for-bit (the running
           // sums are never -0.0f), so whole 16-entry groups are added: 4 x 16-byte LDS reads in
           // flight, then 16 dependent adds in correspondence order
-          const int cnt      = nc - c0 < kAlignThreads ? nc - c0 : kAlignThreads;
-          const float4* row4 = reinterpret_cast<const float4*>(terms + tid * kAlignThreads);
+          const int cnt      = nc - c0 < T ? nc - c0 : T;
+          const float4* row4 = reinterpret_cast<const float4*>(terms + tid * T);
           float4 n0 = row4[0], n1 = row4[1], n2 = row4[2], n3 = row4[3];
           for (int j = 0; j < cnt; j += 16) {
             const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
@@ -903,11 +1010,13 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
   // ---- write back --------------------------------------------------------------------------------
   __syncthreads();
   if (tid < 16) {
-    g.b.X[(size_t) frame * 16 + tid]           = sh.X[tid];
+    if (!split_search) {
+      g.b.X[(size_t) frame * 16 + tid] = sh.X[tid];
+    }
     gstate->local_map_in_sensor[tid]          = sh.T[tid];
     gstate->local_map_in_sensor_previous[tid] = sh.Tprev[tid];
   }
-  for (int i = tid; i < 36; i += kAlignThreads) {
+  for (int i = tid; i < 36; i += T) {
     gres->H[i] = sh.H[i];
   }
   if (tid < 6) {
@@ -932,6 +1041,11 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
     gres->iterations             = g.mode == PRS_MODE_ALIGN ? g.a.max_iterations : 1;
     gres->iterations_executed    = executed;
     gres->warnings               = sh.error ? sh.error : sh.flags;
+    if (split_search) {
+      ctl->flags |= sh.flags;
+      ctl->need_search = 0;
+      gres->warnings   = sh.error ? sh.error : ctl->flags;
+    }
     if (g.stamps) {
       unsigned long long* st = g.stamps + (size_t) frame * 16;
       st[0] = 0;
@@ -940,6 +1054,299 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(const AlignArgs g)
       st[3] = acc_finder + acc_lin + acc_sum;
       st[4] = acc_finder + acc_lin + acc_sum + acc_solve;
     }
+  }
+}
+
+// ---- split pipeline, GN half -------------------------------------------------------------------------
+// One 256-thread workgroup per frame runs aligner iterations (linearize + damped GN step, with the
+// finder's "nothing new" bookkeeping in between) until the finder needs a projective search again or
+// max_iterations is reached.  The per-correspondence operands written by the search kernel sit in
+// registers (<= 4 per thread), so a workgroup needs only the 29 x 256 term matrix in LDS and many
+// frames share a CU.  Arithmetic and summation order are those of the fused kernel.
+constexpr int kGnThreads = 256;
+constexpr int kGnSlots   = 4;  // correspondences per thread: max_fixed <= 1024
+
+struct GnShared {
+  float X[16], T[16], Tprev[16], H[36], b[6];
+  float chi_in, chi_tot;
+  unsigned long long it;
+  int converged, need_search, n_inl, n_out, n_inv, stop, flags;
+};
+
+__global__ __launch_bounds__(kGnThreads) void gn_kernel(const AlignArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid   = threadIdx.x;
+  const int frame = blockIdx.x;
+  FrameCtl* ctl   = g.ctl + frame;
+  if (ctl->done || ctl->need_search) {
+    return;  // finished, or waiting for the search kernel (block-uniform)
+  }
+  float* terms             = reinterpret_cast<float*>(smem);
+  GnShared& sh             = *reinterpret_cast<GnShared*>(smem + kTerms * kGnThreads * sizeof(float));
+  prs_pcf_state* gstate    = g.b.state + frame;
+  prs_align_result* gres   = g.b.result + frame;
+  const float4* gops       = g.ops + (size_t) frame * (size_t) g.max_fixed * 2;
+  const int nc             = g.b.n_corr[frame];
+  const float mean_dsp     = gres->mean_disparity;
+
+  if (tid < 16) {
+    sh.X[tid]     = g.b.X[(size_t) frame * 16 + tid];
+    sh.T[tid]     = gstate->local_map_in_sensor[tid];
+    sh.Tprev[tid] = gstate->local_map_in_sensor_previous[tid];
+  }
+  if (tid == 0) {
+    sh.it          = gstate->current_iteration;
+    sh.converged   = gstate->has_converged;
+    sh.need_search = 0;
+    sh.flags       = 0;
+    sh.n_inl       = ctl->n_inl;
+    sh.n_out       = ctl->n_out;
+    sh.n_inv       = ctl->n_inv;
+    sh.chi_in      = gres->chi_inliers;
+    sh.chi_tot     = gres->chi_total;
+    sh.stop        = 0;
+  }
+  for (int i = tid; i < 36; i += kGnThreads) {
+    sh.H[i] = gres->H[i];
+  }
+  if (tid < 6) {
+    sh.b[tid] = gres->b[tid];
+  }
+  // operands of this thread's correspondences stay in registers for the whole launch
+  float4 zf[kGnSlots], pm[kGnSlots];
+#pragma unroll
+  for (int k = 0; k < kGnSlots; ++k) {
+    const int c = k * kGnThreads + tid;
+    zf[k]       = c < nc ? gops[2 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    pm[k]       = c < nc ? gops[2 * c + 1] : make_float4(0.f, 0.f, 1.f, 1.f);
+  }
+  __syncthreads();
+
+  int it_align = ctl->it_align;
+  int executed = ctl->executed;
+  bool first   = true;
+  bool done    = false;
+  while (true) {
+    if (!first) {
+      // finder.setLocalMapInSensor(X); finder.compute() for aligner iteration it_align, as long as it
+      // needs no projective search (CF/correspondence_finder_projective_base_impl.cpp:138-178)
+      if (tid == 0) {
+        for (int i = 0; i < 16; ++i) {
+          sh.T[i] = sh.X[i];
+        }
+        if (!sh.converged) {
+          const unsigned long long k = g.f.number_of_solver_iterations_per_projection;
+          if (k == 0 || sh.it % k == 0 || sh.it == 1) {
+            sh.need_search = 1;
+          } else {
+            for (int i = 0; i < 16; ++i) {
+              sh.Tprev[i] = sh.T[i];
+            }
+            ++sh.it;
+          }
+        }
+        if (!sh.need_search && nc == 0) {
+          sh.flags |= PRS_WARN_NO_MATCHES;  // _postCompute (bruteforce_impl.cpp:237-242)
+        }
+      }
+      __syncthreads();
+      if (sh.need_search) {
+        break;
+      }
+    }
+    first = false;
+    ++executed;
+    if (nc < g.a.min_num_correspondences) {
+      // slice has too few correspondences: no update this iteration
+      if (tid == 0) {
+        sh.n_inl = sh.n_out = sh.n_inv = 0;
+        sh.chi_in = sh.chi_tot = 0.0f;
+      }
+      for (int i = tid; i < 36; i += kGnThreads) {
+        sh.H[i] = 0.0f;
+      }
+      if (tid < 6) {
+        sh.b[tid] = 0.0f;
+      }
+      __syncthreads();
+      ++it_align;
+      if (it_align >= g.a.max_iterations || (g.a.stop_at_fixed_point && sh.converged)) {
+        done = true;
+        break;
+      }
+      continue;
+    }
+    const PoseRegs pose = {sh.X[0], sh.X[1], sh.X[2], sh.X[3], sh.X[4], sh.X[5], sh.X[6], sh.X[7], sh.X[8], sh.X[9], sh.X[10], sh.X[11]};
+    if (tid == 0) {
+      sh.n_inl = sh.n_out = sh.n_inv = 0;
+    }
+    float run = 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kGnSlots; ++k) {
+      const int c0 = k * kGnThreads;
+      if (c0 < nc) {
+        float tv[kTerms];
+#pragma unroll
+        for (int t = 0; t < kTerms; ++t) {
+          tv[t] = 0.0f;
+        }
+        if (c0 + tid < nc) {
+          int cls;
+          factor_terms(g.a, pose, zf[k], pm[k], mean_dsp, tv, cls);
+          atomicAdd(cls == 0 ? &sh.n_inl : (cls == 1 ? &sh.n_out : &sh.n_inv), 1);
+        }
+#pragma unroll
+        for (int t = 0; t < kTerms; ++t) {
+          terms[t * kGnThreads + tid] = tv[t];
+        }
+        __syncthreads();
+        if (tid < kTerms) {
+          const int cnt      = nc - c0 < kGnThreads ? nc - c0 : kGnThreads;
+          const float4* row4 = reinterpret_cast<const float4*>(terms + tid * kGnThreads);
+          float4 n0 = row4[0], n1 = row4[1], n2 = row4[2], n3 = row4[3];
+          for (int j = 0; j < cnt; j += 16) {
+            const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
+            if (j + 16 < cnt) {
+              const int kk = (j >> 2) + 4;
+              n0 = row4[kk];
+              n1 = row4[kk + 1];
+              n2 = row4[kk + 2];
+              n3 = row4[kk + 3];
+            }
+            run += q0.x; run += q0.y; run += q0.z; run += q0.w;
+            run += q1.x; run += q1.y; run += q1.z; run += q1.w;
+            run += q2.x; run += q2.y; run += q2.z; run += q2.w;
+            run += q3.x; run += q3.y; run += q3.z; run += q3.w;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (tid < kTerms) {
+      if (tid < 21) {
+        int r = 0, firstk = 0;
+        while (tid >= firstk + (6 - r)) {
+          firstk += 6 - r;
+          ++r;
+        }
+        const int kk     = r + (tid - firstk);
+        sh.H[6 * r + kk] = run;
+        sh.H[6 * kk + r] = run;
+      } else if (tid < 27) {
+        sh.b[tid - 21] = run;
+      } else if (tid == 27) {
+        sh.chi_in = run;
+      } else {
+        sh.chi_tot = run;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float H[36], b[6], X[16];
+#pragma unroll
+      for (int i = 0; i < 36; ++i) {
+        H[i] = sh.H[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        b[i] = sh.b[i];
+      }
+      if (g.b.prior) {
+        const float* pr = g.b.prior + (size_t) frame * 42;
+#pragma unroll
+        for (int i = 0; i < 36; ++i) {
+          H[i] += pr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          b[i] += pr[36 + i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        X[i] = sh.X[i];
+      }
+      gn_step(H, b, g.a.damping, X);
+      bool same = true;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        same    = same && (__float_as_uint(X[i]) == __float_as_uint(sh.X[i]));
+        sh.X[i] = X[i];
+      }
+      sh.stop = (g.a.stop_at_fixed_point && same && sh.converged) ? 1 : 0;
+    }
+    __syncthreads();
+    ++it_align;
+    if (it_align >= g.a.max_iterations || sh.stop) {
+      done = true;
+      break;
+    }
+  }
+
+  __syncthreads();
+  if (tid < 16) {
+    g.b.X[(size_t) frame * 16 + tid]           = sh.X[tid];
+    gstate->local_map_in_sensor[tid]          = sh.T[tid];
+    gstate->local_map_in_sensor_previous[tid] = sh.Tprev[tid];
+  }
+  for (int i = tid; i < 36; i += kGnThreads) {
+    gres->H[i] = sh.H[i];
+  }
+  if (tid < 6) {
+    gres->b[tid] = sh.b[tid];
+  }
+  if (tid == 0) {
+    gstate->current_iteration = sh.it;
+    gres->chi_inliers         = sh.chi_in;
+    gres->chi_total           = sh.chi_tot;
+    gres->num_inliers         = sh.n_inl;
+    gres->num_outliers        = sh.n_out;
+    gres->num_invalid         = sh.n_inv;
+    gres->num_correspondences = nc;
+    gres->status              = sh.n_inl >= g.a.min_num_inliers ? 1 : 0;
+    gres->iterations          = g.a.max_iterations;
+    gres->iterations_executed = executed;
+    ctl->flags |= sh.flags;
+    gres->warnings   = ctl->flags;
+    ctl->it_align    = it_align;
+    ctl->executed    = executed;
+    ctl->n_inl       = sh.n_inl;
+    ctl->n_out       = sh.n_out;
+    ctl->n_inv       = sh.n_inv;
+    ctl->need_search = done ? 0 : 1;
+    ctl->done        = done ? 1 : 0;
+    if (!done) {
+      atomicAdd(g.pending, 1);
+    }
+  }
+}
+
+__global__ void split_init_kernel(FrameCtl* ctl, prs_align_result* res, int* pending, int batch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < batch) {
+    FrameCtl c;
+    c.it_align    = 0;
+    c.need_search = 1;
+    c.done        = 0;
+    c.executed    = 0;
+    c.flags       = 0;
+    c.n_inl = c.n_out = c.n_inv = 0;
+    ctl[i]                      = c;
+    prs_align_result r;
+    for (int k = 0; k < 36; ++k) {
+      r.H[k] = 0.0f;
+    }
+    for (int k = 0; k < 6; ++k) {
+      r.b[k] = 0.0f;
+    }
+    r.chi_inliers = r.chi_total = r.mean_disparity = 0.0f;
+    r.num_inliers = r.num_outliers = r.num_invalid = r.num_correspondences = 0;
+    r.status = r.iterations = r.iterations_executed = r.warnings = 0;
+    res[i]                                                        = r;
+  }
+  if (i == 0) {
+    *pending = 0;
   }
 }
 
@@ -1006,7 +1413,27 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   g.lut_cap = (int) lut_cap;
   uint32_t off = 0;
   g.off_db       = off; off = align_up16(off + nf * 8);
-  g.off_rowfirst = off; off = align_up16(off + (R + 2) * 2);
+  // 2-D cell grid over the canvas: 16 x 32 px cells, coarsened until there are at most 2048 of them
+  int sy = 4, sx = 5;
+  auto cells_of = [&](int shift_y, int shift_x, int& ncy, int& ncx) {
+    ncy = ((int) R + (1 << shift_y) - 1) >> shift_y;
+    ncx = (finder->projector.canvas_cols + (1 << shift_x) - 1) >> shift_x;
+    return ncy * ncx;
+  };
+  int ncy = 0, ncx = 0;
+  while (cells_of(sy, sx, ncy, ncx) > 2048) {
+    if (ncy > ncx) {
+      ++sy;
+    } else {
+      ++sx;
+    }
+  }
+  g.cell_sy  = sy;
+  g.cell_sx  = sx;
+  g.cell_ncy = ncy;
+  g.cell_ncx = ncx;
+  g.ncells   = ncy * ncx;
+  g.off_cellstart = off; off = align_up16(off + ((uint32_t) g.ncells + 2) * 2);
   g.off_cfix     = off; off = align_up16(off + nf * 16);
   g.off_cmov     = off; off = align_up16(off + nf * 16);
   g.off_sh       = off; off = align_up16(off + (uint32_t) sizeof(AlignShared));
@@ -1021,7 +1448,8 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   // GN-phase terms; the region also serves the database build (hist + slot + bucket) and the disparity column
   g.off_terms = off;
   uint32_t terms_bytes       = kTerms * kAlignThreads * 4;
-  const uint32_t build_bytes = (R + 2) * 4 + (nf + 2) * 2 * 2 + 16;
+  const uint32_t histcap     = (R > (uint32_t) g.ncells ? R : (uint32_t) g.ncells) + 2;
+  const uint32_t build_bytes = histcap * 4 + (nf + 2) * 2 * 3 + (R + 2) * 2 + 16;
   if (build_bytes > terms_bytes) {
     terms_bytes = build_bytes;
   }
@@ -1038,17 +1466,79 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   if (!g.cand) {
     return ctx_fail(ctx, PRS_ERR_HIP, "prs_align_batch_run: candidate scratch allocation failed");
   }
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+  g.ops     = nullptr;
+  g.ctl     = nullptr;
+  g.pending = nullptr;
+  hipStream_t stream = ctx_stream(ctx);
+  hipError_t e;
+  const bool split = mode == PRS_MODE_ALIGN && !ctx_fused_align(ctx) && max_fixed <= kGnThreads * kGnSlots && !g.stamps;
+  if (!split) {
+    auto kernel = align_kernel<kAlignThreads>;
+    e           = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    if (e != hipSuccess) {
+      return ctx_fail_hip(ctx, e, "prs_align_batch_run attribute");
+    }
+    hipLaunchKernelGGL(kernel, dim3(batch->batch), dim3(kAlignThreads), lds, stream, g);
+    e = hipGetLastError();
+    if (e != hipSuccess) {
+      return ctx_fail_hip(ctx, e, "prs_align_batch_run launch");
+    }
+    if (g.stamps) {
+      ctx_report_stamps(ctx, batch->batch, 5, "align: finder | linearize | sequential sums | GN solve  (cycles accumulated over the frame loop)");
+    }
+    return PRS_OK;
+  }
+  // ---- split pipeline: search kernel (512 threads/frame) and GN kernel (operands in registers,
+  //      ~30 KB LDS, many frames per CU) alternate; every launch skips frames that do not wait for it.
+  const size_t ops_bytes = (size_t) batch->batch * (size_t) max_fixed * 2 * sizeof(float4);
+  const size_t ctl_bytes = (size_t) batch->batch * sizeof(FrameCtl) + 256;
+  unsigned char* small   = static_cast<unsigned char*>(ctx_device_scratch_slot(ctx, 3, ctl_bytes));
+  g.ops                  = static_cast<float4*>(ctx_device_scratch_slot(ctx, 2, ops_bytes));
+  if (!small || !g.ops) {
+    return ctx_fail(ctx, PRS_ERR_HIP, "prs_align_batch_run: split-pipeline scratch allocation failed");
+  }
+  g.pending = reinterpret_cast<int*>(small);
+  g.ctl     = reinterpret_cast<FrameCtl*>(small + 256);
+  AlignArgs gs = g;
+  gs.mode      = kModeSplitSearch;
+  auto skernel = align_kernel<kSearchThreads>;
+  const size_t lds_gn = (size_t) kTerms * kGnThreads * sizeof(float) + sizeof(GnShared) + 16;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(skernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_align_batch_run attribute");
   }
-  hipLaunchKernelGGL(align_kernel, dim3(batch->batch), dim3(kAlignThreads), lds, ctx_stream(ctx), g);
-  e = hipGetLastError();
-  if (e != hipSuccess) {
-    return ctx_fail_hip(ctx, e, "prs_align_batch_run launch");
-  }
-  if (g.stamps) {
-    ctx_report_stamps(ctx, batch->batch, 5, "align: finder | linearize | sequential sums | GN solve  (cycles accumulated over the frame loop)");
+  hipLaunchKernelGGL(split_init_kernel, dim3((batch->batch + 255) / 256), dim3(256), 0, stream, g.ctl, batch->result, g.pending, batch->batch);
+  // nominal schedule: searches at finder iterations 0, 1, k, 2k, ... until the finder latches (typically
+  // 4 rounds); retries can shift it, so completion is confirmed by reading back the pending counter
+  int rounds_left = 5;
+  int total       = 0;
+  const int limit = 2 * aligner->max_iterations + 8;
+  for (;;) {
+    for (int r = 0; r < rounds_left; ++r) {
+      (void) hipMemsetAsync(g.pending, 0, sizeof(int), stream);
+      hipLaunchKernelGGL(skernel, dim3(batch->batch), dim3(kSearchThreads), lds, stream, gs);
+      hipLaunchKernelGGL(gn_kernel, dim3(batch->batch), dim3(kGnThreads), lds_gn, stream, g);
+      ++total;
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) {
+      return ctx_fail_hip(ctx, e, "prs_align_batch_run split launch");
+    }
+    int pending = 0;
+    e           = hipMemcpyAsync(&pending, g.pending, sizeof(int), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) {
+      e = hipStreamSynchronize(stream);
+    }
+    if (e != hipSuccess) {
+      return ctx_fail_hip(ctx, e, "prs_align_batch_run split completion check");
+    }
+    if (pending == 0) {
+      break;
+    }
+    if (total > limit) {
+      return ctx_fail(ctx, PRS_ERR_HIP, "prs_align_batch_run: split pipeline did not finish");
+    }
+    rounds_left = 4;
   }
   return PRS_OK;
 }

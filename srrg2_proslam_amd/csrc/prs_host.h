@@ -13,6 +13,7 @@ struct prs_context {
   hipStream_t stream    = nullptr;  // stream work is enqueued on
   hipStream_t own       = nullptr;  // stream created (and destroyed) by the context
   std::string last_error;
+  bool fused_align      = false;    // PRS_FUSED_ALIGN=1: one fused kernel per frame loop instead of the split search/GN pipeline
   bool force_unstaged   = false;    // test hook: PRS_FORCE_UNSTAGED=1 selects the no-LDS-staging variant
   // reusable device scratch for the host-pointer entry points
   void* d_scratch       = nullptr;
@@ -33,6 +34,9 @@ int ctx_fail(prs_context* ctx, int status, const char* what);
 int ctx_fail_hip(prs_context* ctx, hipError_t e, const char* what);
 inline hipStream_t ctx_stream(prs_context* ctx) {
   return ctx->stream;
+}
+inline bool ctx_fused_align(const prs_context* ctx) {
+  return ctx->fused_align;
 }
 inline bool ctx_force_unstaged(const prs_context* ctx) {
   return ctx->force_unstaged;
