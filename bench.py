@@ -159,7 +159,7 @@ def main():
 
     ctx = ops.Context(local_rank)
     stream = torch.cuda.Stream(device=dev)
-    sp = ops.stereo_params(cfg["stereo_matcher"], cfg["camera"]["rows"])
+    sp = ops.stereo_params(cfg["stereo_matcher"], cfg["camera"]["rows"], cfg["camera"]["cols"])
     tp = ops.triangulator_params(cfg)
     pp = ops.pcf_params(cfg)
     ap = ops.aligner_params(cfg, stop_at_fixed_point=0 if args.all_iterations else 1)

@@ -118,6 +118,7 @@ public:
   PropertyUnsignedInt param_epipolar_line_thickness_pixels{0};
   // extent of the row table (image rows); the reference needs none because it compare-sorts
   PropertyUnsignedInt param_image_rows{4096};
+  PropertyUnsignedInt param_image_cols{0};  // 0 = unknown; the image width selects the faster binned kernel
 
   void setFixed(const FixedType* fixed_) {
     _fixed              = fixed_;
@@ -153,6 +154,7 @@ public:
     p.maximum_disparity_pixels              = (int32_t) param_maximum_disparity_pixels.value();
     p.epipolar_line_thickness_pixels        = (int32_t) param_epipolar_line_thickness_pixels.value();
     p.image_rows                            = (int32_t) param_image_rows.value();
+    p.image_cols                            = (int32_t) param_image_cols.value();
     _correspondences->clear();
     _correspondences->resize(_fixed->size() + 1);
     int32_t n    = 0;

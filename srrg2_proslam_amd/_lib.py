@@ -35,6 +35,7 @@ class StereoParams(C.Structure):
         ("maximum_disparity_pixels", C.c_int32),
         ("epipolar_line_thickness_pixels", C.c_int32),
         ("image_rows", C.c_int32),
+        ("image_cols", C.c_int32),
     ]
 
 

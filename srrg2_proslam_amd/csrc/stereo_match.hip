@@ -709,6 +709,13 @@ int stereo_match_batch_launch(prs_context* ctx, const prs_stereo_params* params,
   if (params->epipolar_line_thickness_pixels > 120) {
     return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_stereo_match_batch: epipolar_line_thickness_pixels > 120");
   }
+  {
+    // second-generation kernel when the image width is stated and the frame fits it
+    const int rc4 = stereo_match_v4_launch(ctx, params, batch);
+    if (rc4 != 1) {
+      return rc4;
+    }
+  }
   StereoArgs a;
   a.p        = *params;
   a.b        = *batch;

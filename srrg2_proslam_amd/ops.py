@@ -59,7 +59,8 @@ class Context:
         _check(self, _lib.load().prs_context_synchronize(self._h), "prs_context_synchronize")
 
 
-def stereo_params(cfg_matcher, image_rows):
+def stereo_params(cfg_matcher, image_rows, image_cols=0):
+    """image_cols > 0 states the image width and selects the binned kernel (stride <= 2048)"""
     return StereoParams(
         float(cfg_matcher["maximum_descriptor_distance"]),
         float(cfg_matcher["maximum_distance_ratio_to_second_best"]),
@@ -67,6 +68,7 @@ def stereo_params(cfg_matcher, image_rows):
         int(cfg_matcher["maximum_disparity_pixels"]),
         int(cfg_matcher["epipolar_line_thickness_pixels"]),
         int(image_rows),
+        int(image_cols),
     )
 
 

@@ -61,7 +61,7 @@ def test_hip_reproduces_stereo_golden(hip_ctx, path):
     cfg = configs.get(str(g["cfg_name"]))
     m = dict(cfg["stereo_matcher"])
     m["epipolar_line_thickness_pixels"] = int(g["thickness"])
-    sp = ops.stereo_params(m, cfg["camera"]["rows"])
+    sp = ops.stereo_params(m, cfg["camera"]["rows"], cfg["camera"]["cols"])
     corr, flags = ops.stereo_match(hip_ctx, sp, g["uv_left"], g["desc_left"], g["uv_right"], g["desc_right"])
     assert np.array_equal(corr["fixed_idx"], g["corr_fixed"]) and np.array_equal(corr["moving_idx"], g["corr_moving"])
     assert np.array_equal(corr["response"], g["corr_response"]) and flags == int(g["flags"])
