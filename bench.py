@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames generated on the host and tiled")
     ap.add_argument("--cpu-frames", type=int, default=384, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--binned-matcher", action="store_true", help="use the second-generation (row, column-block) binned matcher kernel")
     ap.add_argument("--all-iterations", action="store_true", help="disable the exact fixed-point early exit of the GN loop")
     return ap.parse_args()
 
@@ -159,7 +160,7 @@ def main():
 
     ctx = ops.Context(local_rank)
     stream = torch.cuda.Stream(device=dev)
-    sp = ops.stereo_params(cfg["stereo_matcher"], cfg["camera"]["rows"], cfg["camera"]["cols"])
+    sp = ops.stereo_params(cfg["stereo_matcher"], cfg["camera"]["rows"], cfg["camera"]["cols"] if args.binned_matcher else 0)
     tp = ops.triangulator_params(cfg)
     pp = ops.pcf_params(cfg)
     ap = ops.aligner_params(cfg, stop_at_fixed_point=0 if args.all_iterations else 1)

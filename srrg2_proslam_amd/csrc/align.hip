@@ -331,12 +331,19 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
     if (tid == 0) {
       float acc = 0.0f;
       int i     = 0;
-      for (; i + 4 <= nF; i += 4) {
-        const float4 q = *reinterpret_cast<const float4*>(terms + i);
-        acc += q.x;
-        acc += q.y;
-        acc += q.z;
-        acc += q.w;
+      const float4* t4 = reinterpret_cast<const float4*>(terms);
+      float4 n0 = t4[0], n1 = t4[1], n2 = t4[2], n3 = t4[3];  // the column is padded with zeros up to a multiple of 16
+      for (; i + 16 <= nF; i += 16) {
+        const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
+        const int k = (i >> 2) + 4;
+        n0 = t4[k];
+        n1 = t4[k + 1];
+        n2 = t4[k + 2];
+        n3 = t4[k + 3];
+        acc += q0.x; acc += q0.y; acc += q0.z; acc += q0.w;
+        acc += q1.x; acc += q1.y; acc += q1.z; acc += q1.w;
+        acc += q2.x; acc += q2.y; acc += q2.z; acc += q2.w;
+        acc += q3.x; acc += q3.y; acc += q3.z; acc += q3.w;
       }
       for (; i < nF; ++i) {
         acc += terms[i];
@@ -362,6 +369,9 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
   }
 
   unsigned long long acc_finder = 0, acc_lin = 0, acc_sum = 0, acc_solve = 0, t_mark = 0;
+  unsigned long long acc_db = 0, acc_search = 0, acc_pass2 = 0, acc_filter = 0, acc_commit = 0, t_sub = 0;
+#define SUB_MARK() (t_sub = (g.stamps && tid == 0) ? (unsigned long long) clock64() : 0ull)
+#define SUB_ACC(v) do { if (g.stamps && tid == 0) { const unsigned long long now_ = (unsigned long long) clock64(); v += now_ - t_sub; t_sub = now_; } } while (0)
 #define ALIGN_MARK() (t_mark = (g.stamps && tid == 0) ? (unsigned long long) clock64() : 0ull)
 #define ALIGN_ACC(v) do { if (g.stamps && tid == 0) { v += (unsigned long long) clock64() - t_mark; } } while (0)
   const int max_it = (g.mode == PRS_MODE_ALIGN && !sh.error) ? g.a.max_iterations : (sh.error ? 0 : 1);
@@ -442,6 +452,7 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
           break;
         }
 
+        SUB_MARK();
         // -- the lattice lives in LDS: (re)build it on the first search of a launch and after every reset
         if (!db_built) {
           // _initializeDatabase (square_impl.cpp:8-31).  The reference scans a row-sorted vector; its
@@ -571,6 +582,7 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
           db_built = true;
         }
 
+        SUB_ACC(acc_db);
         // -- projection + candidate search (:165-166, :192-200)
         const int rad = (int) sh.radius;
         for (int i = tid; i < nF; i += T) {
@@ -602,8 +614,25 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
           const float max_dd = g.f.maximum_descriptor_distance;
           const float r2f    = (float) (sh.radius * sh.radius);
           int projected      = 0;
-          for (int m = tid; m < nM; m += T) {
-            const float4 p = gmov[m];
+          // four queries per thread are fetched together (point + 256-bit row: 48 B each) so the
+          // global-memory latency is paid once per block of queries, not once per query
+          for (int m0 = tid; m0 < nM; m0 += 4 * T) {
+           float4 pre_p[4];
+           au32x4 pre_q0[4], pre_q1[4];
+#pragma unroll
+           for (int qi = 0; qi < 4; ++qi) {
+             const int mm = m0 + qi * T < nM ? m0 + qi * T : m0;
+             pre_p[qi]     = gmov[mm];
+             pre_q0[qi]    = gmd[2 * mm];
+             pre_q1[qi]    = gmd[2 * mm + 1];
+           }
+#pragma unroll
+           for (int qi = 0; qi < 4; ++qi) {
+            const int m = m0 + qi * T;
+            if (m >= nM) {
+              continue;
+            }
+            const float4 p = pre_p[qi];
             // PointProjectorPinhole_::compute (external)
             const float x = ((W0 * p.x + W1 * p.y) + W2 * p.z) + W3;
             const float y = ((W4 * p.x + W5 * p.y) + W6 * p.z) + W7;
@@ -620,7 +649,7 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
             }
             if (visible) {
               ++projected;
-              const au32x4 q0 = gmd[2 * m], q1 = gmd[2 * m + 1];
+              const au32x4 q0 = pre_q0[qi], q1 = pre_q1[qi];
               // top-2 on (distance, canonical lattice position) keys: identical to the reference's
               // sequential "strictly smaller wins" scan, but independent of the visiting order
               uint32_t bestk = kNoneU32, seck = kNoneU32;
@@ -658,11 +687,10 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
                     const uint2 e  = db[pos];
                     const int drow = (int) (int16_t) (e.x & 0xffffu);
                     const int dcol = (int) (int16_t) (e.x >> 16);
-                    const int fi   = (int) (e.y & 0xffffu);
                     bool accept;
                     if (!lattice) {
                       // exact radius query (kdtree_impl.cpp:39-50)
-                      const float2 c = fuv[fi];
+                      const float2 c = fuv[e.y & 0xffffu];
                       const float du = c.x - u, dv = c.y - v;
                       accept = !(du * du + dv * dv > r2f);
                     } else if (drow < rmin || drow >= rmax) {
@@ -682,6 +710,7 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
                       accept = dcol > col - width && dcol < col + width;
                     }
                     if (accept) {
+                      const int fi     = (int) (e.y & 0xffffu);
                       const uint32_t d = (uint32_t) hamming_regs(fdesc[2 * fi], fdesc[2 * fi + 1], q0, q1);
                       // kdtree_impl.cpp:54: the best is initialised to maximum_descriptor_distance
                       if (lattice || (float) d < max_dd) {
@@ -716,12 +745,14 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
               }
             }
             cand[m] = cd;
+           }
           }
           if (projected) {
             atomicAdd(&sh.n_projected, projected);
           }
         }
         __syncthreads();
+        SUB_ACC(acc_search);
         // -- second lowest response per fixed index (:57-68): minimum over everything but the winner
         for (int m = tid; m < nM; m += T) {
           const uint2 cd = cand[m];
@@ -739,6 +770,7 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
           }
         }
         __syncthreads();
+        SUB_ACC(acc_pass2);
         // -- _filterCorrespondences (:41-102) in ascending fixed index; second[] is recycled to hold
         //    the output slot of accepted entries
         {
@@ -824,6 +856,7 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
         if (sh.decision == kDecisionRetry) {
           continue;
         }
+        SUB_ACC(acc_filter);
         // -- commit: correspondences->swap(filtered) (:268) + per-correspondence operands for the factor
         for (int f = tid; f < nF; f += T) {
           const uint32_t slot = second[f];
@@ -845,6 +878,7 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
           }
         }
         __syncthreads();
+        SUB_ACC(acc_commit);
         break;
       }  // finder compute()
       if (sh.error) {
@@ -1053,6 +1087,11 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
       st[2] = acc_finder + acc_lin;
       st[3] = acc_finder + acc_lin + acc_sum;
       st[4] = acc_finder + acc_lin + acc_sum + acc_solve;
+      st[5] = st[4] + acc_db;
+      st[6] = st[5] + acc_search;
+      st[7] = st[6] + acc_pass2;
+      st[8] = st[7] + acc_filter;
+      st[9] = st[8] + acc_commit;
     }
   }
 }
@@ -1453,8 +1492,8 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   if (build_bytes > terms_bytes) {
     terms_bytes = build_bytes;
   }
-  if (nf * 4 + 16 > terms_bytes) {
-    terms_bytes = nf * 4 + 16;
+  if (nf * 4 + 160 > terms_bytes) {
+    terms_bytes = nf * 4 + 160;
   }
   const uint32_t t_end = align_up16(off + terms_bytes);
   const size_t lds     = u > t_end ? u : t_end;
@@ -1484,7 +1523,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
       return ctx_fail_hip(ctx, e, "prs_align_batch_run launch");
     }
     if (g.stamps) {
-      ctx_report_stamps(ctx, batch->batch, 5, "align: finder | linearize | sequential sums | GN solve  (cycles accumulated over the frame loop)");
+      ctx_report_stamps(ctx, batch->batch, 10, "align (fused, 256 threads): finder | linearize | sequential sums | GN solve || of finder: lattice build | projection+search | second-best pass | filter | commit");
     }
     return PRS_OK;
   }

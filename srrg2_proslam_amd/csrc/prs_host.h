@@ -14,6 +14,7 @@ struct prs_context {
   hipStream_t own       = nullptr;  // stream created (and destroyed) by the context
   std::string last_error;
   bool fused_align      = false;    // PRS_FUSED_ALIGN=1: one fused kernel per frame loop instead of the split search/GN pipeline
+  int ablate            = 0;        // PRS_ABLATE=<mask>: diagnostic phase skipping (wrong results, timing only)
   bool matcher_v3       = false;    // PRS_MATCHER_V3=1: always use the first-generation matcher kernel
   bool force_unstaged   = false;    // test hook: PRS_FORCE_UNSTAGED=1 selects the no-LDS-staging variant
   // reusable device scratch for the host-pointer entry points
@@ -39,6 +40,9 @@ inline hipStream_t ctx_stream(prs_context* ctx) {
 inline bool ctx_fused_align(const prs_context* ctx) {
   return ctx->fused_align;
 }
+inline int ctx_ablate(const prs_context* ctx) {
+  return ctx->ablate;
+}
 inline bool ctx_matcher_v3(const prs_context* ctx) {
   return ctx->matcher_v3;
 }
@@ -54,6 +58,10 @@ unsigned long long* ctx_stamps(prs_context* ctx, size_t bytes);
 // synchronises and prints mean per-phase cycle counts (n_stamps consecutive stamps per block)
 void ctx_report_stamps(prs_context* ctx, int blocks, int n_stamps, const char* legend);
 
+// exact integer form of `best < max_distance && best / second < max_ratio` (epipolar_impl.cpp:171-173),
+// evaluated on the host with the same IEEE float operations the reference performs:
+// accept iff best < *best_lim && best <= bmax[second] (index 257 = no second candidate)
+void fill_accept_table(const prs_stereo_params* params, int* best_lim, int16_t* bmax258);
 int stereo_match_v4_launch(prs_context* ctx, const prs_stereo_params* params, const prs_stereo_batch* batch);
 int stereo_match_batch_launch(prs_context* ctx, const prs_stereo_params* params, const prs_stereo_batch* batch);
 int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs_aligner_params* aligner, const prs_align_batch* batch, int mode);

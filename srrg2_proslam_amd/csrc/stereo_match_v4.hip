@@ -736,6 +736,27 @@ __global__ __launch_bounds__(kV4Threads, 4) void stereo_match_v4_kernel(const St
   }
 }
 
+void fill_accept_table(const prs_stereo_params* params, int* best_lim, int16_t* bmax) {
+  const float max_dist = params->maximum_descriptor_distance, ratio = params->maximum_distance_ratio_to_second_best;
+  int lim = 0;
+  while (lim <= 256 && (float) lim < max_dist) {
+    ++lim;
+  }
+  *best_lim = lim;
+  for (int s = 0; s <= 257; ++s) {
+    const float fs = s == 257 ? 3.402823466e+38f : (float) s;
+    int bm         = -1;
+    for (int b = 0; b <= 256; ++b) {
+      if ((float) b / fs < ratio) {
+        bm = b;  // monotone in b for fs > 0; for fs == 0 the quotient is NaN or +inf: never accepted
+      } else if (s != 0) {
+        break;
+      }
+    }
+    bmax[s] = (int16_t) (s == 0 ? -1 : bm);
+  }
+}
+
 static inline uint32_t v4_align16(uint32_t v) {
   return (v + 15u) / 16u * 16u;
 }
@@ -761,28 +782,7 @@ int stereo_match_v4_launch(prs_context* ctx, const prs_stereo_params* params, co
   a.cbs = cbs;
   a.ncb = ncb;
   a.nb  = params->image_rows * ncb;
-  // exact integer form of `best < max_distance && best / second < max_ratio` (epipolar_impl.cpp:171-173),
-  // evaluated here with the same IEEE float operations the reference performs
-  {
-    const float max_dist = params->maximum_descriptor_distance, ratio = params->maximum_distance_ratio_to_second_best;
-    int lim = 0;
-    while (lim <= 256 && (float) lim < max_dist) {
-      ++lim;
-    }
-    a.best_lim = lim;
-    for (int s = 0; s <= 257; ++s) {
-      const float fs = s == 257 ? 3.402823466e+38f : (float) s;
-      int bm         = -1;
-      for (int b = 0; b <= 256; ++b) {
-        if ((float) b / fs < ratio) {
-          bm = b;  // monotone in b for fs > 0; for fs == 0 the quotient is NaN or +inf: never accepted
-        } else if (s != 0) {
-          break;
-        }
-      }
-      a.bmax[s] = (int16_t) (s == 0 ? -1 : bm);
-    }
-  }
+  fill_accept_table(params, &a.best_lim, a.bmax);
   const uint32_t nwords = ((uint32_t) stride + 31) / 32;
   uint32_t off = 0;
   const uint32_t bin_bytes = v4_align16(((uint32_t) a.nb + 2) * 2);

@@ -28,7 +28,7 @@ for b in range(uniq, B):
 print("gen+upload %.1fs" % (time.time() - t0))
 ctx = ops.Context(0)
 ctx.use_torch_stream()
-sp = ops.stereo_params(cfg["stereo_matcher"], cfg["camera"]["rows"], cfg["camera"]["cols"])
+sp = ops.stereo_params(cfg["stereo_matcher"], cfg["camera"]["rows"], cfg["camera"]["cols"] if os.environ.get("BINNED") == "1" else 0)
 tp = ops.triangulator_params(cfg)
 for epi in (None, tp):
     for _ in range(3):
