@@ -112,6 +112,33 @@ def cpu_baseline(cfg, frames, n_frames):
     return n_frames / dt, dt, poses
 
 
+
+def pmc_traffic_bytes(kernel_substrings, frames_per_launch):
+    """HBM bytes per bench step of the named kernels (= per launch for the matcher) from the committed rocprofv3 PMC passes of this same
+    command (profiles/rNN/rocprof_summary.json, written by tools/profile_round.sh: FETCH_SIZE and
+    WRITE_SIZE collected in separate passes).  Per /opt/skills/guides/MI355X_MICROARCH.md the
+    counters are KiB and FETCH_SIZE reports half of wide coalesced reads on gfx950, so it is doubled.
+    Returns (bytes, source) or (None, None) when no summary matches this configuration."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "rocprof_summary.json")), reverse=True):
+        try:
+            summ = json.load(open(path))
+            if int(summ.get("frames_per_launch", 2048)) != int(frames_per_launch):
+                continue
+            total = 0.0
+            steps = [v["FETCH_SIZE"]["launches"] for k, v in summ["pmc_fetch"].items() if "stereo_match_kernel" in k][0]
+            for sub in kernel_substrings:
+                f = [v["FETCH_SIZE"] for k, v in summ["pmc_fetch"].items() if sub in k]
+                w = [v["WRITE_SIZE"] for k, v in summ["pmc_write"].items() if sub in k]
+                if not f or not w:
+                    raise KeyError(sub)
+                # launches of this kernel per bench step (the matcher is launched once per step)
+                total += (2.0 * f[0]["mean"] + w[0]["mean"]) * 1024.0 * (f[0]["launches"] / steps)
+            return total, os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
 def main():
     args = parse()
     import torch
@@ -218,6 +245,9 @@ def main():
     gbps_match = B * bytes_match / (ms_match * 1e-3) / 1e9
     gbps_align = B * bytes_align / (ms_align * 1e-3) / 1e9
     fps = world * B * args.steps / elapsed
+    traffic_match, traffic_src = pmc_traffic_bytes(["stereo_match_kernel"], B)
+    # all search + GN rounds of one step
+    traffic_align, _ = pmc_traffic_bytes(["align_kernel", "gn_kernel"], B)
 
     out = {
         "metric": "tracked frames/sec on KITTI-00 stereo (1241x376, ~2k kp); SE(3) vs ref",
@@ -252,19 +282,22 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": gbps_match / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": traffic_match,
+            "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate PMC passes)",
+            "traffic_source": traffic_src,
             "ms_per_launch": ms_match,
             "algorithmic_bytes_per_frame": bytes_match,
             "frames_per_launch": B,
         },
         "roofline_align": {
-            "kernel": "align_kernel (time-dominant: serial GN chain, latency/issue bound, not HBM bound)",
+            "kernel": "align_kernel<512> (projective search) + gn_kernel, all rounds of one step "
+                      "(time-dominant: serial GN chain, latency/issue bound, not HBM bound)",
             "bound": "hbm",
             "achieved": gbps_align,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": gbps_align / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": traffic_align,
             "ms_per_launch": ms_align,
             "algorithmic_bytes_per_frame": bytes_align,
             "frames_per_launch": B,

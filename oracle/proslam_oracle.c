@@ -1519,3 +1519,71 @@ int orc_bruteforce_match(const uint8_t* desc_fixed,
   }
   return flags;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* 8f #2: scene clipper (mapping/scene_clipper_projective_3d.cpp:9-67)                         */
+/* ------------------------------------------------------------------------------------------ */
+int orc_scene_clip(const orc_projector* proj,
+                   const float* robot_in_local_map,
+                   const float* sensor_in_robot,
+                   const float* scene_xyzw,
+                   const uint8_t* scene_desc,
+                   int n,
+                   float* clipped_xyzw,
+                   uint8_t* clipped_desc,
+                   int32_t* global_indices,
+                   int* n_clipped) {
+  if (n <= 0) {
+    return ORC_WARN_EMPTY_INPUT; /* :21-28: status Ready, clipped scene untouched */
+  }
+  float camera_pose[16], W[16];
+  orc_se3_mul(robot_in_local_map, sensor_in_robot, camera_pose); /* :46 */
+  orc_se3_inverse(camera_pose, W);
+  float I[16];
+  orc_se3_identity(I);
+  /* :61 exact element-wise comparison (-0.0f == 0.0f as in the reference's matrix operator!=) */
+  int differs = 0;
+  for (int k = 0; k < 16; ++k) {
+    if (sensor_in_robot[k] != I[k]) {
+      differs = 1;
+    }
+  }
+  const float* S   = sensor_in_robot;
+  const float cols = (float) proj->canvas_cols;
+  const float rows = (float) proj->canvas_rows;
+  int m            = 0;
+  for (int i = 0; i < n; ++i) {
+    const float px = scene_xyzw[4 * i + 0], py = scene_xyzw[4 * i + 1], pz = scene_xyzw[4 * i + 2];
+    /* same projector arithmetic as orc_project (section 8a6) */
+    const float x = ((W[0] * px + W[1] * py) + W[2] * pz) + W[3];
+    const float y = ((W[4] * px + W[5] * py) + W[6] * pz) + W[7];
+    const float z = ((W[8] * px + W[9] * py) + W[10] * pz) + W[11];
+    if (z < proj->range_min || z > proj->range_max) {
+      continue;
+    }
+    const float hx = proj->fx * x + proj->cx * z;
+    const float hy = proj->fy * y + proj->cy * z;
+    const float u  = hx / z;
+    const float v  = hy / z;
+    if (u < 0.0f || u >= cols || v < 0.0f || v >= rows) {
+      continue;
+    }
+    float ox = x, oy = y, oz = z;
+    if (differs) { /* transformInPlace<Isometry>(sensor_in_robot), :61-63 */
+      ox = ((S[0] * x + S[1] * y) + S[2] * z) + S[3];
+      oy = ((S[4] * x + S[5] * y) + S[6] * z) + S[7];
+      oz = ((S[8] * x + S[9] * y) + S[10] * z) + S[11];
+    }
+    clipped_xyzw[4 * m + 0] = ox;
+    clipped_xyzw[4 * m + 1] = oy;
+    clipped_xyzw[4 * m + 2] = oz;
+    clipped_xyzw[4 * m + 3] = scene_xyzw[4 * i + 3];
+    if (scene_desc && clipped_desc) {
+      memcpy(clipped_desc + 32 * (size_t) m, scene_desc + 32 * (size_t) i, 32);
+    }
+    global_indices[m] = i;
+    ++m;
+  }
+  *n_clipped = m;
+  return m == 0 ? ORC_WARN_NO_PROJECTION : 0;
+}

@@ -261,6 +261,24 @@ int orc_bruteforce_match(const uint8_t* desc_fixed,
                          int capacity,
                          int* n_out);
 
+/* ---- section 8f next #2: SceneClipperProjective3D::compute (mapping/scene_clipper_projective_3d.cpp:9-67)
+ * camera pose = robot_in_local_map * sensor_in_robot (:46); the projector keeps the points inside
+ * range and canvas and returns them IN THE CAMERA FRAME with their source indices (:53); if
+ * sensor_in_robot is not exactly the identity the kept points are moved into the robot frame (:61-63).
+ * scene_xyzw: [n][4], w is carried through (the per-landmark information scale column);
+ * returns ORC_WARN_EMPTY_INPUT for an empty scene (outputs untouched, :21-28), ORC_WARN_NO_PROJECTION
+ * when nothing survives (:55-58), else 0. */
+int orc_scene_clip(const orc_projector* proj,
+                   const float* robot_in_local_map,
+                   const float* sensor_in_robot,
+                   const float* scene_xyzw,
+                   const uint8_t* scene_desc,
+                   int n,
+                   float* clipped_xyzw,
+                   uint8_t* clipped_desc,
+                   int32_t* global_indices,
+                   int* n_clipped);
+
 #ifdef __cplusplus
 }
 #endif
