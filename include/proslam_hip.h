@@ -335,6 +335,52 @@ PRS_API int prs_gn_step(prs_context* ctx, const float* H36, const float* b6, flo
  * (aligner_slice_processor_projective.cpp:46-52: n > 2 ? 1 + log(n) : 1) */
 PRS_API void prs_info_scale_from_nopt(const uint32_t* n_opt, int32_t n, float* scale);
 
+/* ================================================================================================
+ * Scene clipper
+ * replaces SceneClipperProjective3D::compute (mapping/scene_clipper_projective_3d.cpp:9-67):
+ * projector->setCameraPose(robot_in_local_map * sensor_in_robot) (:46), the projector keeps the
+ * local-map points inside [range_min, range_max] and the canvas and returns them in the camera
+ * frame together with their indices into the full scene (:53, globalIndices()); when
+ * sensor_in_robot is not exactly the identity the kept points are moved to the robot frame
+ * (:61-63).  Survivors keep ascending source order.  The clipped cloud has the layout of the
+ * aligner's `moving` arrays, so it can be consumed in place.
+ * Status per scene: PRS_WARN_EMPTY_INPUT for an empty full scene (outputs AND n_clipped left
+ * untouched, like the reference :21-28), PRS_WARN_NO_PROJECTION when nothing survives (:55-58).
+ * ============================================================================================== */
+typedef struct {
+  int32_t batch;                   /* independent scenes (one per sequence) */
+  int32_t stride;                  /* row stride (points) of every per-scene array */
+  const float* scene_xyzw;         /* [batch][stride][4] local-map points; w is carried through (information scale) */
+  const uint8_t* scene_desc;       /* [batch][stride][32] or NULL (then clipped_desc must be NULL too) */
+  const int32_t* n_scene;          /* [batch] */
+  const float* robot_in_local_map; /* [batch][16] row-major */
+  float* clipped_xyzw;             /* out [batch][stride][4] */
+  uint8_t* clipped_desc;           /* out [batch][stride][32] or NULL */
+  int32_t* global_indices;         /* out [batch][stride]: clipped index -> full-scene index */
+  int32_t* n_clipped;              /* out [batch] */
+  int32_t* status;                 /* out [batch] */
+} prs_clip_batch;
+
+/* device pointers, asynchronous on the context's stream */
+PRS_API int prs_scene_clip_batch(prs_context* ctx,
+                                 const prs_projector* projector,
+                                 const float* sensor_in_robot16, /* host */
+                                 const prs_clip_batch* batch);
+
+/* host pointers, one scene; capacity = rows available in the three output arrays (>= n) */
+PRS_API int prs_scene_clip(prs_context* ctx,
+                           const prs_projector* projector,
+                           const float* robot_in_local_map16,
+                           const float* sensor_in_robot16,
+                           const float* scene_xyzw,
+                           const uint8_t* scene_desc, /* or NULL */
+                           int32_t n,
+                           float* clipped_xyzw,
+                           uint8_t* clipped_desc, /* or NULL */
+                           int32_t* global_indices,
+                           int32_t capacity,
+                           int32_t* n_clipped);
+
 #ifdef __cplusplus
 }
 #endif

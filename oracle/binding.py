@@ -169,6 +169,8 @@ def lib():
         L.orc_tnq2t.argtypes = [vp, vp]
         L.orc_project.restype = C.c_int
         L.orc_project.argtypes = [C.POINTER(Projector), vp, vp, C.c_int, vp, vp]
+        L.orc_scene_clip.restype = C.c_int
+        L.orc_scene_clip.argtypes = [C.POINTER(Projector), vp, vp, vp, vp, C.c_int, vp, vp, vp, C.POINTER(C.c_int)]
         L.orc_pcf_create.restype = vp
         L.orc_pcf_create.argtypes = [C.POINTER(PcfParams)]
         L.orc_pcf_destroy.restype = None
@@ -437,3 +439,19 @@ def bruteforce_match(desc_fixed, desc_moving, max_distance, max_ratio):
     if flags < 0:
         raise RuntimeError("orc_bruteforce_match error %d" % flags)
     return out[: n.value].copy(), flags
+
+
+def scene_clip(projector, robot_in_local_map, sensor_in_robot, scene_xyzw, scene_desc=None):
+    """SceneClipperProjective3D::compute -> (clipped_xyzw, clipped_desc | None, global_indices, flags)"""
+    xyzw = _f32(scene_xyzw, (-1, 4))
+    n = xyzw.shape[0]
+    desc = None if scene_desc is None else _u8(scene_desc).reshape(-1, 32)
+    R, S = _f32(robot_in_local_map, (4, 4)), _f32(sensor_in_robot, (4, 4))
+    out = np.zeros((max(n, 1), 4), dtype=np.float32)
+    odesc = None if desc is None else np.zeros((max(n, 1), 32), dtype=np.uint8)
+    idx = np.zeros(max(n, 1), dtype=np.int32)
+    m = C.c_int(0)
+    flags = lib().orc_scene_clip(C.byref(projector), _ptr(R), _ptr(S), _ptr(xyzw), None if desc is None else _ptr(desc), n,
+                                 _ptr(out), None if odesc is None else _ptr(odesc), _ptr(idx), C.byref(m))
+    k = m.value
+    return out[:k].copy(), (None if odesc is None else odesc[:k].copy()), idx[:k].copy(), flags

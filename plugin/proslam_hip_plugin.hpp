@@ -9,6 +9,7 @@
 //   CorrespondenceFinderProjective{KDTree,Square,Circle,Rhombus}   -> CorrespondenceFinderProjectiveHIP<SEARCH>
 //     (CF/correspondence_finder_projective_base.h:14-155)
 //   TriangulatorRigidStereo (mapping/triangulator_rigid_stereo.h)  -> TriangulatorRigidStereoHIP
+//   SceneClipperProjective3D (mapping/scene_clipper_projective_3d.h) -> SceneClipperProjective3DHIP
 //   MultiAligner3DQR + AlignerSliceProcessorProjective*            -> AlignerProjectiveHIP
 //     (registration/aligner_slice_processor_projective.h:14-192, tests/test_aligners.cpp:1237-1253)
 //
@@ -502,6 +503,71 @@ protected:
   Status _status = Fail;
   CorrespondenceVector _correspondences;
   prs_align_result _result;
+};
+
+// ---- scene clipper ----------------------------------------------------------------------------------
+// SceneClipperProjective3D (mapping/scene_clipper_projective_3d.h:10-43, .cpp:9-67)
+class SceneClipperProjective3DHIP {
+public:
+  using SceneType = PointIntensityDescriptorVectorCloud<3>;
+  enum Status { Error = 0, Ready = 1, Successful = 2 };
+  explicit SceneClipperProjective3DHIP(ContextPtr ctx) : _ctx(std::move(ctx)), param_projector(new ProjectorPinholeHIP()) {
+    const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::memcpy(_robot_in_local_map, I, sizeof(I));
+    std::memcpy(_sensor_in_robot, I, sizeof(I));
+  }
+  void setFullScene(const SceneType* full_scene_) { _full_scene = full_scene_; }
+  void setClippedSceneInRobot(SceneType* clipped_) { _clipped_scene_in_robot = clipped_; }
+  void setRobotInLocalMap(const float* T16) { std::memcpy(_robot_in_local_map, T16, sizeof(_robot_in_local_map)); }
+  void setSensorInRobot(const float* T16) { std::memcpy(_sensor_in_robot, T16, sizeof(_sensor_in_robot)); }
+  const std::vector<int> globalIndices() const { return _global_indices; }
+  Status status() const { return _status; }
+  void compute() {
+    _status = Error;
+    if (!param_projector) throw std::runtime_error("SceneClipperProjective3D::compute|ERROR: missing projector");
+    if (!_clipped_scene_in_robot) throw std::runtime_error("SceneClipperProjective3D::compute|ERROR: missing clipped scene");
+    if (!_full_scene) throw std::runtime_error("SceneClipperProjective3D::compute|ERROR: missing global scene");
+    if (_full_scene->empty()) {  // scene_clipper_projective_3d.cpp:21-28: nothing is cleared
+      std::cerr << "SceneClipperProjective3D::compute|WARNING: global scene is empty, no clipping will be performed" << std::endl;
+      _status = Ready;
+      return;
+    }
+    const size_t n = _full_scene->size();
+    std::vector<float> xyzw(4 * n), out(4 * n);
+    std::vector<uint8_t> desc(PRS_DESC_BYTES * n), odesc(PRS_DESC_BYTES * n);
+    std::vector<int32_t> idx(n);
+    for (size_t i = 0; i < n; ++i) {  // AoS -> SoA gather; w carries the index so the other fields can be copied back
+      std::memcpy(&xyzw[4 * i], (*_full_scene)[i].coords, sizeof(float) * 3);
+      xyzw[4 * i + 3] = 0.f;
+      std::memcpy(&desc[PRS_DESC_BYTES * i], (*_full_scene)[i].descriptor_row, PRS_DESC_BYTES);
+    }
+    const prs_projector p = param_projector->raw();
+    int32_t m             = 0;
+    const int rc = prs_scene_clip(_ctx->get(), &p, _robot_in_local_map, _sensor_in_robot, xyzw.data(), desc.data(), (int32_t) n,
+                                  out.data(), odesc.data(), idx.data(), (int32_t) n, &m);
+    if (rc < 0) throw std::runtime_error(std::string("SceneClipperProjective3DHIP::compute|ERROR: ") + prs_last_error(_ctx->get()));
+    _clipped_scene_in_robot->clear();
+    _global_indices.clear();
+    _clipped_scene_in_robot->reserve((size_t) m);
+    for (int32_t k = 0; k < m; ++k) {
+      PointIntensityDescriptor3f q = (*_full_scene)[(size_t) idx[k]];  // intensity, statistics, descriptor travel with the point
+      std::memcpy(q.coords, &out[4 * (size_t) k], sizeof(float) * 3);
+      _clipped_scene_in_robot->push_back(q);
+      _global_indices.push_back(idx[k]);
+    }
+    if (rc & PRS_WARN_NO_PROJECTION) std::cerr << "SceneClipperProjective3D::compute|WARNING: clipped empty scene" << std::endl;
+    _status = Successful;
+  }
+  ProjectorPinholeHIPPtr param_projector;
+
+protected:
+  ContextPtr _ctx;
+  const SceneType* _full_scene       = nullptr;
+  SceneType* _clipped_scene_in_robot = nullptr;
+  float _robot_in_local_map[16];
+  float _sensor_in_robot[16];
+  std::vector<int> _global_indices;
+  Status _status = Error;
 };
 
 }  // namespace proslam_hip

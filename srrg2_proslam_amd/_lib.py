@@ -163,6 +163,17 @@ class AlignBatch(C.Structure):
     ]
 
 
+class ClipBatch(C.Structure):
+    """prs_clip_batch (device pointers)"""
+    _fields_ = [
+        ("batch", C.c_int32), ("stride", C.c_int32),
+        ("scene_xyzw", C.c_void_p), ("scene_desc", C.c_void_p), ("n_scene", C.c_void_p),
+        ("robot_in_local_map", C.c_void_p),
+        ("clipped_xyzw", C.c_void_p), ("clipped_desc", C.c_void_p), ("global_indices", C.c_void_p),
+        ("n_clipped", C.c_void_p), ("status", C.c_void_p),
+    ]
+
+
 MODE_ALIGN, MODE_FINDER, MODE_LINEARIZE = 0, 1, 2
 
 # every symbol include/proslam_hip.h declares: (restype, argtypes)
@@ -196,6 +207,8 @@ SYMBOLS = {
     "prs_info_scale_from_nopt": (None, [_vp, C.c_int32, _vp]),
     "prs_triangulate": (C.c_int, [_vp, C.POINTER(TriangulatorParams), _vp, C.c_int32, _vp, _vp]),
     "prs_triangulate_dev": (C.c_int, [_vp, C.POINTER(TriangulatorParams), _vp, C.c_int64, _vp]),
+    "prs_scene_clip_batch": (C.c_int, [_vp, C.POINTER(Projector), _vp, C.POINTER(ClipBatch)]),
+    "prs_scene_clip": (C.c_int, [_vp, C.POINTER(Projector), _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, C.c_int32, _i32p]),
 }
 
 _lib = None

@@ -391,4 +391,108 @@ int prs_triangulate(prs_context* ctx, const prs_triangulator_params* params, con
   return PRS_OK;
 }
 
+int prs_scene_clip_batch(prs_context* ctx, const prs_projector* projector, const float* sensor_in_robot16, const prs_clip_batch* batch) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  (void) hipSetDevice(ctx->device);
+  return scene_clip_launch(ctx, projector, sensor_in_robot16, batch);
+}
+
+int prs_scene_clip(prs_context* ctx,
+                   const prs_projector* projector,
+                   const float* robot_in_local_map16,
+                   const float* sensor_in_robot16,
+                   const float* scene_xyzw,
+                   const uint8_t* scene_desc,
+                   int32_t n,
+                   float* clipped_xyzw,
+                   uint8_t* clipped_desc,
+                   int32_t* global_indices,
+                   int32_t capacity,
+                   int32_t* n_clipped) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  // scene_clipper_projective_3d.cpp:12-20: missing projector / clipped scene / global scene throw
+  if (!projector) {
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_scene_clip: missing projector");
+  }
+  if (!clipped_xyzw || !global_indices || !n_clipped) {
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_scene_clip: missing clipped scene");
+  }
+  if (n < 0 || (n > 0 && !scene_xyzw) || !robot_in_local_map16 || !sensor_in_robot16) {
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_scene_clip: missing global scene");
+  }
+  if ((scene_desc == nullptr) != (clipped_desc == nullptr)) {
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_scene_clip: descriptor rows need both the scene and the clipped buffer");
+  }
+  if (n == 0) {
+    return PRS_WARN_EMPTY_INPUT;  // :21-28, nothing is cleared
+  }
+  if (capacity < n) {
+    return ctx_fail(ctx, PRS_ERR_CAPACITY, "prs_scene_clip: output capacity below the scene size");
+  }
+  (void) hipSetDevice(ctx->device);
+  const size_t nn      = (size_t) n;
+  const size_t b_xyzw  = align256(nn * 16);
+  const size_t b_desc  = scene_desc ? align256(nn * PRS_DESC_BYTES) : 0;
+  const size_t b_idx   = align256(nn * 4);
+  const size_t b_small = 256;  // n_scene, pose, n_clipped, status
+  const size_t total   = 2 * b_xyzw + 2 * b_desc + b_idx + b_small;
+  unsigned char* d     = static_cast<unsigned char*>(ctx_device_scratch(ctx, total));
+  unsigned char* h     = static_cast<unsigned char*>(ctx_pinned_scratch(ctx, total));
+  if (!d || !h) {
+    return ctx_fail(ctx, PRS_ERR_HIP, "prs_scene_clip: scratch allocation failed");
+  }
+  // staging layout (same on both sides): [inputs: xyzw | desc | small] [outputs: xyzw | desc | idx]
+  const size_t o_in_xyzw = 0, o_in_desc = b_xyzw, o_small = b_xyzw + b_desc;
+  const size_t o_out_xyzw = o_small + b_small, o_out_desc = o_out_xyzw + b_xyzw, o_out_idx = o_out_desc + b_desc;
+  memcpy(h + o_in_xyzw, scene_xyzw, nn * 16);
+  if (scene_desc) {
+    memcpy(h + o_in_desc, scene_desc, nn * PRS_DESC_BYTES);
+  }
+  int32_t* hs = reinterpret_cast<int32_t*>(h + o_small);
+  hs[0]       = n;   // n_scene
+  hs[1]       = 0;   // n_clipped
+  hs[2]       = 0;   // status
+  memcpy(hs + 4, robot_in_local_map16, 64);
+  hipStream_t s = ctx->stream;
+  hipError_t e  = hipMemcpyAsync(d, h, o_out_xyzw, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_scene_clip upload");
+  }
+  prs_clip_batch b;
+  b.batch              = 1;
+  b.stride             = n;
+  b.scene_xyzw         = reinterpret_cast<const float*>(d + o_in_xyzw);
+  b.scene_desc         = scene_desc ? d + o_in_desc : nullptr;
+  b.n_scene            = reinterpret_cast<const int32_t*>(d + o_small);
+  b.robot_in_local_map = reinterpret_cast<const float*>(d + o_small + 16);
+  b.clipped_xyzw       = reinterpret_cast<float*>(d + o_out_xyzw);
+  b.clipped_desc       = scene_desc ? d + o_out_desc : nullptr;
+  b.global_indices     = reinterpret_cast<int32_t*>(d + o_out_idx);
+  b.n_clipped          = reinterpret_cast<int32_t*>(d + o_small + 4);
+  b.status             = reinterpret_cast<int32_t*>(d + o_small + 8);
+  const int rc = scene_clip_launch(ctx, projector, sensor_in_robot16, &b);
+  if (rc != PRS_OK) {
+    return rc;
+  }
+  e = hipMemcpyAsync(h + o_small, d + o_small, total - o_small, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) {
+    e = hipStreamSynchronize(s);
+  }
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_scene_clip download");
+  }
+  const int32_t m = hs[1];
+  memcpy(clipped_xyzw, h + o_out_xyzw, (size_t) m * 16);
+  if (clipped_desc) {
+    memcpy(clipped_desc, h + o_out_desc, (size_t) m * PRS_DESC_BYTES);
+  }
+  memcpy(global_indices, h + o_out_idx, (size_t) m * 4);
+  *n_clipped = m;
+  return hs[2];
+}
+
 }  // extern "C"

@@ -433,3 +433,85 @@ def align_batch(ctx, finder_params, aligner_params_, frames, mode=_lib.MODE_ALIG
     rc = _lib.load().prs_align_batch_run(ctx._h, C.byref(finder_params), C.byref(aligner_params_), C.byref(d), int(mode))
     _check(ctx, rc, "prs_align_batch_run")
     return rc
+
+
+# ---- scene clipper (SceneClipperProjective3D, mapping/scene_clipper_projective_3d.cpp:9-67) ----
+def projector_params(cfg):
+    """prs_projector from a config's camera + projector section"""
+    return pcf_params(cfg).projector
+
+
+def scene_clip(ctx, projector, robot_in_local_map, sensor_in_robot, scene_xyzw, scene_desc=None):
+    """host arrays, one scene -> (clipped_xyzw [m,4], clipped_desc [m,32] | None, global_indices [m], warning bits)"""
+    xyzw = _np(scene_xyzw, np.float32, (-1, 4))
+    n = xyzw.shape[0]
+    desc = None if scene_desc is None else _np(scene_desc, np.uint8, (-1, 32))
+    R = _np(robot_in_local_map, np.float32, (16,))
+    S = _np(sensor_in_robot, np.float32, (16,))
+    out_xyzw = np.zeros((max(n, 1), 4), dtype=np.float32)
+    out_desc = None if desc is None else np.zeros((max(n, 1), 32), dtype=np.uint8)
+    out_idx = np.zeros(max(n, 1), dtype=np.int32)
+    m = C.c_int32(0)
+    rc = _lib.load().prs_scene_clip(ctx._h, C.byref(projector), _p(R), _p(S), _p(xyzw), None if desc is None else _p(desc), n,
+                                    _p(out_xyzw), None if out_desc is None else _p(out_desc), _p(out_idx), out_idx.shape[0], C.byref(m))
+    _check(ctx, rc, "prs_scene_clip")
+    k = m.value
+    return out_xyzw[:k].copy(), (None if out_desc is None else out_desc[:k].copy()), out_idx[:k].copy(), rc
+
+
+class ClipScenes:
+    """B local maps resident in HBM + the clipper's outputs (laid out like the aligner's moving cloud)"""
+
+    def __init__(self, device, batch, stride, with_desc=True):
+        import torch
+        dev = torch.device("cuda", device)
+        self.batch, self.stride = int(batch), int(stride)
+        self.scene_xyzw = torch.zeros((batch, stride, 4), dtype=torch.float32, device=dev)
+        self.scene_desc = torch.zeros((batch, stride, 32), dtype=torch.uint8, device=dev) if with_desc else None
+        self.n_scene = torch.zeros((batch,), dtype=torch.int32, device=dev)
+        self.robot_in_local_map = torch.eye(4, dtype=torch.float32, device=dev).repeat(batch, 1, 1).contiguous()
+        self.clipped_xyzw = torch.zeros((batch, stride, 4), dtype=torch.float32, device=dev)
+        self.clipped_desc = torch.zeros((batch, stride, 32), dtype=torch.uint8, device=dev) if with_desc else None
+        self.global_indices = torch.zeros((batch, stride), dtype=torch.int32, device=dev)
+        self.n_clipped = torch.zeros((batch,), dtype=torch.int32, device=dev)
+        self.status = torch.zeros((batch,), dtype=torch.int32, device=dev)
+
+    def upload(self, b, xyzw, desc, robot_in_local_map):
+        import torch
+        n = len(xyzw)
+        dev = self.scene_xyzw.device
+        if n:
+            self.scene_xyzw[b, :n] = torch.from_numpy(np.ascontiguousarray(xyzw, dtype=np.float32).reshape(n, 4)).to(dev)
+            if self.scene_desc is not None:
+                self.scene_desc[b, :n] = torch.from_numpy(np.ascontiguousarray(desc, dtype=np.uint8).reshape(n, 32)).to(dev)
+        self.n_scene[b] = n
+        self.robot_in_local_map[b] = torch.from_numpy(np.ascontiguousarray(robot_in_local_map, dtype=np.float32).reshape(4, 4)).to(dev)
+
+    def descriptor(self):
+        d = _lib.ClipBatch()
+        d.batch, d.stride = self.batch, self.stride
+        d.scene_xyzw = self.scene_xyzw.data_ptr()
+        d.scene_desc = self.scene_desc.data_ptr() if self.scene_desc is not None else None
+        d.n_scene = self.n_scene.data_ptr()
+        d.robot_in_local_map = self.robot_in_local_map.data_ptr()
+        d.clipped_xyzw = self.clipped_xyzw.data_ptr()
+        d.clipped_desc = self.clipped_desc.data_ptr() if self.clipped_desc is not None else None
+        d.global_indices = self.global_indices.data_ptr()
+        d.n_clipped = self.n_clipped.data_ptr()
+        d.status = self.status.data_ptr()
+        return d
+
+    def clipped_of(self, b):
+        m = int(self.n_clipped[b].item())
+        return (self.clipped_xyzw[b, :m].cpu().numpy(),
+                None if self.clipped_desc is None else self.clipped_desc[b, :m].cpu().numpy(),
+                self.global_indices[b, :m].cpu().numpy(), int(self.status[b].item()))
+
+
+def scene_clip_batch(ctx, projector, sensor_in_robot, scenes):
+    """enqueue the clipper for every scene of the batch on the context stream (asynchronous)"""
+    S = _np(sensor_in_robot, np.float32, (16,))
+    d = scenes.descriptor()
+    rc = _lib.load().prs_scene_clip_batch(ctx._h, C.byref(projector), _p(S), C.byref(d))
+    _check(ctx, rc, "prs_scene_clip_batch")
+    return rc

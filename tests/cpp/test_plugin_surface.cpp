@@ -218,6 +218,52 @@ static void test_TriangulatorRigidStereo(ContextPtr ctx) {
   ASSERT_EQ(triangulator.indicesInvalidated().size(), (size_t) 1);
 }
 
+// SceneClipperProjective3D: no motion keeps the cloud, half roll sees nothing, unset buffers throw
+// (tests/test_scene_clippers.cpp:186-219,257-283; scene_clipper_projective_3d.cpp:12-28)
+static void test_SceneClipperProjective3D(ContextPtr ctx) {
+  SyntheticWorld world(3);
+  SceneClipperProjective3DHIP clipper(ctx);
+  clipper.param_projector->setCameraMatrix(world.K);
+  clipper.param_projector->param_canvas_cols.setValue(1000);
+  clipper.param_projector->param_canvas_rows.setValue(1000);
+  clipper.param_projector->param_range_max.setValue(1000);
+  clipper.param_projector->param_range_min.setValue(0.1f);
+  bool thrown = false;
+  try {
+    clipper.compute();
+  } catch (const std::runtime_error&) {
+    thrown = true;
+  }
+  ASSERT_TRUE(thrown);
+  PointIntensityDescriptorVectorCloud<3> points_visible;
+  clipper.setFullScene(&world.points_in_world);
+  clipper.setClippedSceneInRobot(&points_visible);
+  clipper.compute();
+  const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, zero[3] = {0, 0, 0};
+  PointIntensityDescriptorVectorCloud<2> expected;
+  std::vector<int> truth;
+  world.project<2>(I9, zero, expected, truth);
+  ASSERT_EQ((int) clipper.status(), (int) SceneClipperProjective3DHIP::Successful);
+  ASSERT_EQ(points_visible.size(), expected.size());
+  ASSERT_EQ(clipper.globalIndices().size(), expected.size());
+  for (size_t k = 0; k < points_visible.size(); ++k) {
+    ASSERT_EQ(clipper.globalIndices()[k], truth[k]);
+    ASSERT_TRUE(points_visible[k].coords[2] > 0);
+    ASSERT_TRUE(std::memcmp(points_visible[k].descriptor_row, world.points_in_world[(size_t) truth[k]].descriptor_row, PRS_DESC_BYTES) == 0);
+  }
+  const float roll[16] = {1, 0, 0, 0, 0, -1, 0, 0, 0, 0, -1, 0, 0, 0, 0, 1};  // AngleAxisf(M_PI, UnitX)
+  clipper.setRobotInLocalMap(roll);
+  clipper.compute();
+  ASSERT_EQ(points_visible.size(), (size_t) 0);
+  // empty full scene: status Ready, previous result untouched
+  PointIntensityDescriptorVectorCloud<3> nothing;
+  points_visible.resize(5);
+  clipper.setFullScene(&nothing);
+  clipper.compute();
+  ASSERT_EQ((int) clipper.status(), (int) SceneClipperProjective3DHIP::Ready);
+  ASSERT_EQ(points_visible.size(), (size_t) 5);
+}
+
 int main() {
   ContextPtr ctx;
   try {
@@ -237,6 +283,7 @@ int main() {
   RUN(test_ProjectiveCircle_NoMotionNoNoise);
   RUN(test_AlignerSliceProcessorProjective);
   RUN(test_TriangulatorRigidStereo);
+  RUN(test_SceneClipperProjective3D);
   std::printf("%d failure(s)\n", g_failures);
   return g_failures ? 1 : 0;
 }

@@ -130,3 +130,33 @@ def make_align_case(cfg_name, seed, n_kp=600, n_moving=600, sigma_t=0.05, sigma_
     mp = syn.local_map(rng, cfg, frame, T, n_moving=n_moving)
     X0 = syn.perturb(rng, T, sigma_t, sigma_r)
     return cfg, fixed, dfix, mp, T.astype(np.float32), X0
+
+
+# ---- scene clipper inputs (tests/test_scene_clippers.cpp: ICL dense 640x480 unprojection, sparse clouds)
+def icl_dense_scene(seed=0, rows=480, cols=640):
+    """every pixel of a smooth synthetic depth image unprojected with the ICL camera
+    (tests/test_scene_clippers.cpp:28: 307200 points in camera 00); w column = 1"""
+    rng = np.random.default_rng(seed)
+    cam = configs.get("icl")["camera"]
+    r, c = np.mgrid[0:rows, 0:cols].astype(np.float32)
+    a = rng.uniform(0.5, 1.5, 4).astype(np.float32)
+    depth = (3.0 + np.sin(a[0] * c / 97.0) * np.cos(a[1] * r / 53.0) + 0.5 * np.sin(a[2] * (r + c) / 211.0)).astype(np.float32)
+    # pixel centres (+0.5) so that the round trip through the projection stays inside the canvas
+    x = ((c + np.float32(0.5)) - np.float32(cam["cx"])) / np.float32(cam["fx"]) * depth
+    y = ((r + np.float32(0.5)) - np.float32(cam["cy"])) / np.float32(cam["fy"]) * depth
+    xyzw = np.stack([x, y, depth, np.ones_like(depth)], axis=-1).reshape(-1, 4).astype(np.float32)
+    return xyzw
+
+
+def rot(axis, angle):
+    """4x4 float32 rotation about a unit axis (AngleAxisf)"""
+    c, s = np.cos(angle), np.sin(angle)
+    T = np.eye(4)
+    i, j = {"x": (1, 2), "y": (2, 0), "z": (0, 1)}[axis]
+    T[i, i], T[i, j], T[j, i], T[j, j] = c, -s, s, c
+    return T.astype(np.float32)
+
+
+def clip_projector(ob, cfg_name="icl", range_min=0.1, range_max=10.0):
+    cam = configs.get(cfg_name)["camera"]
+    return ob.Projector(cam["fx"], cam["fy"], cam["cx"], cam["cy"], int(cam["cols"]), int(cam["rows"]), range_min, range_max)
