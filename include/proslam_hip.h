@@ -381,6 +381,53 @@ PRS_API int prs_scene_clip(prs_context* ctx,
                            int32_t capacity,
                            int32_t* n_clipped);
 
+/* ================================================================================================
+ * Bijective brute-force descriptor matcher
+ * replaces CorrespondenceFinderDescriptorBasedBruteforce::compute
+ * (CF/correspondence_finder_descriptor_based_bruteforce_impl.cpp:8-155,157-199,247-293): all
+ * N_f x N_m Hamming distances, candidates below maximum_descriptor_distance, registration pool by
+ * pool (one pool per distinct distance) with the in-pool uniqueness test and Lowe's ratio on the
+ * fixed AND the moving side.  Output order: ascending (response, fixed index) -- the reference's
+ * std::sort by response alone (:94-97) leaves ties unspecified.
+ * Status per pair of clouds: PRS_WARN_EMPTY_INPUT (:217-226), PRS_WARN_NO_MATCHES (:237-242),
+ * PRS_ERR_CAPACITY when more candidates pass the threshold than candidate_capacity.
+ * ============================================================================================== */
+typedef struct {
+  float maximum_descriptor_distance;           /* CF/..bruteforce.h:22-26 (default 50); must be <= 256 */
+  float maximum_distance_ratio_to_second_best; /* CF/..bruteforce.h:27-31 (default 0.9) */
+  float minimum_matching_ratio;                /* CF/..bruteforce.h:32-36; not read by compute() */
+} prs_bruteforce_params;
+
+typedef struct {
+  int32_t batch;               /* independent (fixed, moving) cloud pairs */
+  int32_t fixed_stride;        /* <= 8192 */
+  int32_t moving_stride;       /* <= 65535 */
+  const uint8_t* fixed_desc;   /* [batch][fixed_stride][32] */
+  const int32_t* n_fixed;      /* [batch] */
+  const uint8_t* moving_desc;  /* [batch][moving_stride][32] */
+  const int32_t* n_moving;     /* [batch] */
+  prs_corr* matches;           /* out [batch][min(fixed_stride, moving_stride)] */
+  int32_t* n_matches;          /* out [batch] */
+  int32_t* status;             /* out [batch] */
+  int32_t candidate_capacity;  /* 0 = 16 * max(stride): pairs below the threshold the kernel can hold per cloud pair */
+} prs_bruteforce_batch;
+
+/* device pointers, asynchronous on the context's stream */
+PRS_API int prs_bruteforce_match_batch(prs_context* ctx,
+                                       const prs_bruteforce_params* params,
+                                       const prs_bruteforce_batch* batch);
+
+/* host pointers, one pair of clouds; capacity >= min(n_fixed, n_moving) */
+PRS_API int prs_bruteforce_match(prs_context* ctx,
+                                 const prs_bruteforce_params* params,
+                                 const uint8_t* fixed_desc,
+                                 int32_t n_fixed,
+                                 const uint8_t* moving_desc,
+                                 int32_t n_moving,
+                                 prs_corr* correspondences,
+                                 int32_t capacity,
+                                 int32_t* n_correspondences);
+
 #ifdef __cplusplus
 }
 #endif

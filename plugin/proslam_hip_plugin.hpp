@@ -6,6 +6,8 @@
 //   reference class (srrg2_proslam)                               -> class here
 //   CorrespondenceFinderDescriptorBasedEpipolar<..>                -> CorrespondenceFinderDescriptorBasedEpipolarHIP
 //     (CF/correspondence_finder_descriptor_based_epipolar.h:8-47)
+//   CorrespondenceFinderDescriptorBasedBruteforce<..>              -> CorrespondenceFinderDescriptorBasedBruteforceHIP
+//     (CF/correspondence_finder_descriptor_based_bruteforce.h:8-95)
 //   CorrespondenceFinderProjective{KDTree,Square,Circle,Rhombus}   -> CorrespondenceFinderProjectiveHIP<SEARCH>
 //     (CF/correspondence_finder_projective_base.h:14-155)
 //   TriangulatorRigidStereo (mapping/triangulator_rigid_stereo.h)  -> TriangulatorRigidStereoHIP
@@ -18,6 +20,7 @@
 // PointIntensityDescriptor_<Dim> (coordinates, intensity, 32-byte descriptor row); the adapters
 // gather them into the SoA layout the C-ABI takes.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -182,6 +185,64 @@ using CorrespondenceFinderDescriptorBasedEpipolarHIP3D3D =
   CorrespondenceFinderDescriptorBasedEpipolarHIP<PointIntensityDescriptorVectorCloud<3>, PointIntensityDescriptorVectorCloud<3>>;
 using CorrespondenceFinderDescriptorBasedEpipolarHIP2D2D =
   CorrespondenceFinderDescriptorBasedEpipolarHIP<PointIntensityDescriptorVectorCloud<2>, PointIntensityDescriptorVectorCloud<2>>;
+
+// ---- bijective brute-force matcher -----------------------------------------------------------------
+// CorrespondenceFinderDescriptorBasedBruteforce (CF/correspondence_finder_descriptor_based_bruteforce.h:8-95)
+template <typename FixedType_, typename MovingType_>
+class CorrespondenceFinderDescriptorBasedBruteforceHIP {
+public:
+  using FixedType  = FixedType_;
+  using MovingType = MovingType_;
+  explicit CorrespondenceFinderDescriptorBasedBruteforceHIP(ContextPtr ctx) : _ctx(std::move(ctx)) {}
+  // CF/correspondence_finder_descriptor_based_bruteforce.h:22-36
+  PropertyFloat param_maximum_descriptor_distance{50.0f};
+  PropertyFloat param_maximum_distance_ratio_to_second_best{0.9f};
+  PropertyFloat param_minimum_matching_ratio{0.25f};
+  void setFixed(const FixedType* fixed_) {
+    _fixed              = fixed_;
+    _fixed_changed_flag = true;
+  }
+  void setMoving(const MovingType* moving_) {
+    _moving              = moving_;
+    _moving_changed_flag = true;
+  }
+  void setCorrespondences(CorrespondenceVector* correspondences_) { _correspondences = correspondences_; }
+  void compute() {
+    // _preCompute (CF/..bruteforce_impl.cpp:203-226)
+    if (!_fixed) throw std::runtime_error("CorrespondenceFinderDescriptorBased::compute|ERROR: fixed not set");
+    if (!_moving) throw std::runtime_error("CorrespondenceFinderDescriptorBased::compute|ERROR: moving not set");
+    if (!_correspondences) throw std::runtime_error("CorrespondenceFinderDescriptorBased::compute|ERROR: correspondences not set");
+    if (!_fixed_changed_flag && !_moving_changed_flag) return;  // :12-14
+    std::vector<uint8_t> df(_fixed->size() * PRS_DESC_BYTES), dm(_moving->size() * PRS_DESC_BYTES);
+    for (size_t i = 0; i < _fixed->size(); ++i) std::memcpy(&df[i * PRS_DESC_BYTES], (*_fixed)[i].descriptor(), PRS_DESC_BYTES);
+    for (size_t i = 0; i < _moving->size(); ++i) std::memcpy(&dm[i * PRS_DESC_BYTES], (*_moving)[i].descriptor(), PRS_DESC_BYTES);
+    prs_bruteforce_params p;
+    p.maximum_descriptor_distance           = param_maximum_descriptor_distance.value();
+    p.maximum_distance_ratio_to_second_best = param_maximum_distance_ratio_to_second_best.value();
+    p.minimum_matching_ratio                = param_minimum_matching_ratio.value();
+    _correspondences->clear();
+    _correspondences->resize(std::min(_fixed->size(), _moving->size()) + 1);
+    int32_t n    = 0;
+    const int rc = prs_bruteforce_match(_ctx->get(), &p, df.data(), (int32_t) _fixed->size(), dm.data(), (int32_t) _moving->size(),
+                                        reinterpret_cast<prs_corr*>(_correspondences->data()), (int32_t) _correspondences->size(), &n);
+    if (rc < 0) {
+      _correspondences->clear();
+      throw std::runtime_error(std::string("CorrespondenceFinderDescriptorBasedBruteforceHIP::compute|ERROR: ") + prs_last_error(_ctx->get()));
+    }
+    _correspondences->resize((size_t) n);
+    warn("CorrespondenceFinderDescriptorBasedBruteforceHIP::compute", rc);
+    _fixed_changed_flag = _moving_changed_flag = false;  // _postCompute (:231-236)
+  }
+
+protected:
+  ContextPtr _ctx;
+  const FixedType* _fixed                 = nullptr;
+  const MovingType* _moving               = nullptr;
+  CorrespondenceVector* _correspondences = nullptr;
+  bool _fixed_changed_flag = false, _moving_changed_flag = false;
+};
+using CorrespondenceFinderDescriptorBasedBruteforceHIP3D3D =
+  CorrespondenceFinderDescriptorBasedBruteforceHIP<PointIntensityDescriptorVectorCloud<3>, PointIntensityDescriptorVectorCloud<3>>;
 
 // ---- pinhole projector parameters (PointProjectorPinhole_ as seen through param_projector) -------
 struct ProjectorPinholeHIP {

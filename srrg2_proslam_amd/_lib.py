@@ -174,6 +174,25 @@ class ClipBatch(C.Structure):
     ]
 
 
+class BruteforceParams(C.Structure):
+    """prs_bruteforce_params"""
+    _fields_ = [
+        ("maximum_descriptor_distance", C.c_float),
+        ("maximum_distance_ratio_to_second_best", C.c_float),
+        ("minimum_matching_ratio", C.c_float),
+    ]
+
+
+class BruteforceBatch(C.Structure):
+    """prs_bruteforce_batch (device pointers)"""
+    _fields_ = [
+        ("batch", C.c_int32), ("fixed_stride", C.c_int32), ("moving_stride", C.c_int32),
+        ("fixed_desc", C.c_void_p), ("n_fixed", C.c_void_p), ("moving_desc", C.c_void_p), ("n_moving", C.c_void_p),
+        ("matches", C.c_void_p), ("n_matches", C.c_void_p), ("status", C.c_void_p),
+        ("candidate_capacity", C.c_int32),
+    ]
+
+
 MODE_ALIGN, MODE_FINDER, MODE_LINEARIZE = 0, 1, 2
 
 # every symbol include/proslam_hip.h declares: (restype, argtypes)
@@ -207,6 +226,8 @@ SYMBOLS = {
     "prs_info_scale_from_nopt": (None, [_vp, C.c_int32, _vp]),
     "prs_triangulate": (C.c_int, [_vp, C.POINTER(TriangulatorParams), _vp, C.c_int32, _vp, _vp]),
     "prs_triangulate_dev": (C.c_int, [_vp, C.POINTER(TriangulatorParams), _vp, C.c_int64, _vp]),
+    "prs_bruteforce_match_batch": (C.c_int, [_vp, C.POINTER(BruteforceParams), C.POINTER(BruteforceBatch)]),
+    "prs_bruteforce_match": (C.c_int, [_vp, C.POINTER(BruteforceParams), _vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
     "prs_scene_clip_batch": (C.c_int, [_vp, C.POINTER(Projector), _vp, C.POINTER(ClipBatch)]),
     "prs_scene_clip": (C.c_int, [_vp, C.POINTER(Projector), _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, C.c_int32, _i32p]),
 }

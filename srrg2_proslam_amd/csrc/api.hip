@@ -495,4 +495,97 @@ int prs_scene_clip(prs_context* ctx,
   return hs[2];
 }
 
+int prs_bruteforce_match_batch(prs_context* ctx, const prs_bruteforce_params* params, const prs_bruteforce_batch* batch) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  (void) hipSetDevice(ctx->device);
+  return bruteforce_batch_launch(ctx, params, batch);
+}
+
+int prs_bruteforce_match(prs_context* ctx,
+                         const prs_bruteforce_params* params,
+                         const uint8_t* fixed_desc,
+                         int32_t n_fixed,
+                         const uint8_t* moving_desc,
+                         int32_t n_moving,
+                         prs_corr* correspondences,
+                         int32_t capacity,
+                         int32_t* n_correspondences) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  // bruteforce_impl.cpp:203-216: unset buffers throw
+  if (!params || n_fixed < 0 || (n_fixed > 0 && !fixed_desc)) {
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_bruteforce_match: fixed not set");
+  }
+  if (n_moving < 0 || (n_moving > 0 && !moving_desc)) {
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_bruteforce_match: moving not set");
+  }
+  if (!correspondences || !n_correspondences) {
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_bruteforce_match: correspondences not set");
+  }
+  *n_correspondences = 0;
+  if (n_fixed == 0 || n_moving == 0) {
+    return PRS_WARN_EMPTY_INPUT | PRS_WARN_NO_MATCHES;  // :217-226, :237-242
+  }
+  const int32_t n_min = n_fixed < n_moving ? n_fixed : n_moving;
+  if (capacity < n_min) {
+    return ctx_fail(ctx, PRS_ERR_CAPACITY, "prs_bruteforce_match: output capacity below min(n_fixed, n_moving)");
+  }
+  (void) hipSetDevice(ctx->device);
+  const size_t b_f   = align256((size_t) n_fixed * PRS_DESC_BYTES);
+  const size_t b_m   = align256((size_t) n_moving * PRS_DESC_BYTES);
+  const size_t b_s   = 256;  // n_fixed, n_moving, n_matches, status
+  const size_t b_out = align256((size_t) n_min * sizeof(prs_corr));
+  const size_t total = b_f + b_m + b_s + b_out;
+  // slot 3: the launch itself uses slots 0..2
+  unsigned char* d   = static_cast<unsigned char*>(ctx_device_scratch_slot(ctx, 3, total));
+  unsigned char* h   = static_cast<unsigned char*>(ctx_pinned_scratch(ctx, total));
+  if (!d || !h) {
+    return ctx_fail(ctx, PRS_ERR_HIP, "prs_bruteforce_match: scratch allocation failed");
+  }
+  memcpy(h, fixed_desc, (size_t) n_fixed * PRS_DESC_BYTES);
+  memcpy(h + b_f, moving_desc, (size_t) n_moving * PRS_DESC_BYTES);
+  int32_t* hs = reinterpret_cast<int32_t*>(h + b_f + b_m);
+  hs[0] = n_fixed;
+  hs[1] = n_moving;
+  hs[2] = 0;
+  hs[3] = 0;
+  hipStream_t s = ctx->stream;
+  hipError_t e  = hipMemcpyAsync(d, h, b_f + b_m + b_s, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_bruteforce_match upload");
+  }
+  prs_bruteforce_batch b;
+  b.batch              = 1;
+  b.fixed_stride       = n_fixed;
+  b.moving_stride      = n_moving;
+  b.fixed_desc         = d;
+  b.n_fixed            = reinterpret_cast<const int32_t*>(d + b_f + b_m);
+  b.moving_desc        = d + b_f;
+  b.n_moving           = reinterpret_cast<const int32_t*>(d + b_f + b_m + 4);
+  b.matches            = reinterpret_cast<prs_corr*>(d + b_f + b_m + b_s);
+  b.n_matches          = reinterpret_cast<int32_t*>(d + b_f + b_m + 8);
+  b.status             = reinterpret_cast<int32_t*>(d + b_f + b_m + 12);
+  b.candidate_capacity = 0;
+  const int rc = bruteforce_batch_launch(ctx, params, &b);
+  if (rc != PRS_OK) {
+    return rc;
+  }
+  e = hipMemcpyAsync(h + b_f + b_m, d + b_f + b_m, b_s + b_out, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) {
+    e = hipStreamSynchronize(s);
+  }
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_bruteforce_match download");
+  }
+  if (hs[3] < 0) {
+    return ctx_fail(ctx, hs[3], "prs_bruteforce_match: more candidates below the threshold than the kernel's candidate capacity");
+  }
+  memcpy(correspondences, h + b_f + b_m + b_s, (size_t) hs[2] * sizeof(prs_corr));
+  *n_correspondences = hs[2];
+  return hs[3];
+}
+
 }  // extern "C"

@@ -1,0 +1,416 @@
+// bruteforce.hip -- CorrespondenceFinderDescriptorBasedBruteforce::compute on the device
+// (CF/correspondence_finder_descriptor_based_bruteforce_impl.cpp:8-155, pool processing :247-293,
+// Lowe checks :157-199).  SURVEY.md section 8f #4.
+//
+// The reference enumerates all N_f x N_m Hamming distances, keeps the candidates below the
+// threshold, sorts them by distance and registers them pool by pool (one pool per distinct
+// distance): a candidate is registered iff neither index is registered yet, no other pool member
+// shares its fixed or moving index, and Lowe's ratio holds in the distance list of its fixed AND
+// of its moving index.  Registrations only ever happen between pools, so the sequential loop is a
+// level-synchronous process over the distinct distances 0, 1, 2, ... -- which is how it runs here:
+//
+//   phase 1 (dense, VALU bound): one lane per fixed descriptor (rows in registers), the moving
+//            rows arrive through scalar loads (uniform address), 2 VALU per 32-bit word; the rare
+//            candidates are appended to a per-workgroup list, and the per-index distance bitmaps
+//            and candidate counts Lowe's check needs are updated;
+//   phase 2: Lowe flags per candidate (next larger distance = first set bit above d in the
+//            bitmap), counting sort of the candidates by distance level;
+//   phase 3: the levels in ascending order: pool membership, uniqueness counts, registration;
+//   phase 4: emit ordered by (distance, fixed index) -- the canonical order this build defines for the
+//            reference's unstable std::sort by response only (:94-97).
+#include "prs_device.h"
+#include "prs_host.h"
+
+namespace prs {
+
+constexpr int kBfThreads = 1024;
+constexpr int kBfWaves   = kBfThreads / 64;
+constexpr int kBfLevels  = 256;  // distances 0..255 (a candidate at 256 needs a threshold above 256: unsupported)
+
+struct BfArgs {
+  prs_bruteforce_batch b;
+  float max_ratio;
+  int lim;             // candidate iff d < lim  (== (float) d < maximum_descriptor_distance)
+  int nw;              // bitmap words per index = ceil(lim / 32)
+  int cap;             // candidate capacity per frame
+  uint2* cand;         // [grid][cap] (fixed | moving << 16, distance)
+  uint2* by_level;     // [grid][cap] (fixed | moving << 16, lowe ok)
+  uint32_t* bitmaps;   // [grid][(fixed_stride + moving_stride) * nw]
+  // LDS carve (bytes)
+  uint32_t off_cnt_f, off_cnt_m, off_reg_f, off_reg_m, off_acc, off_hist;
+};
+
+// Lowe's ratio against the sorted distance list of one index (bruteforce_impl.cpp:157-199):
+// a single-entry list passes (:181-184); otherwise the first strictly larger distance is the second
+// best, none = equal = reject (:163-165), else best / second < maximum ratio in float.
+__device__ __forceinline__ bool lowe_ok(uint32_t* bm, int nw, uint32_t count, int d, float max_ratio) {
+  if (count == 1) {
+    return true;
+  }
+  int second = -1;
+  int w      = d >> 5;
+  // the rows are updated with device-scope atomics: read them the same way (never from a stale L1 line)
+  uint32_t word = __hip_atomic_load(&bm[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~((2u << (d & 31)) - 1u);  // bits above d
+  while (true) {
+    if (word) {
+      second = (w << 5) + __ffs(word) - 1;
+      break;
+    }
+    if (++w >= nw) {
+      break;
+    }
+    word = __hip_atomic_load(&bm[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (second < 0) {
+    return false;
+  }
+  return (float) d / (float) second < max_ratio;
+}
+
+template <int KPT>
+__global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* cnt_f  = reinterpret_cast<uint32_t*>(smem + a.off_cnt_f);   // candidates per fixed; later pool counts
+  uint32_t* cnt_m  = reinterpret_cast<uint32_t*>(smem + a.off_cnt_m);
+  uint8_t* reg_f   = smem + a.off_reg_f;                                 // registered_indices_fixed (:105)
+  uint8_t* reg_m   = smem + a.off_reg_m;
+  uint32_t* acc    = reinterpret_cast<uint32_t*>(smem + a.off_acc);     // per fixed: moving | level << 16, ~0 = none
+  uint32_t* hist   = reinterpret_cast<uint32_t*>(smem + a.off_hist);    // [256] candidates per level
+  uint32_t* lstart = hist + kBfLevels;                                   // [257]
+  uint32_t* lfill  = lstart + kBfLevels + 1;                             // [256]
+  uint32_t* hist2  = lfill + kBfLevels;                                  // [256] registrations per level
+  uint32_t* misc   = hist2 + kBfLevels;                                  // [0] candidates, [1] registrations
+  const int tid    = threadIdx.x;
+  const int lane   = tid & 63;
+  const int wave   = tid >> 6;
+  uint2* __restrict__ cand     = a.cand + (size_t) blockIdx.x * a.cap;
+  uint2* __restrict__ by_level = a.by_level + (size_t) blockIdx.x * a.cap;
+  uint32_t* __restrict__ bm_f  = a.bitmaps + (size_t) blockIdx.x * (size_t) (a.b.fixed_stride + a.b.moving_stride) * a.nw;
+  uint32_t* __restrict__ bm_m  = bm_f + (size_t) a.b.fixed_stride * a.nw;
+
+  for (int frame = blockIdx.x; frame < a.b.batch; frame += gridDim.x) {
+    int nf = a.b.n_fixed[frame];
+    int nm = a.b.n_moving[frame];
+    nf     = nf < 0 ? 0 : (nf > a.b.fixed_stride ? a.b.fixed_stride : nf);
+    nm     = nm < 0 ? 0 : (nm > a.b.moving_stride ? a.b.moving_stride : nm);
+    const int out_stride = a.b.fixed_stride < a.b.moving_stride ? a.b.fixed_stride : a.b.moving_stride;
+    prs_corr* __restrict__ out = a.b.matches + (size_t) frame * out_stride;
+    const uint32_t* __restrict__ gdf =
+      reinterpret_cast<const uint32_t*>(a.b.fixed_desc + (size_t) frame * a.b.fixed_stride * PRS_DESC_BYTES);
+    // the moving rows are read-only for the whole launch: constant address space + uniform index
+    // = scalar loads (s_load_dwordx8), the row sits in SGPRs and feeds v_xor as the scalar operand
+    typedef const uint32_t __attribute__((address_space(4))) const_u32;
+    const_u32* gdm = (const_u32*) (uintptr_t) (a.b.moving_desc + (size_t) frame * a.b.moving_stride * PRS_DESC_BYTES);
+
+    // ---- reset ----------------------------------------------------------------------------------
+    for (int i = tid; i < nf; i += kBfThreads) {
+      cnt_f[i] = 0;
+      reg_f[i] = 0;
+      acc[i]   = 0xffffffffu;
+    }
+    for (int i = tid; i < nm; i += kBfThreads) {
+      cnt_m[i] = 0;
+      reg_m[i] = 0;
+    }
+    for (int i = tid; i < (nf + nm) * a.nw; i += kBfThreads) {
+      // fixed rows first, moving rows behind them (bm_m = bm_f + fixed_stride * nw)
+      const int idx = i < nf * a.nw ? i : (a.b.fixed_stride * a.nw + (i - nf * a.nw));
+      bm_f[idx]     = 0;
+    }
+    for (int i = tid; i < 4 * kBfLevels + 8; i += kBfThreads) {
+      hist[i] = 0;
+    }
+    __syncthreads();
+
+    // ---- phase 1: all pairs (bruteforce_impl.cpp:32-79) ----------------------------------------
+    uint32_t fd[KPT][8];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+      const int f  = k * kBfThreads + tid;
+      const int fc = f < nf ? f : (nf > 0 ? nf - 1 : 0);
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        fd[k][w] = nf > 0 ? gdf[8 * fc + w] : 0u;
+      }
+    }
+    uint32_t md_next[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      md_next[w] = nm > 0 ? gdm[w] : 0u;
+    }
+    for (int m = 0; m < nm; ++m) {
+      // uniform address: the row travels through the scalar cache into SGPRs; the next row is
+      // requested before this one is scored
+      uint32_t md[8];
+      const int mn = m + 1 < nm ? m + 1 : m;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        md[w]      = md_next[w];
+        md_next[w] = gdm[8 * mn + w];
+      }
+#pragma unroll
+      for (int k = 0; k < KPT; ++k) {
+        int d = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          d += __popc(fd[k][w] ^ md[w]);
+        }
+        const int f = k * kBfThreads + tid;
+        if (d < a.lim && f < nf) {  // :52
+          const uint32_t slot = atomicAdd(&misc[0], 1u);
+          if (slot < (uint32_t) a.cap) {
+            cand[slot] = make_uint2((uint32_t) f | ((uint32_t) m << 16), (uint32_t) d);
+          }
+          const uint32_t bit = 1u << (d & 31);
+          atomicOr(&bm_f[f * a.nw + (d >> 5)], bit);
+          atomicOr(&bm_m[m * a.nw + (d >> 5)], bit);
+          atomicAdd(&cnt_f[f], 1u);
+          atomicAdd(&cnt_m[m], 1u);
+          atomicAdd(&hist[d], 1u);
+        }
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t n_cand = misc[0];
+    int status            = (nf == 0 || nm == 0) ? PRS_WARN_EMPTY_INPUT : PRS_OK;  // bruteforce_impl.cpp:217-226
+    if (n_cand > (uint32_t) a.cap) {
+      if (tid == 0) {
+        a.b.n_matches[frame] = 0;
+        a.b.status[frame]    = PRS_ERR_CAPACITY;
+      }
+      __syncthreads();
+      continue;
+    }
+    if (n_cand == 0) {  // :83-85
+      if (tid == 0) {
+        a.b.n_matches[frame] = 0;
+        a.b.status[frame]    = status | PRS_WARN_NO_MATCHES;
+      }
+      __syncthreads();
+      continue;
+    }
+
+    // ---- phase 2: level offsets, Lowe flags, candidates grouped by level -----------------------
+    if (wave == 0) {
+      uint32_t carry = 0;
+      for (int base = 0; base < kBfLevels; base += 64) {
+        const uint32_t h   = hist[base + lane];
+        uint32_t incl      = h;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t v = __shfl_up(incl, o, 64);
+          if (lane >= o) {
+            incl += v;
+          }
+        }
+        lstart[base + lane] = carry + incl - h;
+        carry += __shfl(incl, 63, 64);
+      }
+      if (lane == 0) {
+        lstart[kBfLevels] = carry;
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n_cand; i += kBfThreads) {
+      const uint2 c  = cand[i];
+      const int f    = (int) (c.x & 0xffffu);
+      const int m    = (int) (c.x >> 16);
+      const int d    = (int) c.y;
+      const bool ok  = lowe_ok(bm_f + (size_t) f * a.nw, a.nw, cnt_f[f], d, a.max_ratio) &&
+                      lowe_ok(bm_m + (size_t) m * a.nw, a.nw, cnt_m[m], d, a.max_ratio);  // :279-284
+      const uint32_t pos = lstart[d] + atomicAdd(&lfill[d], 1u);
+      by_level[pos]      = make_uint2(c.x, ok ? 1u : 0u);
+    }
+    __syncthreads();
+    // the candidate counts are dead: the arrays now count pool members per index
+    for (int i = tid; i < nf; i += kBfThreads) {
+      cnt_f[i] = 0;
+    }
+    for (int i = tid; i < nm; i += kBfThreads) {
+      cnt_m[i] = 0;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- phase 3: one pool per distinct distance, ascending (:113-157, :247-293) ----------------
+    for (int d = 0; d < a.lim && d < kBfLevels; ++d) {
+      const uint32_t s0 = lstart[d], s1 = lstart[d + 1];
+      if (s0 == s1) {
+        continue;  // uniform
+      }
+      // pool = candidates of this distance whose indices are both unregistered (:117-118)
+      for (uint32_t i = s0 + tid; i < s1; i += kBfThreads) {
+        const uint32_t x = by_level[i].x;
+        const int f = (int) (x & 0xffffu), m = (int) (x >> 16);
+        if (!reg_f[f] && !reg_m[m]) {
+          atomicAdd(&cnt_f[f], 1u);
+          atomicAdd(&cnt_m[m], 1u);
+        }
+      }
+      __syncthreads();
+      // unique in the pool (:256-266) + Lowe on both sides -> registered (:285-289).  A candidate that
+      // registers has pool counts 1/1, so no other pool member reads the flags it sets.
+      for (uint32_t i = s0 + tid; i < s1; i += kBfThreads) {
+        const uint2 c = by_level[i];
+        const int f = (int) (c.x & 0xffffu), m = (int) (c.x >> 16);
+        if (!reg_f[f] && !reg_m[m] && cnt_f[f] == 1u && cnt_m[m] == 1u && c.y) {
+          acc[f] = (uint32_t) m | ((uint32_t) d << 16);
+          atomicAdd(&hist2[d], 1u);
+        }
+      }
+      __syncthreads();
+      for (uint32_t i = s0 + tid; i < s1; i += kBfThreads) {
+        const uint32_t x = by_level[i].x;
+        const int f = (int) (x & 0xffffu), m = (int) (x >> 16);
+        cnt_f[f] = 0;
+        cnt_m[m] = 0;
+        const uint32_t r = acc[f];
+        if (r != 0xffffffffu && (int) (r & 0xffffu) == m && (int) (r >> 16) == d) {
+          reg_f[f] = 1;
+          reg_m[m] = 1;
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- phase 4: emit ordered by (distance, fixed index) ---------------------------------------
+    if (wave == 0) {
+      uint32_t carry = 0;
+      for (int base = 0; base < kBfLevels; base += 64) {
+        const uint32_t h   = hist2[base + lane];
+        uint32_t incl      = h;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t v = __shfl_up(incl, o, 64);
+          if (lane >= o) {
+            incl += v;
+          }
+        }
+        lfill[base + lane] = carry + incl - h;  // first output slot of the level
+        carry += __shfl(incl, 63, 64);
+      }
+      if (lane == 0) {
+        misc[1] = carry;
+      }
+    }
+    __syncthreads();
+    for (int d = wave; d < a.lim && d < kBfLevels; d += kBfWaves) {
+      if (hist2[d] == 0) {
+        continue;
+      }
+      uint32_t running = lfill[d];
+      for (int base = 0; base < nf; base += 64) {
+        const int f      = base + lane;
+        const uint32_t r = f < nf ? acc[f] : 0xffffffffu;
+        const bool mine  = r != 0xffffffffu && (int) (r >> 16) == d;
+        const uint64_t mask = __ballot(mine);
+        if (mine) {
+          const uint32_t slot = running + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+          prs_corr c;
+          c.fixed_idx  = f;
+          c.moving_idx = (int) (r & 0xffffu);
+          c.response   = (float) d;
+          out[slot]    = c;
+        }
+        running += (uint32_t) __popcll(mask);
+      }
+    }
+    if (tid == 0) {
+      const uint32_t n = misc[1];
+      a.b.n_matches[frame] = (int) n;
+      a.b.status[frame]    = status | (n == 0 ? PRS_WARN_NO_MATCHES : 0);  // :237-242
+    }
+    __syncthreads();
+  }
+}
+
+static inline uint32_t bf_align16(uint32_t v) {
+  return (v + 15u) & ~15u;
+}
+
+int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* params, const prs_bruteforce_batch* batch) {
+  if (!params || !batch || !batch->fixed_desc || !batch->n_fixed) {
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_bruteforce_match: fixed not set");  // bruteforce_impl.cpp:204-206
+  }
+  if (!batch->moving_desc || !batch->n_moving) {
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_bruteforce_match: moving not set");  // :207-210
+  }
+  if (!batch->matches || !batch->n_matches || !batch->status) {
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_bruteforce_match: correspondences not set");  // :211-214
+  }
+  if (batch->batch <= 0) {
+    return PRS_OK;
+  }
+  if (batch->fixed_stride <= 0 || batch->moving_stride <= 0 || batch->fixed_stride > 8192 || batch->moving_stride > 65535) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_bruteforce_match: fixed_stride must be in [1,8192], moving_stride in [1,65535]");
+  }
+  BfArgs a;
+  a.b         = *batch;
+  a.max_ratio = params->maximum_distance_ratio_to_second_best;
+  // (float) d < maximum_descriptor_distance for integer d  <=>  d < lim
+  int lim = 0;
+  while (lim <= 257 && (float) lim < params->maximum_descriptor_distance) {
+    ++lim;
+  }
+  if (lim > kBfLevels) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_bruteforce_match: maximum_descriptor_distance above 256 bits");
+  }
+  a.lim = lim;
+  a.nw  = lim > 0 ? (lim + 31) / 32 : 1;
+  const int big = batch->fixed_stride > batch->moving_stride ? batch->fixed_stride : batch->moving_stride;
+  a.cap = batch->candidate_capacity > 0 ? batch->candidate_capacity : 16 * big;
+  int cus = 256;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) {
+      cus = prop.multiProcessorCount;
+    }
+  }
+  const int grid = batch->batch < cus ? batch->batch : cus;
+  const size_t b_cand = (size_t) grid * a.cap * sizeof(uint2);
+  const size_t b_bm   = (size_t) grid * (size_t) (batch->fixed_stride + batch->moving_stride) * a.nw * sizeof(uint32_t);
+  a.cand     = static_cast<uint2*>(ctx_device_scratch_slot(ctx, 0, b_cand));
+  a.by_level = static_cast<uint2*>(ctx_device_scratch_slot(ctx, 1, b_cand));
+  a.bitmaps  = static_cast<uint32_t*>(ctx_device_scratch_slot(ctx, 2, b_bm));
+  if (!a.cand || !a.by_level || !a.bitmaps) {
+    return ctx_fail(ctx, PRS_ERR_HIP, "prs_bruteforce_match: scratch allocation failed");
+  }
+  uint32_t off = 0;
+  a.off_cnt_f = off; off = bf_align16(off + (uint32_t) batch->fixed_stride * 4);
+  a.off_cnt_m = off; off = bf_align16(off + (uint32_t) batch->moving_stride * 4);
+  a.off_reg_f = off; off = bf_align16(off + (uint32_t) batch->fixed_stride);
+  a.off_reg_m = off; off = bf_align16(off + (uint32_t) batch->moving_stride);
+  a.off_acc   = off; off = bf_align16(off + (uint32_t) batch->fixed_stride * 4);
+  a.off_hist  = off; off = bf_align16(off + (4 * kBfLevels + 8) * 4);
+  if (off > 160u * 1024u) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_bruteforce_match: clouds do not fit the 160 KiB LDS");
+  }
+  const int kpt = (batch->fixed_stride + kBfThreads - 1) / kBfThreads;
+  hipStream_t stream = ctx_stream(ctx);
+  hipError_t e       = hipSuccess;
+  auto launch = [&](auto kernel) {
+    if (off > 64u * 1024u) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) off);
+    }
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBfThreads), off, stream, a);
+      e = hipGetLastError();
+    }
+  };
+  if (kpt <= 1) {
+    launch(bruteforce_kernel<1>);
+  } else if (kpt <= 2) {
+    launch(bruteforce_kernel<2>);
+  } else if (kpt <= 4) {
+    launch(bruteforce_kernel<4>);
+  } else {
+    launch(bruteforce_kernel<8>);
+  }
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_bruteforce_match launch");
+  }
+  return PRS_OK;
+}
+
+}  // namespace prs

@@ -515,3 +515,73 @@ def scene_clip_batch(ctx, projector, sensor_in_robot, scenes):
     rc = _lib.load().prs_scene_clip_batch(ctx._h, C.byref(projector), _p(S), C.byref(d))
     _check(ctx, rc, "prs_scene_clip_batch")
     return rc
+
+
+# ---- bijective brute-force matcher (CF/correspondence_finder_descriptor_based_bruteforce_impl.cpp) ----
+def bruteforce_params(maximum_descriptor_distance=50.0, maximum_distance_ratio_to_second_best=0.9, minimum_matching_ratio=0.25):
+    """defaults of CF/correspondence_finder_descriptor_based_bruteforce.h:22-36"""
+    return _lib.BruteforceParams(maximum_descriptor_distance, maximum_distance_ratio_to_second_best, minimum_matching_ratio)
+
+
+def bruteforce_match(ctx, params, desc_fixed, desc_moving):
+    """host arrays, one pair of clouds -> (correspondences [CORR_DTYPE] ordered by (response, fixed), warning bits)"""
+    df, dm = _np(desc_fixed, np.uint8, (-1, 32)), _np(desc_moving, np.uint8, (-1, 32))
+    nf, nm = df.shape[0], dm.shape[0]
+    out = np.zeros(max(min(nf, nm), 1), dtype=CORR_DTYPE)
+    n = C.c_int32(0)
+    rc = _lib.load().prs_bruteforce_match(ctx._h, C.byref(params), _p(df), nf, _p(dm), nm, _p(out), out.shape[0], C.byref(n))
+    _check(ctx, rc, "prs_bruteforce_match")
+    return out[: n.value].copy(), rc
+
+
+class BruteforceClouds:
+    """B (fixed, moving) descriptor cloud pairs resident in HBM + the matcher's outputs"""
+
+    def __init__(self, device, batch, fixed_stride, moving_stride, candidate_capacity=0):
+        import torch
+        dev = torch.device("cuda", device)
+        self.batch, self.fixed_stride, self.moving_stride = int(batch), int(fixed_stride), int(moving_stride)
+        self.candidate_capacity = int(candidate_capacity)
+        self.fixed_desc = torch.zeros((batch, fixed_stride, 32), dtype=torch.uint8, device=dev)
+        self.moving_desc = torch.zeros((batch, moving_stride, 32), dtype=torch.uint8, device=dev)
+        self.n_fixed = torch.zeros((batch,), dtype=torch.int32, device=dev)
+        self.n_moving = torch.zeros((batch,), dtype=torch.int32, device=dev)
+        self.out_stride = min(self.fixed_stride, self.moving_stride)
+        self.matches = torch.zeros((batch, self.out_stride, 3), dtype=torch.int32, device=dev)
+        self.n_matches = torch.zeros((batch,), dtype=torch.int32, device=dev)
+        self.status = torch.zeros((batch,), dtype=torch.int32, device=dev)
+
+    def upload(self, b, desc_fixed, desc_moving):
+        import torch
+        dev = self.fixed_desc.device
+        nf, nm = len(desc_fixed), len(desc_moving)
+        if nf:
+            self.fixed_desc[b, :nf] = torch.from_numpy(np.ascontiguousarray(desc_fixed, dtype=np.uint8).reshape(nf, 32)).to(dev)
+        if nm:
+            self.moving_desc[b, :nm] = torch.from_numpy(np.ascontiguousarray(desc_moving, dtype=np.uint8).reshape(nm, 32)).to(dev)
+        self.n_fixed[b], self.n_moving[b] = nf, nm
+
+    def descriptor(self):
+        d = _lib.BruteforceBatch()
+        d.batch, d.fixed_stride, d.moving_stride = self.batch, self.fixed_stride, self.moving_stride
+        d.fixed_desc, d.n_fixed = self.fixed_desc.data_ptr(), self.n_fixed.data_ptr()
+        d.moving_desc, d.n_moving = self.moving_desc.data_ptr(), self.n_moving.data_ptr()
+        d.matches, d.n_matches, d.status = self.matches.data_ptr(), self.n_matches.data_ptr(), self.status.data_ptr()
+        d.candidate_capacity = self.candidate_capacity
+        return d
+
+    def matches_of(self, b):
+        n = int(self.n_matches[b].item())
+        raw = self.matches[b, :n].cpu().numpy()
+        out = np.zeros(n, dtype=CORR_DTYPE)
+        out["fixed_idx"], out["moving_idx"] = raw[:, 0], raw[:, 1]
+        out["response"] = raw[:, 2].view(np.float32)
+        return out
+
+
+def bruteforce_match_batch(ctx, params, clouds):
+    """enqueue the matcher for every cloud pair of the batch on the context stream (asynchronous)"""
+    d = clouds.descriptor()
+    rc = _lib.load().prs_bruteforce_match_batch(ctx._h, C.byref(params), C.byref(d))
+    _check(ctx, rc, "prs_bruteforce_match_batch")
+    return rc

@@ -264,6 +264,33 @@ static void test_SceneClipperProjective3D(ContextPtr ctx) {
   ASSERT_EQ(points_visible.size(), (size_t) 5);
 }
 
+// SyntheticWorldWithDescriptorsSE3.Bruteforce_CloudVersusItself (tests/test_correspondence_finders.cpp:139-181)
+static void test_Bruteforce_CloudVersusItself(ContextPtr ctx) {
+  SyntheticWorld world(7);
+  CorrespondenceFinderDescriptorBasedBruteforceHIP3D3D finder(ctx);
+  CorrespondenceVector correspondences;
+  bool thrown = false;
+  try {
+    finder.compute();
+  } catch (const std::runtime_error&) {
+    thrown = true;
+  }
+  ASSERT_TRUE(thrown);
+  finder.setFixed(&world.points_in_world);
+  finder.setMoving(&world.points_in_world);
+  finder.setCorrespondences(&correspondences);
+  finder.compute();
+  ASSERT_EQ(correspondences.size(), world.points_in_world.size());
+  for (const Correspondence& c : correspondences) {
+    ASSERT_EQ(c.fixed_idx, c.moving_idx);
+    ASSERT_TRUE(c.response == 0.0f);
+  }
+  // neither input changed: the last result is kept (bruteforce_impl.cpp:12-14)
+  correspondences.resize(3);
+  finder.compute();
+  ASSERT_EQ(correspondences.size(), (size_t) 3);
+}
+
 int main() {
   ContextPtr ctx;
   try {
@@ -284,6 +311,7 @@ int main() {
   RUN(test_AlignerSliceProcessorProjective);
   RUN(test_TriangulatorRigidStereo);
   RUN(test_SceneClipperProjective3D);
+  RUN(test_Bruteforce_CloudVersusItself);
   std::printf("%d failure(s)\n", g_failures);
   return g_failures ? 1 : 0;
 }

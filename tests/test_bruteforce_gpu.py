@@ -1,0 +1,132 @@
+"""GPU parity of the bijective brute-force matcher through the C-ABI:
+correspondence vectors identical to the oracle INCLUDING order ((response, fixed) ascending)."""
+import numpy as np
+import pytest
+
+from srrg2_proslam_amd import ops
+from tests import helpers as hp
+
+pytestmark = pytest.mark.gpu
+
+
+def _tie_heavy(rng, n_base, n, flips):
+    """descriptors drawn from few prototypes with a handful of flipped bits: many equal distances,
+    shared best partners, pools with conflicts (bruteforce_impl.cpp:247-266)"""
+    base = rng.integers(0, 256, (n_base, 32), dtype=np.uint8)
+    out = base[rng.integers(0, n_base, n)].copy()
+    for i in range(n):
+        for _ in range(int(rng.integers(0, flips + 1))):
+            b = int(rng.integers(0, 256))
+            out[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    return out
+
+
+@pytest.mark.parametrize("max_dist,ratio", [(50.0, 0.9), (25.0, 0.8), (75.0, 0.5), (33.5, 0.95), (256.0, 1.5)])
+def test_stereo_pair_descriptors(oracle, hip_ctx, max_dist, ratio):
+    n = 2000 if max_dist < 100 else 300  # threshold 256 keeps every pair: n^2 candidates
+    cfg, fr = hp.kitti_frame(41, n=n)
+    ref, rflags = oracle.bruteforce_match(fr["desc_left"], fr["desc_right"], max_dist, ratio)
+    if max_dist >= 100:
+        from srrg2_proslam_amd import _lib
+        clouds = ops.BruteforceClouds(0, 1, n, n, candidate_capacity=n * n)
+        clouds.upload(0, fr["desc_left"], fr["desc_right"])
+        ops.bruteforce_match_batch(hip_ctx, ops.bruteforce_params(max_dist, ratio), clouds)
+        hip_ctx.synchronize()
+        got, gflags = clouds.matches_of(0), int(clouds.status[0].item())
+    else:
+        got, gflags = ops.bruteforce_match(hip_ctx, ops.bruteforce_params(max_dist, ratio), fr["desc_left"], fr["desc_right"])
+    assert len(ref) > (100 if max_dist < 100 else 0)
+    assert hp.corr_equal(ref, got) and rflags == gflags
+
+
+def test_cloud_versus_itself(oracle, hip_ctx):
+    # identical clouds: every point matches itself with response 0 (tests/test_correspondence_finders.cpp:160-181)
+    rng = np.random.default_rng(2)
+    d = rng.integers(0, 256, (777, 32), dtype=np.uint8)
+    got, _ = ops.bruteforce_match(hip_ctx, ops.bruteforce_params(), d, d)
+    ref, _ = oracle.bruteforce_match(d, d, 50.0, 0.9)
+    assert hp.corr_equal(ref, got)
+    assert len(got) == 777 and np.array_equal(got["fixed_idx"], got["moving_idx"]) and np.all(got["response"] == 0)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_pools_with_ties_and_conflicts(oracle, hip_ctx, seed):
+    rng = np.random.default_rng(100 + seed)
+    nf, nm = int(rng.integers(50, 1500)), int(rng.integers(50, 1500))
+    df = _tie_heavy(rng, 40, nf, 6)
+    dm = _tie_heavy(np.random.default_rng(100 + seed), 40, nm, 6)  # same prototypes
+    for max_dist, ratio in ((20.0, 0.9), (12.0, 0.7), (30.0, 1.0)):
+        ref, rflags = oracle.bruteforce_match(df, dm, max_dist, ratio)
+        clouds = ops.BruteforceClouds(0, 1, nf, nm, candidate_capacity=nf * nm)
+        clouds.upload(0, df, dm)
+        ops.bruteforce_match_batch(hip_ctx, ops.bruteforce_params(max_dist, ratio), clouds)
+        hip_ctx.synchronize()
+        assert hp.corr_equal(ref, clouds.matches_of(0)), (seed, max_dist, ratio)
+        assert int(clouds.status[0].item()) == rflags
+
+
+def test_batched_ragged_and_large_fixed_clouds(oracle, hip_ctx):
+    rng = np.random.default_rng(9)
+    sizes = [(0, 10), (10, 0), (1, 1), (1500, 2600), (2600, 1500), (1025, 64), (333, 4000)]
+    clouds = ops.BruteforceClouds(0, len(sizes), 2600, 4000)
+    inputs = []
+    for b, (nf, nm) in enumerate(sizes):
+        proto = rng.integers(0, 256, (max(nf, nm, 1), 32), dtype=np.uint8)
+        df = proto[:nf].copy()
+        dm = proto[rng.permutation(max(nf, nm, 1))[:nm]].copy()
+        flips = rng.integers(0, 256, (nm, 10))
+        for i in range(nm):
+            for bit in flips[i][: int(rng.integers(0, 11))]:
+                dm[i, bit >> 3] ^= np.uint8(1 << (bit & 7))
+        inputs.append((df, dm))
+        clouds.upload(b, df, dm)
+    ops.bruteforce_match_batch(hip_ctx, ops.bruteforce_params(50.0, 0.9), clouds)
+    hip_ctx.synchronize()
+    for b, (df, dm) in enumerate(inputs):
+        ref, rflags = oracle.bruteforce_match(df, dm, 50.0, 0.9)
+        assert hp.corr_equal(ref, clouds.matches_of(b)), b
+        assert int(clouds.status[b].item()) == rflags, b
+
+
+def test_many_pairs_share_workgroups(oracle, hip_ctx):
+    # more cloud pairs than workgroups in flight: per-workgroup scratch is reused pair after pair
+    rng = np.random.default_rng(17)
+    B, n = 600, 96
+    clouds = ops.BruteforceClouds(0, B, n, n)
+    inputs = []
+    for b in range(B):
+        nf, nm = int(rng.integers(1, n + 1)), int(rng.integers(1, n + 1))
+        df = _tie_heavy(rng, 8, nf, 4)
+        dm = np.concatenate([df[: min(nf, nm)], _tie_heavy(rng, 8, nm, 4)])[:nm]
+        inputs.append((df, dm))
+        clouds.upload(b, df, dm)
+    ops.bruteforce_match_batch(hip_ctx, ops.bruteforce_params(16.0, 0.9), clouds)
+    hip_ctx.synchronize()
+    for b in range(0, B, 7):
+        ref, rflags = oracle.bruteforce_match(inputs[b][0], inputs[b][1], 16.0, 0.9)
+        assert hp.corr_equal(ref, clouds.matches_of(b)), b
+        assert int(clouds.status[b].item()) == rflags, b
+
+
+def test_error_and_warning_contract(hip_ctx):
+    import ctypes as C
+    from srrg2_proslam_amd import _lib
+    L = _lib.load()
+    p = ops.bruteforce_params()
+    d = np.zeros((4, 32), np.uint8)
+    out = np.zeros(4, dtype=ops.CORR_DTYPE)
+    n = C.c_int32(0)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    # unset buffers throw in the reference (bruteforce_impl.cpp:203-216)
+    assert L.prs_bruteforce_match(hip_ctx._h, C.byref(p), None, 4, vp(d), 4, vp(out), 4, C.byref(n)) == -1
+    assert b"fixed not set" in L.prs_last_error(hip_ctx._h)
+    assert L.prs_bruteforce_match(hip_ctx._h, C.byref(p), vp(d), 4, None, 4, vp(out), 4, C.byref(n)) == -1
+    assert b"moving not set" in L.prs_last_error(hip_ctx._h)
+    assert L.prs_bruteforce_match(hip_ctx._h, C.byref(p), vp(d), 4, vp(d), 4, None, 4, C.byref(n)) == -1
+    assert b"correspondences not set" in L.prs_last_error(hip_ctx._h)
+    # empty clouds: warnings, empty result (:217-226, :237-242)
+    assert L.prs_bruteforce_match(hip_ctx._h, C.byref(p), vp(d), 0, vp(d), 4, vp(out), 4, C.byref(n)) == 3 and n.value == 0
+    # all-equal descriptors: n^2 candidates at distance 0 exceed the default candidate capacity -> loud error
+    big = np.zeros((300, 32), np.uint8)
+    o2 = np.zeros(300, dtype=ops.CORR_DTYPE)
+    assert L.prs_bruteforce_match(hip_ctx._h, C.byref(p), vp(big), 300, vp(big), 300, vp(o2), 300, C.byref(n)) == -2
