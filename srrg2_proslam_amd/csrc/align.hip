@@ -1116,6 +1116,9 @@ __global__ __launch_bounds__(kGnThreads) void gn_kernel(const AlignArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid   = threadIdx.x;
   const int frame = blockIdx.x;
+  // the single-wave phases (ordered sums, 6x6 solve) run on a different wave -- hence a different
+  // SIMD -- from frame to frame, so that the workgroups sharing a CU do not queue them on one SIMD
+  const int stid  = tid - 64 * (frame & (kGnThreads / 64 - 1));
   FrameCtl* ctl   = g.ctl + frame;
   if (ctl->done || ctl->need_search) {
     return;  // finished, or waiting for the search kernel (block-uniform)
@@ -1169,7 +1172,7 @@ __global__ __launch_bounds__(kGnThreads) void gn_kernel(const AlignArgs g) {
     if (!first) {
       // finder.setLocalMapInSensor(X); finder.compute() for aligner iteration it_align, as long as it
       // needs no projective search (CF/correspondence_finder_projective_base_impl.cpp:138-178)
-      if (tid == 0) {
+      if (stid == 0) {
         for (int i = 0; i < 16; ++i) {
           sh.T[i] = sh.X[i];
         }
@@ -1240,9 +1243,9 @@ __global__ __launch_bounds__(kGnThreads) void gn_kernel(const AlignArgs g) {
           terms[t * kGnThreads + tid] = tv[t];
         }
         __syncthreads();
-        if (tid < kTerms) {
+        if (stid >= 0 && stid < kTerms) {
           const int cnt      = nc - c0 < kGnThreads ? nc - c0 : kGnThreads;
-          const float4* row4 = reinterpret_cast<const float4*>(terms + tid * kGnThreads);
+          const float4* row4 = reinterpret_cast<const float4*>(terms + stid * kGnThreads);
           float4 n0 = row4[0], n1 = row4[1], n2 = row4[2], n3 = row4[3];
           for (int j = 0; j < cnt; j += 16) {
             const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
@@ -1262,26 +1265,26 @@ __global__ __launch_bounds__(kGnThreads) void gn_kernel(const AlignArgs g) {
         __syncthreads();
       }
     }
-    if (tid < kTerms) {
-      if (tid < 21) {
+    if (stid >= 0 && stid < kTerms) {
+      if (stid < 21) {
         int r = 0, firstk = 0;
-        while (tid >= firstk + (6 - r)) {
+        while (stid >= firstk + (6 - r)) {
           firstk += 6 - r;
           ++r;
         }
-        const int kk     = r + (tid - firstk);
+        const int kk     = r + (stid - firstk);
         sh.H[6 * r + kk] = run;
         sh.H[6 * kk + r] = run;
-      } else if (tid < 27) {
-        sh.b[tid - 21] = run;
-      } else if (tid == 27) {
+      } else if (stid < 27) {
+        sh.b[stid - 21] = run;
+      } else if (stid == 27) {
         sh.chi_in = run;
       } else {
         sh.chi_tot = run;
       }
     }
     __syncthreads();
-    if (tid == 0) {
+    if (stid == 0) {
       float H[36], b[6], X[16];
 #pragma unroll
       for (int i = 0; i < 36; ++i) {
