@@ -1073,11 +1073,13 @@ void orc_linearize(const orc_aligner_params* P,
     const float px = moving_xyz[3 * m + 0], py = moving_xyz[3 * m + 1], pz = moving_xyz[3 * m + 2];
 
     /* point in camera, homogeneous image point */
-    const float pcx = ((R00 * px + R01 * py) + R02 * pz) + t0;
-    const float pcy = ((R10 * px + R11 * py) + R12 * pz) + t1;
-    const float pcz = ((R20 * px + R21 * py) + R22 * pz) + t2;
-    const float hx  = fx * pcx + cx * pcz;
-    const float hy  = fy * pcy + cy * pcz;
+    /* the factor arithmetic is written with explicit fused multiply-adds (one rounding per fmaf,
+     * the same on every IEEE machine): BUILD-DEFINED like the rest of the external factor code */
+    const float pcx = fmaf(R02, pz, fmaf(R01, py, fmaf(R00, px, t0)));
+    const float pcy = fmaf(R12, pz, fmaf(R11, py, fmaf(R10, px, t1)));
+    const float pcz = fmaf(R22, pz, fmaf(R21, py, fmaf(R20, px, t2)));
+    const float hx  = fmaf(fx, pcx, cx * pcz);
+    const float hy  = fmaf(fy, pcy, cy * pcz);
     const float hz  = pcz;
     if (!(hz > 0.0f)) {
       ++out->num_invalid;
@@ -1098,7 +1100,7 @@ void orc_linearize(const orc_aligner_params* P,
     float hrx = hx;
     if (dim == ORC_FACTOR_STEREO) {
       hrx  = hx + P->baseline_left_in_right_px[0];
-      e[2] = hrx * iz - z[2];
+      e[2] = fmaf(hrx, iz, -z[2]);
     } else if (dim == ORC_FACTOR_DEPTH) {
       e[2] = hz - z[2];
     }
@@ -1123,9 +1125,9 @@ void orc_linearize(const orc_aligner_params* P,
       Jp[r][0] = Rm[r][0] * wt;
       Jp[r][1] = Rm[r][1] * wt;
       Jp[r][2] = Rm[r][2] * wt;
-      Jp[r][3] = Rm[r][2] * ay - Rm[r][1] * az;
-      Jp[r][4] = Rm[r][0] * az - Rm[r][2] * ax;
-      Jp[r][5] = Rm[r][1] * ax - Rm[r][0] * ay;
+      Jp[r][3] = fmaf(Rm[r][2], ay, -(Rm[r][1] * az));
+      Jp[r][4] = fmaf(Rm[r][0], az, -(Rm[r][2] * ax));
+      Jp[r][5] = fmaf(Rm[r][1], ax, -(Rm[r][0] * ay));
     }
     /* A = K * Jp; J = J_div(h) * A */
     const float hx_iz2 = (hx * iz) * iz;
@@ -1133,13 +1135,13 @@ void orc_linearize(const orc_aligner_params* P,
     const float hr_iz2 = (hrx * iz) * iz;
     float J[3][6];
     for (int c = 0; c < 6; ++c) {
-      const float a0 = fx * Jp[0][c] + cx * Jp[2][c];
-      const float a1 = fy * Jp[1][c] + cy * Jp[2][c];
+      const float a0 = fmaf(fx, Jp[0][c], cx * Jp[2][c]);
+      const float a1 = fmaf(fy, Jp[1][c], cy * Jp[2][c]);
       const float a2 = Jp[2][c];
-      J[0][c]        = a0 * iz - hx_iz2 * a2;
-      J[1][c]        = a1 * iz - hy_iz2 * a2;
+      J[0][c]        = fmaf(a0, iz, -(hx_iz2 * a2));
+      J[1][c]        = fmaf(a1, iz, -(hy_iz2 * a2));
       if (dim == ORC_FACTOR_STEREO) {
-        J[2][c] = a0 * iz - hr_iz2 * a2;
+        J[2][c] = fmaf(a0, iz, -(hr_iz2 * a2));
       } else if (dim == ORC_FACTOR_DEPTH) {
         J[2][c] = a2;
       } else {
@@ -1155,7 +1157,7 @@ void orc_linearize(const orc_aligner_params* P,
     o[2] = edim == 3 ? P->diagonal_info[2] * s : 0.0f;
 
     /* chi2 + saturated kernel (landmark_estimator_pose_based_smoother_impl.cpp:77-84) */
-    float chi = ((o[0] * e[0]) * e[0] + (o[1] * e[1]) * e[1]) + (o[2] * e[2]) * e[2];
+    float chi = fmaf(o[2] * e[2], e[2], fmaf(o[1] * e[1], e[1], (o[0] * e[0]) * e[0]));
     if (chi > P->chi_threshold) {
       const float scale = P->chi_threshold / chi;
       o[0] *= scale;
@@ -1175,9 +1177,9 @@ void orc_linearize(const orc_aligner_params* P,
       const float j1 = J[1][r] * o[1];
       const float j2 = J[2][r] * o[2];
       for (int c = r; c < 6; ++c) {
-        H[r][c] += (j0 * J[0][c] + j1 * J[1][c]) + j2 * J[2][c];
+        H[r][c] += fmaf(j2, J[2][c], fmaf(j1, J[1][c], j0 * J[0][c]));
       }
-      b[r] += (j0 * e[0] + j1 * e[1]) + j2 * e[2];
+      b[r] += fmaf(j2, e[2], fmaf(j1, e[1], j0 * e[0]));
     }
   }
   for (int r = 0; r < 6; ++r) {
@@ -1191,39 +1193,41 @@ void orc_linearize(const orc_aligner_params* P,
 /* IterationAlgorithmGN with damping + dense Cholesky (configurations/kitti.conf:20-22,310-315)
  * and VariableSE3QuaternionRight::applyPerturbation: X <- X * exp(dx) */
 int orc_gn_step(const orc_linear_system* sys, float damping, float* X) {
-  float L[6][6];
+  /* dense Cholesky with fused multiply-subtracts and one reciprocal per pivot (BUILD-DEFINED) */
+  float L[6][6], inv[6];
   memset(L, 0, sizeof(L));
   for (int j = 0; j < 6; ++j) {
     float s = sys->H[6 * j + j] + damping;
     for (int k = 0; k < j; ++k) {
-      s -= L[j][k] * L[j][k];
+      s = fmaf(-L[j][k], L[j][k], s);
     }
     if (!(s > 0.0f)) {
       return 1;
     }
     L[j][j] = sqrtf(s);
+    inv[j]  = 1.0f / L[j][j];
     for (int i = j + 1; i < 6; ++i) {
       float v = sys->H[6 * i + j];
       for (int k = 0; k < j; ++k) {
-        v -= L[i][k] * L[j][k];
+        v = fmaf(-L[i][k], L[j][k], v);
       }
-      L[i][j] = v / L[j][j];
+      L[i][j] = v * inv[j];
     }
   }
   float y[6], dx[6];
   for (int i = 0; i < 6; ++i) {
     float v = -sys->b[i];
     for (int k = 0; k < i; ++k) {
-      v -= L[i][k] * y[k];
+      v = fmaf(-L[i][k], y[k], v);
     }
-    y[i] = v / L[i][i];
+    y[i] = v * inv[i];
   }
   for (int i = 5; i >= 0; --i) {
     float v = y[i];
     for (int k = i + 1; k < 6; ++k) {
-      v -= L[k][i] * dx[k];
+      v = fmaf(-L[k][i], dx[k], v);
     }
-    dx[i] = v / L[i][i];
+    dx[i] = v * inv[i];
   }
   float D[16], Xn[16];
   orc_tnq2t(dx, D);

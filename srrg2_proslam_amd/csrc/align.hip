@@ -133,11 +133,13 @@ __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const 
   const int dim = a.factor_type;
   cls = 0;
     const float px = p.x, py = p.y, pz = p.z;
-    const float pcx = ((R00 * px + R01 * py) + R02 * pz) + t0;
-    const float pcy = ((R10 * px + R11 * py) + R12 * pz) + t1;
-    const float pcz = ((R20 * px + R21 * py) + R22 * pz) + t2;
-    const float hx  = fx * pcx + cx * pcz;
-    const float hy  = fy * pcy + cy * pcz;
+    // explicit fused multiply-adds (one rounding each): the factor arithmetic is defined this way on
+    // both sides of the parity test
+    const float pcx = fmaf(R02, pz, fmaf(R01, py, fmaf(R00, px, t0)));
+    const float pcy = fmaf(R12, pz, fmaf(R11, py, fmaf(R10, px, t1)));
+    const float pcz = fmaf(R22, pz, fmaf(R21, py, fmaf(R20, px, t2)));
+    const float hx  = fmaf(fx, pcx, cx * pcz);
+    const float hy  = fmaf(fy, pcy, cy * pcz);
     const float hz  = pcz;
     bool valid      = hz > 0.0f;
     float iz = 0.0f, u_pred = 0.0f, v_pred = 0.0f;
@@ -154,7 +156,7 @@ __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const 
       float hrx = hx;
       if (dim == PRS_FACTOR_STEREO) {
         hrx = hx + a.baseline_left_in_right_px[0];
-        e2  = hrx * iz - z.z;
+        e2  = fmaf(hrx, iz, -z.z);
       } else if (dim == PRS_FACTOR_DEPTH) {
         e2 = hz - z.z;
       }
@@ -176,9 +178,9 @@ __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const 
         Jp[r][0] = Rm[r][0] * wt;
         Jp[r][1] = Rm[r][1] * wt;
         Jp[r][2] = Rm[r][2] * wt;
-        Jp[r][3] = Rm[r][2] * ay - Rm[r][1] * az;
-        Jp[r][4] = Rm[r][0] * az - Rm[r][2] * ax;
-        Jp[r][5] = Rm[r][1] * ax - Rm[r][0] * ay;
+        Jp[r][3] = fmaf(Rm[r][2], ay, -(Rm[r][1] * az));
+        Jp[r][4] = fmaf(Rm[r][0], az, -(Rm[r][2] * ax));
+        Jp[r][5] = fmaf(Rm[r][1], ax, -(Rm[r][0] * ay));
       }
       const float hx_iz2 = (hx * iz) * iz;
       const float hy_iz2 = (hy * iz) * iz;
@@ -186,19 +188,19 @@ __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const 
       float J0[6], J1[6], J2[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        const float a0 = fx * Jp[0][k] + cx * Jp[2][k];
-        const float a1 = fy * Jp[1][k] + cy * Jp[2][k];
+        const float a0 = fmaf(fx, Jp[0][k], cx * Jp[2][k]);
+        const float a1 = fmaf(fy, Jp[1][k], cy * Jp[2][k]);
         const float a2 = Jp[2][k];
-        J0[k]          = a0 * iz - hx_iz2 * a2;
-        J1[k]          = a1 * iz - hy_iz2 * a2;
-        J2[k]          = dim == PRS_FACTOR_STEREO ? a0 * iz - hr_iz2 * a2 : (dim == PRS_FACTOR_DEPTH ? a2 : 0.0f);
+        J0[k]          = fmaf(a0, iz, -(hx_iz2 * a2));
+        J1[k]          = fmaf(a1, iz, -(hy_iz2 * a2));
+        J2[k]          = dim == PRS_FACTOR_STEREO ? fmaf(a0, iz, -(hr_iz2 * a2)) : (dim == PRS_FACTOR_DEPTH ? a2 : 0.0f);
       }
       // Omega = diag(info) * scale(moving point) (aligner_slice_processor_projective.cpp:46-56)
       const float s = p.w;
       float o0 = a.diagonal_info[0] * s;
       float o1 = a.diagonal_info[1] * s;
       float o2 = dim == PRS_FACTOR_MONO ? 0.0f : a.diagonal_info[2] * s;
-      float chi = ((o0 * e0) * e0 + (o1 * e1) * e1) + (o2 * e2) * e2;
+      float chi = fmaf(o2 * e2, e2, fmaf(o1 * e1, e1, (o0 * e0) * e0));
       if (chi > a.chi_threshold) {  // saturated kernel
         const float scale = a.chi_threshold / chi;
         o0 *= scale;
@@ -217,9 +219,9 @@ __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const 
         const float j0 = J0[r] * o0, j1 = J1[r] * o1, j2 = J2[r] * o2;
 #pragma unroll
         for (int k = r; k < 6; ++k) {
-          tv[t++] = (j0 * J0[k] + j1 * J1[k]) + j2 * J2[k];
+          tv[t++] = fmaf(j2, J2[k], fmaf(j1, J1[k], j0 * J0[k]));
         }
-        tv[21 + r] = (j0 * e0 + j1 * e1) + j2 * e2;
+        tv[21 + r] = fmaf(j2, e2, fmaf(j1, e1, j0 * e0));
       }
     }
 

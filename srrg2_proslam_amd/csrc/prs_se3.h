@@ -146,20 +146,22 @@ __device__ __forceinline__ void tnq2t(const float* v6, float* T) {
 // (H + damping I) dx = -b by dense Cholesky; X <- X * exp(dx).  H: full 6x6 row-major (lower part
 // read), returns false (X untouched) when the system is not positive definite.
 __device__ __forceinline__ bool gn_step(const float* H, const float* b, float damping, float* X) {
-  float L[6][6];
+  // dense Cholesky with fused multiply-subtracts and one reciprocal per pivot
+  float L[6][6], inv[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     float s = H[6 * j + j] + damping;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       if (k < j) {
-        s -= L[j][k] * L[j][k];
+        s = fmaf(-L[j][k], L[j][k], s);
       }
     }
     if (!(s > 0.0f)) {
       return false;
     }
     L[j][j] = sqrtf(s);
+    inv[j]  = 1.0f / L[j][j];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       if (i > j) {
@@ -167,10 +169,10 @@ __device__ __forceinline__ bool gn_step(const float* H, const float* b, float da
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
           if (k < j) {
-            v -= L[i][k] * L[j][k];
+            v = fmaf(-L[i][k], L[j][k], v);
           }
         }
-        L[i][j] = v / L[j][j];
+        L[i][j] = v * inv[j];
       }
     }
   }
@@ -181,10 +183,10 @@ __device__ __forceinline__ bool gn_step(const float* H, const float* b, float da
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       if (k < i) {
-        v -= L[i][k] * y[k];
+        v = fmaf(-L[i][k], y[k], v);
       }
     }
-    y[i] = v / L[i][i];
+    y[i] = v * inv[i];
   }
 #pragma unroll
   for (int i = 5; i >= 0; --i) {
@@ -192,10 +194,10 @@ __device__ __forceinline__ bool gn_step(const float* H, const float* b, float da
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       if (k > i) {
-        v -= L[k][i] * dx[k];
+        v = fmaf(-L[k][i], dx[k], v);
       }
     }
-    dx[i] = v / L[i][i];
+    dx[i] = v * inv[i];
   }
   float D[16], Xn[16];
   tnq2t(dx, D);
