@@ -1106,6 +1106,9 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
 // frames share a CU.  Arithmetic and summation order are those of the fused kernel.
 constexpr int kGnThreads = 256;
 constexpr int kGnSlots   = 4;  // correspondences per thread: max_fixed <= 1024
+// row stride of the term matrix in floats: +4 so that the 29 summing lanes (one row each, 16-B reads)
+// start 16 B apart in the bank space instead of all on the same four banks
+constexpr int kGnRow     = kGnThreads + 4;
 
 struct GnShared {
   float X[16], T[16], Tprev[16], H[36], b[6];
@@ -1126,7 +1129,7 @@ __global__ __launch_bounds__(kGnThreads) void gn_kernel(const AlignArgs g) {
     return;  // finished, or waiting for the search kernel (block-uniform)
   }
   float* terms             = reinterpret_cast<float*>(smem);
-  GnShared& sh             = *reinterpret_cast<GnShared*>(smem + kTerms * kGnThreads * sizeof(float));
+  GnShared& sh             = *reinterpret_cast<GnShared*>(smem + kTerms * kGnRow * sizeof(float));
   prs_pcf_state* gstate    = g.b.state + frame;
   prs_align_result* gres   = g.b.result + frame;
   const float4* gops       = g.ops + (size_t) frame * (size_t) g.max_fixed * 2;
@@ -1235,19 +1238,27 @@ __global__ __launch_bounds__(kGnThreads) void gn_kernel(const AlignArgs g) {
         for (int t = 0; t < kTerms; ++t) {
           tv[t] = 0.0f;
         }
+        int cls = 3;
         if (c0 + tid < nc) {
-          int cls;
           factor_terms(g.a, pose, zf[k], pm[k], mean_dsp, tv, cls);
-          atomicAdd(cls == 0 ? &sh.n_inl : (cls == 1 ? &sh.n_out : &sh.n_inv), 1);
+        }
+        {
+          // inlier / outlier / invalid counts: one LDS atomic per wave and class instead of one per lane
+          const uint64_t m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
+          if ((tid & 63) == 0) {
+            if (m0) atomicAdd(&sh.n_inl, (int) __popcll(m0));
+            if (m1) atomicAdd(&sh.n_out, (int) __popcll(m1));
+            if (m2) atomicAdd(&sh.n_inv, (int) __popcll(m2));
+          }
         }
 #pragma unroll
         for (int t = 0; t < kTerms; ++t) {
-          terms[t * kGnThreads + tid] = tv[t];
+          terms[t * kGnRow + tid] = tv[t];
         }
         __syncthreads();
         if (stid >= 0 && stid < kTerms) {
           const int cnt      = nc - c0 < kGnThreads ? nc - c0 : kGnThreads;
-          const float4* row4 = reinterpret_cast<const float4*>(terms + stid * kGnThreads);
+          const float4* row4 = reinterpret_cast<const float4*>(terms + stid * kGnRow);
           float4 n0 = row4[0], n1 = row4[1], n2 = row4[2], n3 = row4[3];
           for (int j = 0; j < cnt; j += 16) {
             const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
@@ -1546,7 +1557,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   AlignArgs gs = g;
   gs.mode      = kModeSplitSearch;
   auto skernel = align_kernel<kSearchThreads>;
-  const size_t lds_gn = (size_t) kTerms * kGnThreads * sizeof(float) + sizeof(GnShared) + 16;
+  const size_t lds_gn = (size_t) kTerms * kGnRow * sizeof(float) + sizeof(GnShared) + 16;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(skernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_align_batch_run attribute");
