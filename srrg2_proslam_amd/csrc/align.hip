@@ -615,6 +615,9 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
           const float cols = (float) g.f.projector.canvas_cols, rows = (float) g.f.projector.canvas_rows;
           const float max_dd = g.f.maximum_descriptor_distance;
           const float r2f    = (float) (sh.radius * sh.radius);
+          const int rad2     = rad * rad;
+          // the int16 row / column arithmetic of the reference cannot wrap on this canvas
+          const bool circle_exact = rad < 8192 && R + rad < 32000 && (g.cell_ncx << g.cell_sx) + rad < 32000;
           int projected      = 0;
           // four queries per thread are fetched together (point + 256-bit row: 48 B each) so the
           // global-memory latency is paid once per block of queries, not once per query
@@ -695,6 +698,12 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
                       const float2 c = fuv[e.y & 0xffffu];
                       const float du = c.x - u, dv = c.y - v;
                       accept = !(du * du + dv * dv > r2f);
+                    } else if (stype == PRS_SEARCH_CIRCLE && circle_exact) {
+                      // rows [row - r, row + r] (circle_impl.cpp:25-26,40-47) and col - w < dcol < col + w with
+                      // w = int(sqrt(r^2 - h^2) + 1) (:51-56) is |dc| <= isqrt(r^2 - h^2), i.e. the integer test
+                      // dc^2 + h^2 <= r^2 (which also implies |h| <= r): no width table, no row compare
+                      const int h = drow - row, dc = dcol - col;
+                      accept      = dc * dc + h * h <= rad2;
                     } else if (drow < rmin || drow >= rmax) {
                       accept = false;  // outside the scanned rows (circle_impl.cpp:40-47)
                     } else if (stype == PRS_SEARCH_SQUARE) {
