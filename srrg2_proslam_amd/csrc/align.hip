@@ -1477,8 +1477,8 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   g.lut_cap = (int) lut_cap;
   uint32_t off = 0;
   g.off_db       = off; off = align_up16(off + nf * 8);
-  // 2-D cell grid over the canvas: 16 x 32 px cells, coarsened until there are at most 2048 of them
-  int sy = 4, sx = 5;
+  // 2-D cell grid over the canvas: 16 x 16 px cells, coarsened until there are at most 2048 of them
+  int sy = 4, sx = 4;
   auto cells_of = [&](int shift_y, int shift_x, int& ncy, int& ncx) {
     ncy = ((int) R + (1 << shift_y) - 1) >> shift_y;
     ncx = (finder->projector.canvas_cols + (1 << shift_x) - 1) >> shift_x;
