@@ -83,7 +83,7 @@ struct AlignArgs {
   int* pending;    // split pipeline: number of frames the last GN launch left unfinished
   unsigned long long* stamps;  // diagnostic: [batch][16] accumulated shader clocks per phase (NULL = off)
   int max_fixed;   // LDS capacity in fixed points (frames with more are rejected loudly)
-  uint32_t off_db, off_cellstart, off_cfix, off_cmov, off_sh;  // persistent for the whole frame loop
+  uint32_t off_db, off_inv, off_cellstart, off_cfix, off_cmov, off_sh;  // persistent for the whole frame loop
   uint32_t off_u;                                              // phase-exclusive union region:
   uint32_t off_fdesc, off_fuv, off_best, off_second, off_lut;  //   search phase (relative to the LDS base)
   uint32_t off_terms;                                          //   GN phase / database build / disparity column
@@ -251,6 +251,7 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
   prs_align_result* gres          = g.b.result + frame;
 
   uint2* db           = reinterpret_cast<uint2*>(smem + g.off_db);        // cell-sorted lattice: x = row | col << 16, y = fixed index | canonical position << 16
+  uint16_t* inv       = reinterpret_cast<uint16_t*>(smem + g.off_inv);     // canonical position -> fixed index
   uint16_t* cellstart = reinterpret_cast<uint16_t*>(smem + g.off_cellstart);
   float4* cfix        = reinterpret_cast<float4*>(smem + g.off_cfix);      // per-correspondence fixed measurement
   float4* cmov        = reinterpret_cast<float4*>(smem + g.off_cmov);      // per-correspondence moving point + information scale
@@ -579,6 +580,7 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
             cxi            = cxi < g.cell_ncx ? cxi : g.cell_ncx - 1;
             db[cellstart[(row >> g.cell_sy) * g.cell_ncx + cxi] + slot[i]] =
               make_uint2(((uint32_t) row & 0xffffu) | ((uint32_t) col << 16), (uint32_t) i | ((uint32_t) canon[i] << 16));
+            inv[canon[i]] = (uint16_t) i;
           }
           __syncthreads();
           db_built = true;
@@ -658,7 +660,6 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
               // top-2 on (distance, canonical lattice position) keys: identical to the reference's
               // sequential "strictly smaller wins" scan, but independent of the visiting order
               uint32_t bestk = kNoneU32, seck = kNoneU32;
-              int ibest = 0, isec = 0;
               int row = 0, col = 0, rmin = 0, rmax = 0, cmin = 0, cmax = 0;
               int r0, r1, cb0, cb1;
               if (lattice) {
@@ -724,26 +725,19 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
                       const int fi     = (int) (e.y & 0xffffu);
                       const uint32_t d = (uint32_t) hamming_regs(fdesc[2 * fi], fdesc[2 * fi + 1], q0, q1);
                       // kdtree_impl.cpp:54: the best is initialised to maximum_descriptor_distance
-                      if (lattice || (float) d < max_dd) {
-                        const uint32_t key = (d << 16) | (e.y >> 16);
-                        if (key < bestk) {  // circle_impl.cpp:64-72
-                          seck  = bestk;
-                          isec  = ibest;
-                          bestk = key;
-                          ibest = fi;
-                        } else if (key < seck) {
-                          seck = key;
-                          isec = fi;
-                        }
-                      }
+                      // best / second best (circle_impl.cpp:64-72) as min / second-min of unique keys
+                      const uint32_t key = (lattice || (float) d < max_dd) ? ((d << 16) | (e.y >> 16)) : kNoneU32;
+                      const uint32_t hi  = key > bestk ? key : bestk;
+                      seck               = hi < seck ? hi : seck;
+                      bestk              = key < bestk ? key : bestk;
                     }
                   }
                 }
               }
               if (bestk != kNoneU32) {  // circle_impl.cpp:78-92 / kdtree_impl.cpp:72-78 (best only)
-                cd.x = (uint32_t) ibest | ((bestk >> 16) << 16);
+                cd.x = (uint32_t) inv[bestk & 0xffffu] | ((bestk >> 16) << 16);
                 if (lattice && seck != kNoneU32) {
-                  cd.y = (uint32_t) isec | ((seck >> 16) << 16);
+                  cd.y = (uint32_t) inv[seck & 0xffffu] | ((seck >> 16) << 16);
                 }
               }
               // _addCorrespondenceCandidate (:8-37): order-independent reduction on
@@ -1477,6 +1471,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   g.lut_cap = (int) lut_cap;
   uint32_t off = 0;
   g.off_db       = off; off = align_up16(off + nf * 8);
+  g.off_inv      = off; off = align_up16(off + nf * 2);
   // 2-D cell grid over the canvas: 16 x 16 px cells, coarsened until there are at most 2048 of them
   int sy = 4, sx = 4;
   auto cells_of = [&](int shift_y, int shift_x, int& ncy, int& ncx) {
