@@ -227,8 +227,10 @@ __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const 
 
 }
 
-template <int T>
-__global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
+// SPLIT = the search half of the split pipeline (mode kModeSplitSearch): a compile-time flag, so the
+// Gauss-Newton code (and its registers) is not part of that instantiation
+template <int T, bool SPLIT>
+__global__ __launch_bounds__(T, SPLIT ? 4 : 1) void align_kernel(const AlignArgs g) {  // search half: <= 128 VGPRs = two workgroups per CU
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid   = threadIdx.x;
   const int lane  = tid & 63;
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
   const int stype     = g.f.search_type;
   const bool lattice  = stype != PRS_SEARCH_KDTREE;
 
-  const bool split_search = g.mode == kModeSplitSearch;
+  constexpr bool split_search = SPLIT;
   FrameCtl* ctl           = split_search ? g.ctl + frame : nullptr;
   if (split_search && (ctl->done || !ctl->need_search)) {
     return;  // this frame does not wait for a search (block-uniform)
@@ -623,18 +625,19 @@ __global__ __launch_bounds__(T) void align_kernel(const AlignArgs g) {
           int projected      = 0;
           // four queries per thread are fetched together (point + 256-bit row: 48 B each) so the
           // global-memory latency is paid once per block of queries, not once per query
-          for (int m0 = tid; m0 < nM; m0 += 4 * T) {
-           float4 pre_p[4];
-           au32x4 pre_q0[4], pre_q1[4];
+          constexpr int kPre = SPLIT ? 1 : 4;  // queries fetched together
+          for (int m0 = tid; m0 < nM; m0 += kPre * T) {
+           float4 pre_p[kPre];
+           au32x4 pre_q0[kPre], pre_q1[kPre];
 #pragma unroll
-           for (int qi = 0; qi < 4; ++qi) {
+           for (int qi = 0; qi < kPre; ++qi) {
              const int mm = m0 + qi * T < nM ? m0 + qi * T : m0;
              pre_p[qi]     = gmov[mm];
              pre_q0[qi]    = gmd[2 * mm];
              pre_q1[qi]    = gmd[2 * mm + 1];
            }
 #pragma unroll
-           for (int qi = 0; qi < 4; ++qi) {
+           for (int qi = 0; qi < kPre; ++qi) {
             const int m = m0 + qi * T;
             if (m >= nM) {
               continue;
@@ -1469,9 +1472,6 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
     lut_cap = 2048u;
   }
   g.lut_cap = (int) lut_cap;
-  uint32_t off = 0;
-  g.off_db       = off; off = align_up16(off + nf * 8);
-  g.off_inv      = off; off = align_up16(off + nf * 2);
   // 2-D cell grid over the canvas: 16 x 16 px cells, coarsened until there are at most 2048 of them
   int sy = 4, sx = 4;
   auto cells_of = [&](int shift_y, int shift_x, int& ncy, int& ncx) {
@@ -1492,31 +1492,39 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   g.cell_ncy = ncy;
   g.cell_ncx = ncx;
   g.ncells   = ncy * ncx;
-  g.off_cellstart = off; off = align_up16(off + ((uint32_t) g.ncells + 2) * 2);
-  g.off_cfix     = off; off = align_up16(off + nf * 16);
-  g.off_cmov     = off; off = align_up16(off + nf * 16);
-  g.off_sh       = off; off = align_up16(off + (uint32_t) sizeof(AlignShared));
-  g.off_u        = off;
-  // search-phase arrays
-  uint32_t u = off;
-  g.off_fdesc  = u; u = align_up16(u + nf * 32);
-  g.off_fuv    = u; u = align_up16(u + (finder->search_type == PRS_SEARCH_KDTREE ? nf * 8 : 0));
-  g.off_best   = u; u = align_up16(u + nf * 4);
-  g.off_second = u; u = align_up16(u + nf * 4);
-  g.off_lut    = u; u = align_up16(u + lut_cap * 2);
-  // GN-phase terms; the region also serves the database build (hist + slot + bucket) and the disparity column
-  g.off_terms = off;
-  uint32_t terms_bytes       = kTerms * kAlignThreads * 4;
-  const uint32_t histcap     = (R > (uint32_t) g.ncells ? R : (uint32_t) g.ncells) + 2;
-  const uint32_t build_bytes = histcap * 4 + (nf + 2) * 2 * 3 + (R + 2) * 2 + 16;
-  if (build_bytes > terms_bytes) {
-    terms_bytes = build_bytes;
-  }
-  if (nf * 4 + 160 > terms_bytes) {
-    terms_bytes = nf * 4 + 160;
-  }
-  const uint32_t t_end = align_up16(off + terms_bytes);
-  const size_t lds     = u > t_end ? u : t_end;
+  // LDS carve.  with_operands = false: the search half of the split pipeline, which hands the
+  // per-correspondence operand rows to the GN kernel through global memory instead of LDS
+  auto carve = [&](AlignArgs& g, bool with_operands) -> size_t {
+    uint32_t off = 0;
+    g.off_db       = off; off = align_up16(off + nf * 8);
+    g.off_inv      = off; off = align_up16(off + nf * 2);
+    g.off_cellstart = off; off = align_up16(off + ((uint32_t) g.ncells + 2) * 2);
+    g.off_cfix     = off; off = align_up16(off + (with_operands ? nf * 16 : 0));
+    g.off_cmov     = off; off = align_up16(off + (with_operands ? nf * 16 : 0));
+    g.off_sh       = off; off = align_up16(off + (uint32_t) sizeof(AlignShared));
+    g.off_u        = off;
+    // search-phase arrays
+    uint32_t u = off;
+    g.off_fdesc  = u; u = align_up16(u + nf * 32);
+    g.off_fuv    = u; u = align_up16(u + (finder->search_type == PRS_SEARCH_KDTREE ? nf * 8 : 0));
+    g.off_best   = u; u = align_up16(u + nf * 4);
+    g.off_second = u; u = align_up16(u + nf * 4);
+    g.off_lut    = u; u = align_up16(u + lut_cap * 2);
+    // GN-phase terms; the region also serves the database build (hist + slot + bucket) and the disparity column
+    g.off_terms = off;
+    uint32_t terms_bytes       = kTerms * kAlignThreads * 4;
+    const uint32_t histcap     = (R > (uint32_t) g.ncells ? R : (uint32_t) g.ncells) + 2;
+    const uint32_t build_bytes = histcap * 4 + (nf + 2) * 2 * 3 + (R + 2) * 2 + 16;
+    if (build_bytes > terms_bytes) {
+      terms_bytes = build_bytes;
+    }
+    if (nf * 4 + 160 > terms_bytes) {
+      terms_bytes = nf * 4 + 160;
+    }
+    const uint32_t t_end = align_up16(off + terms_bytes);
+    return u > t_end ? u : t_end;
+  };
+  const size_t lds = carve(g, true);
   if (lds > 160 * 1024) {
     return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_run: fixed cloud does not fit the 160 KiB LDS (lower max_fixed)");
   }
@@ -1532,7 +1540,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   hipError_t e;
   const bool split = mode == PRS_MODE_ALIGN && !ctx_fused_align(ctx) && max_fixed <= kGnThreads * kGnSlots && !g.stamps;
   if (!split) {
-    auto kernel = align_kernel<kAlignThreads>;
+    auto kernel = align_kernel<kAlignThreads, false>;
     e           = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     if (e != hipSuccess) {
       return ctx_fail_hip(ctx, e, "prs_align_batch_run attribute");
@@ -1560,9 +1568,10 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   g.ctl     = reinterpret_cast<FrameCtl*>(small + 256);
   AlignArgs gs = g;
   gs.mode      = kModeSplitSearch;
-  auto skernel = align_kernel<kSearchThreads>;
+  const size_t lds_search = carve(gs, false);
+  auto skernel = align_kernel<kSearchThreads, true>;
   const size_t lds_gn = (size_t) kTerms * kGnRow * sizeof(float) + sizeof(GnShared) + 16;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(skernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(skernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_search);
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_align_batch_run attribute");
   }
@@ -1575,7 +1584,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   for (;;) {
     for (int r = 0; r < rounds_left; ++r) {
       (void) hipMemsetAsync(g.pending, 0, sizeof(int), stream);
-      hipLaunchKernelGGL(skernel, dim3(batch->batch), dim3(kSearchThreads), lds, stream, gs);
+      hipLaunchKernelGGL(skernel, dim3(batch->batch), dim3(kSearchThreads), lds_search, stream, gs);
       hipLaunchKernelGGL(gn_kernel, dim3(batch->batch), dim3(kGnThreads), lds_gn, stream, g);
       ++total;
     }
