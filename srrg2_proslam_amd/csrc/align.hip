@@ -1123,7 +1123,7 @@ struct GnShared {
   int converged, need_search, n_inl, n_out, n_inv, stop, flags;
 };
 
-__global__ __launch_bounds__(kGnThreads, 4) void gn_kernel(const AlignArgs g) {
+__global__ __launch_bounds__(kGnThreads, 5) void gn_kernel(const AlignArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid   = threadIdx.x;
   const int frame = blockIdx.x;
