@@ -230,7 +230,7 @@ __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const 
 // SPLIT = the search half of the split pipeline (mode kModeSplitSearch): a compile-time flag, so the
 // Gauss-Newton code (and its registers) is not part of that instantiation
 template <int T, bool SPLIT>
-__global__ __launch_bounds__(T, SPLIT ? 4 : 1) void align_kernel(const AlignArgs g) {  // search half: <= 128 VGPRs = two workgroups per CU
+__global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs g) {  // search half: <= 128 VGPRs = two workgroups per CU
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid   = threadIdx.x;
   const int lane  = tid & 63;
