@@ -160,3 +160,28 @@ def rot(axis, angle):
 def clip_projector(ob, cfg_name="icl", range_min=0.1, range_max=10.0):
     cam = configs.get(cfg_name)["camera"]
     return ob.Projector(cam["fx"], cam["fy"], cam["cx"], cam["cy"], int(cam["cols"]), int(cam["rows"]), range_min, range_max)
+
+
+# ---- LandmarkWorldNoNoise (tests/test_landmark_estimators.cpp:268-327): 1000 points ~ N((10,10,10),(10,10,10)),
+# 10 poses from the origin to (10,10,10) with 0.01 jitter, K = (200,200,100,100), canvas 200x200, 0.5 m baseline
+def landmark_world(seed=0, n_points=1000, n_poses=10):
+    rng = np.random.default_rng(seed)
+    K = (200.0, 200.0, 100.0, 100.0)
+    pts = rng.normal((10, 10, 10), (10, 10, 10), (n_points, 3)).astype(np.float32)
+    poses = []
+    for k in range(n_poses):
+        T = np.eye(4, dtype=np.float32)
+        T[:3, 3] = np.float32(10.0 * k / (n_poses - 1)) + rng.normal(0, 0.01, 3).astype(np.float32)
+        poses.append(T)
+    obs = []  # per pose: list of (world index, p_cam, (uL, vL, uR, vR))
+    for T in poses:
+        Ti = np.linalg.inv(T.astype(np.float64))
+        pc = (Ti[:3, :3] @ pts.T.astype(np.float64)).T + Ti[:3, 3]
+        z = pc[:, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u = K[0] * pc[:, 0] / z + K[2]
+            v = K[1] * pc[:, 1] / z + K[3]
+            ur = K[0] * (pc[:, 0] - 0.5) / z + K[2]
+        ok = (z > 0.5) & (u >= 0) & (u < 200) & (v >= 0) & (v < 200) & (ur >= 0)
+        obs.append([(int(i), pc[i].astype(np.float32), np.array([u[i], v[i], ur[i], v[i]], np.float32)) for i in np.nonzero(ok)[0]])
+    return K, pts, poses, obs
