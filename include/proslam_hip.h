@@ -428,6 +428,113 @@ PRS_API int prs_bruteforce_match(prs_context* ctx,
                                  int32_t capacity,
                                  int32_t* n_correspondences);
 
+/* ================================================================================================
+ * Landmark estimators + projective mergers
+ * replaces MergerProjective_::compute with its RigidStereoTriangulation / RigidStereoProjectiveEKF /
+ * ProjectiveDepthEKF specialisations (mapping/mergers/merger_projective_impl.cpp:8-328,
+ * merger_projective_rigid_stereo_impl.cpp:8-77, .._triangulation_impl.cpp:7-39,
+ * merger_projective_depth_ekf_impl.cpp:8-73) and the estimator each one drives:
+ * LandmarkEstimatorWeightedMean_ (mapping/landmarks/landmark_estimator_weighted_mean_impl.cpp:7-41),
+ * LandmarkEstimatorEKF_ + PointEKFBase + the stereo / depth / mono measurement models in double
+ * (landmark_estimator_ekf_impl.cpp:7-82, filters/point_ekf_base.hpp:63-125,
+ * filters/stereo_projective_point_ekf_impl.cpp:13-48, projective_depth_point_ekf_impl.cpp:7-36,
+ * projective_point_ekf_impl.cpp:16-43), LandmarkEstimatorPoseBasedSmoother_
+ * (landmark_estimator_pose_based_smoother_impl.cpp:7-148).
+ * The local map lives on the device as a structure of arrays; one workgroup merges one frame into
+ * one map: first-come bin blocking by correspondence order (:89-122), one estimator update per
+ * surviving correspondence, then the binned addition of new landmarks (:210-305) in the
+ * reference's order (bins in order of their first measurement, best disparity / depth per bin).
+ * Every scene index may appear in at most one correspondence (the finder's output is bijective).
+ * ============================================================================================== */
+enum { PRS_EST_WEIGHTED_MEAN = 0, PRS_EST_EKF = 1, PRS_EST_SMOOTHER = 2 };
+enum { PRS_MERGER_STEREO_TRIANGULATION = 0, PRS_MERGER_STEREO_EKF = 1, PRS_MERGER_DEPTH_EKF = 2 };
+enum {
+  PRS_ERR_HISTORY    = -7, /* a landmark's measurement history is full (max_measurements) */
+  PRS_ERR_SCENE_FULL = -8, /* the map has no room for the landmarks to add */
+  PRS_ERR_DUPLICATE  = -9  /* a scene index appears in two correspondences */
+};
+
+/* PointStatisticsField3D::CameraMeasurement; the two transforms of a measurement are per frame and
+ * sit in the map's pose table */
+typedef struct {
+  float point_in_image[3];
+  float point_in_camera[3];
+  int32_t frame;
+} prs_camera_measurement;
+
+typedef struct {
+  float sensor_in_world[12]; /* 3x4 row-major */
+  float world_in_sensor[12];
+} prs_frame_pose;
+
+typedef struct {
+  int32_t type;            /* PRS_EST_* */
+  int32_t measurement_dim; /* 2 mono (estimator only), 3 depth, 4 stereo */
+  float maximum_distance_geometry_meters_squared; /* landmark_estimator_base.hpp:21-25 */
+  double minimum_state_element_covariance;        /* landmark_estimator_ekf.h:37-41 */
+  double maximum_covariance_norm_squared;         /* :43-47 */
+  double fx, fy, cx, cy, b_x, b_y;                /* filter calibration (setCameraMatrix / setBaseline) */
+  uint32_t maximum_number_of_iterations;          /* landmark_estimator_pose_based_smoother.h:17-21 */
+  float convergence_criterion_minimum_chi2_delta; /* :23-27 */
+  float maximum_reprojection_error_pixels_squared; /* :29-33 */
+  uint32_t minimum_number_of_measurements_for_optimization; /* :35-39 */
+  float camera_matrix[9];                         /* smoother: setCameraMatrix */
+} prs_estimator_params;
+
+typedef struct {
+  int32_t variant;        /* PRS_MERGER_* */
+  int32_t enable_binning; /* MergerCorrespondence_::param_enable_binning */
+  uint32_t number_of_row_bins, number_of_col_bins; /* merger_projective.h:47-56 */
+  int32_t canvas_rows, canvas_cols;                /* projector canvas (:30-33) */
+  float maximum_distance_appearance;               /* merger_projective.h:42-46 */
+  uint32_t target_number_of_merges;                /* MergerCorrespondence_::param_target_number_of_merges */
+  float target_merge_ratio;                        /* merger_projective.h:57-61 (warning only) */
+  prs_triangulator_params triangulator;            /* stereo variants */
+  float fx, fy, cx, cy;                            /* depth variant: unprojector */
+  prs_estimator_params estimator;
+} prs_merger_params;
+
+typedef struct {
+  int32_t n_merged;
+  int32_t n_added;
+  int32_t status; /* PRS_WARN_NO_MATCHES = all merge attempts failed (:141-144), PRS_WARN_LOW_RATIO = low merge
+                     ratio (:145-150), or a PRS_ERR_* code */
+} prs_merge_result;
+
+/* B local maps + the frames merged into them; device pointers */
+typedef struct {
+  int32_t batch;
+  int32_t capacity;           /* landmarks per map (row stride of the per-landmark arrays) */
+  int32_t max_measurements;   /* history slots per landmark (0 = none kept: not with the smoother) */
+  int32_t max_frames;         /* rows of the pose table per map */
+  /* the map */
+  float* coords;              /* [batch][capacity][4] xyz in the local map frame */
+  uint8_t* desc;              /* [batch][capacity][32] */
+  float* state;               /* [batch][capacity][4] statistics().state(), world frame */
+  float* covariance;          /* [batch][capacity][9] */
+  uint32_t* n_opt;            /* [batch][capacity] numberOfOptimizations */
+  uint8_t* inlier;            /* [batch][capacity] */
+  uint32_t* n_meas;           /* [batch][capacity] */
+  prs_camera_measurement* meas; /* [batch][capacity][max_measurements] */
+  prs_frame_pose* poses;      /* [batch][max_frames] */
+  int32_t* n_points;          /* [batch] in/out */
+  /* the frame */
+  int32_t measurement_stride;
+  const float* measurement;   /* [batch][measurement_stride][4] image-space points ((uL,vL,uR,vR) / (u,v,d,-)) */
+  const uint8_t* measurement_desc; /* [batch][measurement_stride][32] */
+  const int32_t* n_measured;  /* [batch] */
+  int32_t corr_stride;
+  const prs_corr* corr;       /* [batch][corr_stride]: fixed_idx -> scene, moving_idx -> measurement */
+  const int32_t* n_corr;      /* [batch] */
+  const int32_t* scene_index_map; /* optional [batch][capacity]: clipped index -> scene index (prs_clip_batch.global_indices) */
+  const float* measurement_in_world; /* [batch][16] */
+  const float* measurement_in_scene; /* [batch][16] */
+  const int32_t* frame;       /* [batch] pose-table slot of this frame */
+  prs_merge_result* result;   /* [batch] */
+} prs_merge_batch;
+
+PRS_API int prs_merge_batch_run(prs_context* ctx, const prs_merger_params* params, const prs_merge_batch* batch);
+
 #ifdef __cplusplus
 }
 #endif

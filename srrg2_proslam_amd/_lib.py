@@ -193,6 +193,46 @@ class BruteforceBatch(C.Structure):
     ]
 
 
+class EstimatorParams(C.Structure):
+    """prs_estimator_params"""
+    _fields_ = [("type", C.c_int32), ("measurement_dim", C.c_int32),
+                ("maximum_distance_geometry_meters_squared", C.c_float),
+                ("minimum_state_element_covariance", C.c_double), ("maximum_covariance_norm_squared", C.c_double),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("b_x", C.c_double), ("b_y", C.c_double),
+                ("maximum_number_of_iterations", C.c_uint32), ("convergence_criterion_minimum_chi2_delta", C.c_float),
+                ("maximum_reprojection_error_pixels_squared", C.c_float),
+                ("minimum_number_of_measurements_for_optimization", C.c_uint32),
+                ("camera_matrix", C.c_float * 9)]
+
+
+class MergerParams(C.Structure):
+    """prs_merger_params"""
+    _fields_ = [("variant", C.c_int32), ("enable_binning", C.c_int32),
+                ("number_of_row_bins", C.c_uint32), ("number_of_col_bins", C.c_uint32),
+                ("canvas_rows", C.c_int32), ("canvas_cols", C.c_int32),
+                ("maximum_distance_appearance", C.c_float), ("target_number_of_merges", C.c_uint32),
+                ("target_merge_ratio", C.c_float), ("triangulator", TriangulatorParams),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("estimator", EstimatorParams)]
+
+
+class MergeResult(C.Structure):
+    """prs_merge_result"""
+    _fields_ = [("n_merged", C.c_int32), ("n_added", C.c_int32), ("status", C.c_int32)]
+
+
+class MergeBatch(C.Structure):
+    """prs_merge_batch (device pointers)"""
+    _fields_ = [("batch", C.c_int32), ("capacity", C.c_int32), ("max_measurements", C.c_int32), ("max_frames", C.c_int32),
+                ("coords", C.c_void_p), ("desc", C.c_void_p), ("state", C.c_void_p), ("covariance", C.c_void_p),
+                ("n_opt", C.c_void_p), ("inlier", C.c_void_p), ("n_meas", C.c_void_p), ("meas", C.c_void_p),
+                ("poses", C.c_void_p), ("n_points", C.c_void_p),
+                ("measurement_stride", C.c_int32), ("measurement", C.c_void_p), ("measurement_desc", C.c_void_p),
+                ("n_measured", C.c_void_p), ("corr_stride", C.c_int32), ("corr", C.c_void_p), ("n_corr", C.c_void_p),
+                ("scene_index_map", C.c_void_p), ("measurement_in_world", C.c_void_p), ("measurement_in_scene", C.c_void_p),
+                ("frame", C.c_void_p), ("result", C.c_void_p)]
+
+
 MODE_ALIGN, MODE_FINDER, MODE_LINEARIZE = 0, 1, 2
 
 # every symbol include/proslam_hip.h declares: (restype, argtypes)
@@ -228,6 +268,7 @@ SYMBOLS = {
     "prs_triangulate_dev": (C.c_int, [_vp, C.POINTER(TriangulatorParams), _vp, C.c_int64, _vp]),
     "prs_bruteforce_match_batch": (C.c_int, [_vp, C.POINTER(BruteforceParams), C.POINTER(BruteforceBatch)]),
     "prs_bruteforce_match": (C.c_int, [_vp, C.POINTER(BruteforceParams), _vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
+    "prs_merge_batch_run": (C.c_int, [_vp, C.POINTER(MergerParams), C.POINTER(MergeBatch)]),
     "prs_scene_clip_batch": (C.c_int, [_vp, C.POINTER(Projector), _vp, C.POINTER(ClipBatch)]),
     "prs_scene_clip": (C.c_int, [_vp, C.POINTER(Projector), _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, C.c_int32, _i32p]),
 }

@@ -138,6 +138,9 @@ const char* prs_status_string(int status) {
     case PRS_ERR_RANGE: return "input outside the supported coordinate domain";
     case PRS_ERR_UNSUPPORTED: return "size beyond kernel limits";
     case PRS_ERR_NO_DEVICE: return "no HIP device";
+    case PRS_ERR_HISTORY: return "measurement history of a landmark is full";
+    case PRS_ERR_SCENE_FULL: return "map capacity exhausted";
+    case PRS_ERR_DUPLICATE: return "scene index referenced by two correspondences";
     default: return status > 0 ? "warning bits set" : "unknown error";
   }
 }
@@ -586,6 +589,14 @@ int prs_bruteforce_match(prs_context* ctx,
   memcpy(correspondences, h + b_f + b_m + b_s, (size_t) hs[2] * sizeof(prs_corr));
   *n_correspondences = hs[2];
   return hs[3];
+}
+
+int prs_merge_batch_run(prs_context* ctx, const prs_merger_params* params, const prs_merge_batch* batch) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  (void) hipSetDevice(ctx->device);
+  return merge_batch_launch(ctx, params, batch);
 }
 
 }  // extern "C"

@@ -585,3 +585,63 @@ def bruteforce_match_batch(ctx, params, clouds):
     rc = _lib.load().prs_bruteforce_match_batch(ctx._h, C.byref(params), C.byref(d))
     _check(ctx, rc, "prs_bruteforce_match_batch")
     return rc
+
+
+# ---- landmark estimators + projective mergers (mapping/mergers, mapping/landmarks) ----
+EST_WEIGHTED_MEAN, EST_EKF, EST_SMOOTHER = 0, 1, 2
+MERGER_STEREO_TRIANGULATION, MERGER_STEREO_EKF, MERGER_DEPTH_EKF = 0, 1, 2
+
+
+class MapBatch:
+    """B local maps resident in HBM (structure of arrays, torch tensors own the memory) + the
+    per-frame inputs of the merger.  Row layouts follow include/proslam_hip.h prs_merge_batch."""
+
+    MEAS_WORDS = 7    # prs_camera_measurement: 3 + 3 floats + frame index
+    POSE_WORDS = 24   # prs_frame_pose: two 3x4 transforms
+
+    def __init__(self, device, batch, capacity, max_measurements, max_frames, measurement_stride, corr_stride):
+        import torch
+        dev = torch.device("cuda", device)
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        self.batch, self.capacity = int(batch), int(capacity)
+        self.max_measurements, self.max_frames = int(max_measurements), int(max_frames)
+        self.measurement_stride, self.corr_stride = int(measurement_stride), int(corr_stride)
+        self.coords = z((batch, capacity, 4), torch.float32)
+        self.desc = z((batch, capacity, 32), torch.uint8)
+        self.state = z((batch, capacity, 4), torch.float32)
+        self.covariance = z((batch, capacity, 9), torch.float32)
+        self.n_opt = z((batch, capacity), torch.int32)
+        self.inlier = z((batch, capacity), torch.uint8)
+        self.n_meas = z((batch, capacity), torch.int32)
+        self.meas = z((batch, capacity, max(max_measurements, 1), self.MEAS_WORDS), torch.int32)
+        self.poses = z((batch, max_frames, self.POSE_WORDS), torch.float32)
+        self.n_points = z((batch,), torch.int32)
+        self.measurement = z((batch, measurement_stride, 4), torch.float32)
+        self.measurement_desc = z((batch, measurement_stride, 32), torch.uint8)
+        self.n_measured = z((batch,), torch.int32)
+        self.corr = z((batch, corr_stride, 3), torch.int32)
+        self.n_corr = z((batch,), torch.int32)
+        self.scene_index_map = None
+        self.measurement_in_world = torch.eye(4, dtype=torch.float32, device=dev).repeat(batch, 1, 1).contiguous()
+        self.measurement_in_scene = torch.eye(4, dtype=torch.float32, device=dev).repeat(batch, 1, 1).contiguous()
+        self.frame = z((batch,), torch.int32)
+        self.result = z((batch, 3), torch.int32)
+
+    def descriptor(self):
+        d = _lib.MergeBatch()
+        d.batch, d.capacity, d.max_measurements, d.max_frames = self.batch, self.capacity, self.max_measurements, self.max_frames
+        for name in ("coords", "desc", "state", "covariance", "n_opt", "inlier", "n_meas", "poses", "n_points", "measurement",
+                     "measurement_desc", "n_measured", "corr", "n_corr", "measurement_in_world", "measurement_in_scene", "frame", "result"):
+            setattr(d, name, getattr(self, name).data_ptr())
+        d.meas = self.meas.data_ptr() if self.max_measurements > 0 else None
+        d.measurement_stride, d.corr_stride = self.measurement_stride, self.corr_stride
+        d.scene_index_map = self.scene_index_map.data_ptr() if self.scene_index_map is not None else None
+        return d
+
+
+def merge_batch(ctx, params, maps):
+    """enqueue MergerProjective_::compute for every (map, frame) pair of the batch (asynchronous)"""
+    d = maps.descriptor()
+    rc = _lib.load().prs_merge_batch_run(ctx._h, C.byref(params), C.byref(d))
+    _check(ctx, rc, "prs_merge_batch_run")
+    return rc
