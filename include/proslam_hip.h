@@ -359,6 +359,10 @@ typedef struct {
   int32_t* global_indices;         /* out [batch][stride]: clipped index -> full-scene index */
   int32_t* n_clipped;              /* out [batch] */
   int32_t* status;                 /* out [batch] */
+  const uint32_t* scene_n_opt;     /* optional [batch][stride] numberOfOptimizations of the scene points: the clipped
+                                      w column then is the aligner's information scale n > 2 ? 1 + log(n) : 1
+                                      (aligner_slice_processor_projective.cpp:46-52), taken from a table the host
+                                      evaluates with the same double log (n clamped to 4095) */
 } prs_clip_batch;
 
 /* device pointers, asynchronous on the context's stream */
@@ -531,6 +535,9 @@ typedef struct {
   const float* measurement_in_scene; /* [batch][16] */
   const int32_t* frame;       /* [batch] pose-table slot of this frame */
   prs_merge_result* result;   /* [batch] */
+  int32_t corr_from_aligner;  /* 0: fixed_idx -> scene, moving_idx -> measurement (the merger's own convention,
+                                 merger_projective_impl.cpp:60-77); 1: the vector comes straight from
+                                 prs_align_batch.corr (fixed_idx -> measurement, moving_idx -> clipped scene) */
 } prs_merge_batch;
 
 PRS_API int prs_merge_batch_run(prs_context* ctx, const prs_merger_params* params, const prs_merge_batch* batch);

@@ -170,7 +170,7 @@ class ClipBatch(C.Structure):
         ("scene_xyzw", C.c_void_p), ("scene_desc", C.c_void_p), ("n_scene", C.c_void_p),
         ("robot_in_local_map", C.c_void_p),
         ("clipped_xyzw", C.c_void_p), ("clipped_desc", C.c_void_p), ("global_indices", C.c_void_p),
-        ("n_clipped", C.c_void_p), ("status", C.c_void_p),
+        ("n_clipped", C.c_void_p), ("status", C.c_void_p), ("scene_n_opt", C.c_void_p),
     ]
 
 
@@ -230,7 +230,7 @@ class MergeBatch(C.Structure):
                 ("measurement_stride", C.c_int32), ("measurement", C.c_void_p), ("measurement_desc", C.c_void_p),
                 ("n_measured", C.c_void_p), ("corr_stride", C.c_int32), ("corr", C.c_void_p), ("n_corr", C.c_void_p),
                 ("scene_index_map", C.c_void_p), ("measurement_in_world", C.c_void_p), ("measurement_in_scene", C.c_void_p),
-                ("frame", C.c_void_p), ("result", C.c_void_p)]
+                ("frame", C.c_void_p), ("result", C.c_void_p), ("corr_from_aligner", C.c_int32)]
 
 
 MODE_ALIGN, MODE_FINDER, MODE_LINEARIZE = 0, 1, 2

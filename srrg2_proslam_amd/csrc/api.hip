@@ -42,6 +42,28 @@ void* ctx_device_scratch(prs_context* ctx, size_t bytes) {
   return ctx->d_scratch;
 }
 
+const float* ctx_info_scale_table(prs_context* ctx) {
+  if (!ctx->d_info_lut) {
+    constexpr int kN = 4096;
+    uint32_t n[kN];
+    float scale[kN];
+    for (int i = 0; i < kN; ++i) {
+      n[i] = (uint32_t) i;
+    }
+    prs_info_scale_from_nopt(n, kN, scale);
+    float* d = nullptr;
+    if (hipMalloc(&d, sizeof(scale)) != hipSuccess) {
+      return nullptr;
+    }
+    if (hipMemcpy(d, scale, sizeof(scale), hipMemcpyHostToDevice) != hipSuccess) {
+      (void) hipFree(d);
+      return nullptr;
+    }
+    ctx->d_info_lut = d;
+  }
+  return ctx->d_info_lut;
+}
+
 void* ctx_device_scratch_slot(prs_context* ctx, int slot, size_t bytes) {
   if (bytes <= ctx->d_slot_size[slot]) {
     return ctx->d_slot[slot];
@@ -195,6 +217,9 @@ int prs_context_destroy(prs_context* ctx) {
   }
   if (ctx->d_stamps) {
     (void) hipFree(ctx->d_stamps);
+  }
+  if (ctx->d_info_lut) {
+    (void) hipFree(ctx->d_info_lut);
   }
   for (int i = 0; i < 4; ++i) {
     if (ctx->d_slot[i]) {
@@ -477,6 +502,7 @@ int prs_scene_clip(prs_context* ctx,
   b.global_indices     = reinterpret_cast<int32_t*>(d + o_out_idx);
   b.n_clipped          = reinterpret_cast<int32_t*>(d + o_small + 4);
   b.status             = reinterpret_cast<int32_t*>(d + o_small + 8);
+  b.scene_n_opt        = nullptr;
   const int rc = scene_clip_launch(ctx, projector, sensor_in_robot16, &b);
   if (rc != PRS_OK) {
     return rc;

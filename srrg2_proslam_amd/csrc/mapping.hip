@@ -723,11 +723,11 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
   // ---- correspondences: inlier reset, appearance gate, first-come bin blocking (:59-122) --------------
   for (int c = tid; c < n_corr; c += kMergeThreads) {
     const prs_corr cr = corr[c];
-    int s             = cr.fixed_idx;
+    int s             = B.corr_from_aligner ? cr.moving_idx : cr.fixed_idx;
     if (s >= 0 && s < B.capacity && imap) {
       s = imap[s];
     }
-    const int m = cr.moving_idx;
+    const int m = B.corr_from_aligner ? cr.fixed_idx : cr.moving_idx;
     if (s < 0 || s >= n_points || m < 0 || m >= n_meas) {
       sh.error = PRS_ERR_RANGE;
       continue;
@@ -766,8 +766,9 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
     if (cr.response > P.maximum_distance_appearance) {
       continue;
     }
-    const int s    = imap ? imap[cr.fixed_idx] : cr.fixed_idx;
-    const int m    = cr.moving_idx;
+    const int sc   = B.corr_from_aligner ? cr.moving_idx : cr.fixed_idx;
+    const int s    = imap ? imap[sc] : sc;
+    const int m    = B.corr_from_aligner ? cr.fixed_idx : cr.moving_idx;
     const float4 z = zs[m];
     if (P.enable_binning) {
       const uint32_t br = bin_of(z.y, a.row_w), bc = bin_of(z.x, a.col_w);

@@ -22,6 +22,7 @@ struct prs_context {
   size_t d_scratch_size = 0;
   void* d_slot[4]       = {nullptr, nullptr, nullptr, nullptr};  // kernel-owned scratch (candidates, ...)
   size_t d_slot_size[4] = {0, 0, 0, 0};
+  float* d_info_lut     = nullptr;  // information scale by landmark age, 4096 entries (scene clipper)
   void* h_pinned        = nullptr;
   size_t h_pinned_size  = 0;
   // diagnostic phase stamps (PRS_STAMPS=1): never enabled in timed runs
@@ -53,6 +54,8 @@ inline bool ctx_force_unstaged(const prs_context* ctx) {
 void* ctx_device_scratch(prs_context* ctx, size_t bytes);
 void* ctx_pinned_scratch(prs_context* ctx, size_t bytes);
 void* ctx_device_scratch_slot(prs_context* ctx, int slot, size_t bytes);
+// device table scale[n] = n > 2 ? 1 + log(n) : 1 for n < 4096 (built once per context)
+const float* ctx_info_scale_table(prs_context* ctx);
 // diagnostic: device buffer for phase stamps when PRS_STAMPS=1, else nullptr
 unsigned long long* ctx_stamps(prs_context* ctx, size_t bytes);
 // synchronises and prints mean per-phase cycle counts (n_stamps consecutive stamps per block)

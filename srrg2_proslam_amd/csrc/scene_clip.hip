@@ -31,6 +31,7 @@ struct ClipArgs {
   int to_robot;     // sensor_in_robot != identity (scene_clipper_projective_3d.cpp:61)
   int tiles;        // tiles per scene (tile-parallel shape)
   int* counts;      // [batch][tiles] survivors per tile (tile-parallel shape)
+  const float* info_lut;  // information scale by landmark age (4096 entries), used when scene_n_opt is set
 };
 
 enum { kClipWalk = 0, kClipCount = 1, kClipScatter = 2 };
@@ -51,6 +52,7 @@ __device__ __forceinline__ int clip_tile(const ClipArgs& a,
                                          float4* __restrict__ out_xyzw,
                                          u32x4c* __restrict__ out_desc,
                                          int32_t* __restrict__ out_index,
+                                         const uint32_t* __restrict__ in_nopt,
                                          int* wave_counts /* LDS [kClipSub * kClipWaves] */) {
   const int tid  = threadIdx.x;
   const int lane = tid & 63;
@@ -116,7 +118,12 @@ __device__ __forceinline__ int clip_tile(const ClipArgs& a,
           oy = ((a.S[4] * cx[k] + a.S[5] * cy[k]) + a.S[6] * cz[k]) + a.S[7];
           oz = ((a.S[8] * cx[k] + a.S[9] * cy[k]) + a.S[10] * cz[k]) + a.S[11];
         }
-        out_xyzw[slot]  = make_float4(ox, oy, oz, p[k].w);
+        float w = p[k].w;
+        if (in_nopt) {  // aligner_slice_processor_projective.cpp:46-52
+          const uint32_t n = in_nopt[i];
+          w                = a.info_lut[n < 4095u ? n : 4095u];
+        }
+        out_xyzw[slot]  = make_float4(ox, oy, oz, w);
         out_index[slot] = i;
         if (in_desc && out_desc) {
           const u32x4c d0        = in_desc[2 * i];
@@ -157,6 +164,7 @@ __global__ __launch_bounds__(kClipThreads) void scene_clip_kernel(const ClipArgs
   u32x4c* __restrict__ out_desc =
     a.b.clipped_desc ? reinterpret_cast<u32x4c*>(a.b.clipped_desc + base * PRS_DESC_BYTES) : nullptr;
   int32_t* __restrict__ out_index = a.b.global_indices + base;
+  const uint32_t* __restrict__ in_nopt = a.b.scene_n_opt ? a.b.scene_n_opt + base : nullptr;
 
   // projector->setCameraPose(_robot_in_local_map * _sensor_in_robot), :46; points go through its inverse
   ClipPose pose;
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(kClipThreads) void scene_clip_kernel(const ClipArgs
   if (MODE == kClipWalk) {
     int running = 0;
     for (int tile_base = 0; tile_base < n; tile_base += kClipTile) {
-      running += clip_tile<kClipWalk>(a, pose, in_xyzw, in_desc, n, tile_base, running, out_xyzw, out_desc, out_index, wave_counts);
+      running += clip_tile<kClipWalk>(a, pose, in_xyzw, in_desc, n, tile_base, running, out_xyzw, out_desc, out_index, in_nopt, wave_counts);
     }
     if (tid == 0) {
       a.b.n_clipped[scene] = running;
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(kClipThreads) void scene_clip_kernel(const ClipArgs
     const int tile_base = blockIdx.x * kClipTile;
     int total           = 0;
     if (tile_base < n) {
-      total = clip_tile<kClipCount>(a, pose, in_xyzw, in_desc, n, tile_base, 0, out_xyzw, out_desc, out_index, wave_counts);
+      total = clip_tile<kClipCount>(a, pose, in_xyzw, in_desc, n, tile_base, 0, out_xyzw, out_desc, out_index, in_nopt, wave_counts);
     }
     if (tid == 0) {
       a.counts[(size_t) scene * a.tiles + blockIdx.x] = total;
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(kClipThreads) void scene_clip_kernel(const ClipArgs
     const int tile_base = blockIdx.x * kClipTile;
     int total           = 0;
     if (tile_base < n) {
-      total = clip_tile<kClipScatter>(a, pose, in_xyzw, in_desc, n, tile_base, before, out_xyzw, out_desc, out_index, wave_counts);
+      total = clip_tile<kClipScatter>(a, pose, in_xyzw, in_desc, n, tile_base, before, out_xyzw, out_desc, out_index, in_nopt, wave_counts);
     }
     if (tid == 0 && (int) blockIdx.x == a.tiles - 1) {
       a.b.n_clipped[scene] = before + total;
@@ -253,6 +261,13 @@ int scene_clip_launch(prs_context* ctx, const prs_projector* projector, const fl
   a.to_robot = differs ? 1 : 0;
   a.tiles    = (batch->stride + kClipTile - 1) / kClipTile;
   a.counts   = nullptr;
+  a.info_lut = nullptr;
+  if (batch->scene_n_opt) {
+    a.info_lut = ctx_info_scale_table(ctx);
+    if (!a.info_lut) {
+      return ctx_fail(ctx, PRS_ERR_HIP, "prs_scene_clip: information scale table allocation failed");
+    }
+  }
   hipStream_t stream = ctx_stream(ctx);
   // many scenes (or short ones): one workgroup walks a scene; few long scenes: tile-parallel
   const bool walk = batch->batch >= 128 || a.tiles <= 2;

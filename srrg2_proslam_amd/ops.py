@@ -499,6 +499,7 @@ class ClipScenes:
         d.global_indices = self.global_indices.data_ptr()
         d.n_clipped = self.n_clipped.data_ptr()
         d.status = self.status.data_ptr()
+        d.scene_n_opt = self.scene_n_opt.data_ptr() if getattr(self, "scene_n_opt", None) is not None else None
         return d
 
     def clipped_of(self, b):
@@ -622,6 +623,7 @@ class MapBatch:
         self.corr = z((batch, corr_stride, 3), torch.int32)
         self.n_corr = z((batch,), torch.int32)
         self.scene_index_map = None
+        self.corr_from_aligner = 0
         self.measurement_in_world = torch.eye(4, dtype=torch.float32, device=dev).repeat(batch, 1, 1).contiguous()
         self.measurement_in_scene = torch.eye(4, dtype=torch.float32, device=dev).repeat(batch, 1, 1).contiguous()
         self.frame = z((batch,), torch.int32)
@@ -636,6 +638,7 @@ class MapBatch:
         d.meas = self.meas.data_ptr() if self.max_measurements > 0 else None
         d.measurement_stride, d.corr_stride = self.measurement_stride, self.corr_stride
         d.scene_index_map = self.scene_index_map.data_ptr() if self.scene_index_map is not None else None
+        d.corr_from_aligner = int(self.corr_from_aligner)
         return d
 
 

@@ -184,7 +184,11 @@ def test_depth_ekf_merger_and_index_map(oracle, hip_ctx):
             maps.scene_index_map = torch.from_numpy(imap.reshape(1, cap)).cuda()
         rc, res = om.merge(po, T, T, poses, k, m, fixed, desc, corr, imap)
         assert rc == 0
-        _upload_frame(maps, 0, fixed, desc, corr, T, T, k)
+        # the device side receives the vector in the aligner's orientation (fixed -> measurement, moving -> scene)
+        swapped = corr.copy()
+        swapped["fixed_idx"], swapped["moving_idx"] = corr["moving_idx"], corr["fixed_idx"]
+        maps.corr_from_aligner = 1
+        _upload_frame(maps, 0, fixed, desc, swapped, T, T, k)
         ops.merge_batch(hip_ctx, pg, maps)
         hip_ctx.synchronize()
         got = maps.result[0].cpu().numpy()

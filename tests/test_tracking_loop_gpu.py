@@ -1,0 +1,147 @@
+"""Closed loop on the device vs the same chain on the CPU oracle (SURVEY.md 8a + 8f rows 1, 2):
+   frame k: stereo matcher (+ adaptor / triangulator epilogue) -> scene clipper on the resident map ->
+   projective finder + GN aligner -> merger (estimator updates + binned additions) -> map for frame k+1.
+Device buffers are chained without host copies (the matcher's fixed cloud feeds the aligner and the merger,
+the map arrays feed the clipper, the clipper's cloud is the aligner's moving cloud, the aligner's
+correspondence vector and the clipper's index map feed the merger); only the 4x4 pose update (prediction * X^-1) runs on the host.
+Every stage must equal the oracle bit for bit, and the estimated trajectory must follow the truth."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import aligner_params as oracle_aligner_params, corr_equal, oracle_stereo_params, oracle_tri_params, pcf_params_from_cfg
+from oracle import binding_mapping as om
+from srrg2_proslam_amd import _lib, configs, ops, synthetic as syn
+from tests.test_mapping_gpu import _assert_map_equal, _gpu_params
+from tests.test_oracle_mapping import merger_params as oracle_merger_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _camera_pose(k):
+    T = syn.make_transform((0.03 * k, -0.01 * k, 0.7 * k), (0.002 * k, 0.012 * k, -0.001 * k))
+    return np.asarray(T, dtype=np.float32).reshape(4, 4)
+
+
+@pytest.mark.parametrize("estimator", ["smoother", "weighted_mean"])
+def test_tracking_loop_matches_the_oracle_chain(oracle, hip_ctx, estimator):
+    cfg = configs.get("kitti")
+    cam = cfg["camera"]
+    K = (cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    B, n_kp, n_frames, cap, max_meas = 2, 700, 5, 3000, 8
+    est = (om.estimator_params(om.EST_SMOOTHER, 4, K, max_dist2=100.0, chi2_delta=1e-6) if estimator == "smoother"
+           else om.estimator_params(om.EST_WEIGHTED_MEAN, 4, K, max_dist2=100.0))
+    po = oracle_merger_params(cfg, om.MERGER_STEREO_TRIANGULATION, est, max_appearance=100.0, target_merges=10 ** 6)  # kitti.conf:188-227
+    pg = _gpu_params(po)
+    hip_ctx.use_torch_stream()
+
+    # ---- device side: one set of buffers, chained by aliasing --------------------------------------------
+    sframes = ops.StereoFrames(0, B, n_kp, epilogue=True)
+    maps = ops.MapBatch(0, B, cap, max_meas, n_frames + 1, n_kp, n_kp)
+    maps.measurement, maps.measurement_desc, maps.n_measured = sframes.fixed_uvuv, sframes.fixed_desc, sframes.n_fixed
+    clip = ops.ClipScenes(0, B, cap)
+    clip.scene_xyzw, clip.scene_desc, clip.n_scene, clip.scene_n_opt = maps.coords, maps.desc, maps.n_points, maps.n_opt
+    aframes = ops.AlignFrames(0, B, n_kp, cap)
+    aframes.fixed, aframes.fixed_desc, aframes.n_fixed = sframes.fixed_uvuv, sframes.fixed_desc, sframes.n_fixed
+    aframes.moving, aframes.moving_desc, aframes.n_moving = clip.clipped_xyzw, clip.clipped_desc, clip.n_clipped
+    maps.corr, maps.n_corr, maps.corr_from_aligner = aframes.corr, aframes.n_corr, 1
+    maps.scene_index_map = clip.global_indices
+    sp, tp = ops.stereo_params(cfg["stereo_matcher"], cam["rows"]), ops.triangulator_params(cfg)
+    proj = ops.pcf_params(cfg).projector
+    I4 = np.eye(4, dtype=np.float32)
+
+    # ---- oracle side ------------------------------------------------------------------------------------------
+    omaps = [om.Map(cap, max_meas) for _ in range(B)]
+    oposes = [om.pose_table(n_frames + 1) for _ in range(B)]
+    worlds = []
+    for b in range(B):
+        rng = np.random.default_rng(900 + b)
+        worlds.append((rng, syn.sample_landmarks(rng, cam, cfg["depth"], 520), syn.random_descriptors(rng, 520)))
+    est_pose = [I4.copy() for _ in range(B)]
+    zero_corr = np.zeros(0, oracle.CORR_DTYPE)
+
+    for k in range(n_frames):
+        truth = _camera_pose(k)
+        frames = []
+        for b, (rng, W, D) in enumerate(worlds):
+            Ti = np.linalg.inv(truth.astype(np.float64))
+            pk = ((Ti[:3, :3] @ W.T.astype(np.float64)).T + Ti[:3, 3]).astype(np.float32)
+            fr = syn.stereo_frame(rng, cfg, n_kp, landmarks=pk, landmark_desc=D)
+            frames.append(fr)
+            sframes.upload(b, fr["uv_left"], fr["desc_left"], fr["uv_right"], fr["desc_right"])
+        # 1. stereo matcher + adaptor + triangulator
+        ops.stereo_match_batch(hip_ctx, sp, sframes, tp)
+        fixed_o = []
+        for b, fr in enumerate(frames):
+            corr, _ = oracle.stereo_match(fr["uv_left"], fr["desc_left"], fr["uv_right"], fr["desc_right"], oracle_stereo_params(oracle, cfg["stereo_matcher"]))
+            fixed, src = oracle.stereo_assemble(fr["uv_left"], fr["uv_right"], corr)
+            fixed_o.append((fixed, fr["desc_left"][src]))
+        if k > 0:
+            # 2. scene clipper with the previous pose as the prediction; 3. finder + aligner
+            for b in range(B):
+                clip.robot_in_local_map[b] = torch.from_numpy(est_pose[b]).cuda()
+                # the clipped cloud is expressed in the predicted sensor frame (scene_clipper_projective_3d.cpp:46-53),
+                # so the aligner estimates the motion relative to the prediction, starting from the identity
+                aframes.X[b] = torch.from_numpy(I4.reshape(16).copy()).cuda()
+            aframes.reset_state()
+            aframes.inputs_changed.fill_(1)
+            ops.scene_clip_batch(hip_ctx, proj, I4, clip)
+            ops.align_batch(hip_ctx, ops.pcf_params(cfg), ops.aligner_params(cfg), aframes)
+            torch.cuda.synchronize()
+        corr_o, imap_o = [zero_corr] * B, [None] * B
+        for b in range(B):
+            m = omaps[b]
+            if k == 0:
+                continue
+            xyzw = m.coords[: m.n_points].copy()
+            xyzw[:, 3] = oracle.info_scale_from_nopt(m.n_opt[: m.n_points])
+            po_proj = pcf_params_from_cfg(oracle, cfg).projector
+            cx, cd, gi, cflags = oracle.scene_clip(po_proj, est_pose[b], I4, xyzw, m.desc[: m.n_points])
+            got = clip.clipped_of(b)
+            assert np.array_equal(_bits(cx), _bits(got[0])) and np.array_equal(cd, got[1]) and np.array_equal(gi, got[2]), (k, b, "clip")
+            assert len(gi) > 150
+            fixed, fdesc = fixed_o[b]
+            of = oracle.ProjectiveFinder(pcf_params_from_cfg(oracle, cfg))
+            of.set_fixed(fixed, fdesc)
+            of.set_moving(cx[:, :3], cd)
+            X0 = I4
+            res, rcorr = oracle.align_frame(of, oracle_aligner_params(oracle, cfg, mean_disparity=oracle.mean_disparity(fixed)), fixed, cx[:, :3], cx[:, 3], X0)
+            assert corr_equal(rcorr, aframes.corr_of(b)), (k, b, "correspondences")
+            Xr = np.array(res.X, np.float32).reshape(4, 4)
+            assert np.array_equal(_bits(Xr).ravel(), _bits(aframes.X[b].cpu().numpy()).ravel()), (k, b, "pose")
+            assert res.status == 1 and len(rcorr) > 100
+            est_pose[b] = oracle.se3_mul(est_pose[b], oracle.se3_inverse(Xr))  # prediction * (moving in fixed)^-1
+            # the merger's own orientation: fixed -> scene (through the clipper's index map), moving -> measurement
+            sw = rcorr.copy()
+            sw["fixed_idx"], sw["moving_idx"] = rcorr["moving_idx"], rcorr["fixed_idx"]
+            corr_o[b] = sw
+            imap_o[b] = np.concatenate([gi, np.zeros(cap - len(gi), np.int32)])
+        # 4. merger
+        for b in range(B):
+            maps.measurement_in_world[b] = torch.from_numpy(est_pose[b]).cuda()
+            maps.measurement_in_scene[b] = torch.from_numpy(est_pose[b]).cuda()
+            maps.frame[b] = k
+        if k == 0:
+            maps.n_corr = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        else:
+            maps.n_corr = aframes.n_corr
+        ops.merge_batch(hip_ctx, pg, maps)
+        torch.cuda.synchronize()
+        for b in range(B):
+            fixed, fdesc = fixed_o[b]
+            rc, res = om.merge(po, est_pose[b], est_pose[b], oposes[b], k, omaps[b], fixed, fdesc, corr_o[b], imap_o[b])
+            assert rc == 0
+            got = maps.result[b].cpu().numpy()
+            assert (int(got[0]), int(got[1]), int(got[2])) == (res.n_merged, res.n_added, res.flags), (k, b, got, res.n_merged, res.n_added)
+            _assert_map_equal(maps, b, omaps[b], oposes[b], k + 1)
+            if k > 0:
+                assert res.n_merged > 30
+        # the trajectory follows the truth (tests/test_trackers.cpp style gate, loose)
+        for b in range(B):
+            assert np.linalg.norm(est_pose[b][:3, 3] - truth[:3, 3]) < 0.15, (k, b, est_pose[b][:3, 3], truth[:3, 3])
+    assert all(m.n_points > 400 for m in omaps)
+    assert all(int(m.n_opt[: m.n_points].max()) >= 3 for m in omaps)
