@@ -147,12 +147,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook for 1-GPU boxes: all ranks share device 0 and the rendezvous runs on gloo, so that the
+    # multi-rank control flow (barriers, MAX over ranks, rank-0 reporting) can be exercised without 8 GPUs
+    shared = os.environ.get("PRS_BENCH_SHARE_GPU", "0") == "1"
+    if shared:
+        local_rank = 0
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if shared:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from srrg2_proslam_amd import _lib, configs, ops, synthetic as syn
 
@@ -223,7 +231,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
