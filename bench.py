@@ -38,7 +38,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=2048, help="independent sequences (frames per step) per GPU")
+    ap.add_argument("--batch", type=int, default=7680,
+                    help="independent sequences (frames per step) per GPU; 7680 = 30 per CU, a multiple of the 1 / 3 / 5 workgroups "
+                         "per CU the matcher / search / GN kernels keep resident (no partial last wave)")
     ap.add_argument("--keypoints", type=int, default=2000, help="keypoints per image (KITTI config: ~2000)")
     ap.add_argument("--moving", type=int, default=2000, help="local-map points per frame")
     ap.add_argument("--max-fixed", type=int, default=896, help="LDS sizing bound on stereo matches per frame")
@@ -123,7 +125,7 @@ def pmc_traffic_bytes(kernel_substrings, frames_per_launch):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "rocprof_summary.json")), reverse=True):
         try:
             summ = json.load(open(path))
-            if int(summ.get("frames_per_launch", 2048)) != int(frames_per_launch):
+            if int(summ.get("frames_per_launch", 0)) != int(frames_per_launch):
                 continue
             total = 0.0
             steps = [v["FETCH_SIZE"]["launches"] for k, v in summ["pmc_fetch"].items() if "stereo_match_kernel" in k][0]
