@@ -133,18 +133,8 @@ template <int KPT, bool STAGE>
 __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const StereoArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid    = threadIdx.x;
-  const int frame  = blockIdx.x;
   const int stride = a.b.stride;
   const int rows   = a.p.image_rows;
-  int nL           = a.b.n_left[frame];
-  int nR           = a.b.n_right[frame];
-  nL               = nL < 0 ? 0 : (nL > stride ? stride : nL);
-  nR               = nR < 0 ? 0 : (nR > stride ? stride : nR);
-  const size_t base = (size_t) frame * (size_t) stride;
-  const prs_kp2* __restrict__ kpL = a.b.left_kp + base;
-  const prs_kp2* __restrict__ kpR = a.b.right_kp + base;
-  const u32x4* __restrict__ gdL   = reinterpret_cast<const u32x4*>(a.b.left_desc + base * PRS_DESC_BYTES);
-  const u32x4* __restrict__ gdR   = reinterpret_cast<const u32x4*>(a.b.right_desc + base * PRS_DESC_BYTES);
 
   u32x4* ldR         = reinterpret_cast<u32x4*>(smem + a.off_desc_r);
   uint32_t* sortedL  = reinterpret_cast<uint32_t*>(smem + a.off_sorted_l);
@@ -164,15 +154,52 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
   uint32_t* histL    = sortedL;  // the histograms die before the sorted arrays are born
   uint32_t* histR    = sortedR;
 
+  // The staged variant keeps ONE workgroup per CU, so nothing would cover the latency of a frame's
+  // first loads.  It therefore runs persistently (grid = CUs, frames strided over the workgroups):
+  // the coordinates of the next frame (the first thing a frame needs) are requested while this frame
+  // is scored, chained and emitted; the descriptor rows of a frame are requested when it starts and
+  // arrive while its coordinates are sorted (they are first touched by the staging / scoring phases).
+  constexpr bool PERSIST = STAGE;
+  prs_kp2 cLn[KPT], cRn[KPT];
+  int nLn = 0, nRn = 0;
+  auto fetch_coords = [&](int f) {
+    int fl = a.b.n_left[f];
+    int fr = a.b.n_right[f];
+    fl     = fl < 0 ? 0 : (fl > stride ? stride : fl);
+    fr     = fr < 0 ? 0 : (fr > stride ? stride : fr);
+    nLn    = fl;
+    nRn    = fr;
+    const size_t fbase = (size_t) f * (size_t) stride;
+    const prs_kp2* __restrict__ fkL = a.b.left_kp + fbase;
+    const prs_kp2* __restrict__ fkR = a.b.right_kp + fbase;
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+      const int i = k * kStereoThreads + tid;
+      cLn[k]      = fkL[i < fl ? i : (fl > 0 ? fl - 1 : 0)];
+      cRn[k]      = fkR[i < fr ? i : (fr > 0 ? fr - 1 : 0)];
+    }
+  };
+  if (PERSIST && (int) blockIdx.x < a.b.batch) {
+    fetch_coords((int) blockIdx.x);
+  }
+  for (int frame = blockIdx.x; frame < a.b.batch; frame += gridDim.x) {
   PRS_STAMP(0);
-  // ---- A: issue every global read of this frame up front -------------------------------------
+  if (!PERSIST) {
+    fetch_coords(frame);
+  }
+  const int nL      = nLn;
+  const int nR      = nRn;
+  const size_t base = (size_t) frame * (size_t) stride;
+  const prs_kp2* __restrict__ kpR = a.b.right_kp + base;
+  const u32x4* __restrict__ gdL   = reinterpret_cast<const u32x4*>(a.b.left_desc + base * PRS_DESC_BYTES);
+  const u32x4* __restrict__ gdR   = reinterpret_cast<const u32x4*>(a.b.right_desc + base * PRS_DESC_BYTES);
   prs_kp2 cL[KPT], cR[KPT];
 #pragma unroll
   for (int k = 0; k < KPT; ++k) {
-    const int i = k * kStereoThreads + tid;
-    cL[k]       = kpL[i < nL ? i : (nL > 0 ? nL - 1 : 0)];
-    cR[k]       = kpR[i < nR ? i : (nR > 0 ? nR - 1 : 0)];
+    cL[k] = cLn[k];
+    cR[k] = cRn[k];
   }
+  // ---- A: issue every descriptor read of this frame up front -------------------------------------
   // thread t owns descriptor rows t, t+1024, ..: tail lanes re-read the last valid row (same
   // cache line, no extra HBM traffic) so the loads stay unconditional and in registers
   u32x4 dL[STAGE ? 2 * KPT : 2], dR[STAGE ? 2 * KPT : 2];
@@ -190,6 +217,7 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
       dR[2 * k + 1] = gdR[2 * ir + 1];
     }
   }
+  const int next_frame = frame + (int) gridDim.x;
 
   // ---- B: Feature{row,col,unsorted_index} + counting sort by row (epipolar_impl.cpp:8-42) ----
   for (int i = tid; i <= rows; i += kStereoThreads) {
@@ -248,7 +276,11 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
         a.b.n_fixed[frame] = 0;
       }
     }
-    return;
+    if (PERSIST && next_frame < a.b.batch) {
+      fetch_coords(next_frame);
+    }
+    __syncthreads();  // misc[] is rewritten by the next frame
+    continue;
   }
   PRS_STAMP(2);
   if (tid < 64) {
@@ -333,6 +365,9 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
   }
   __syncthreads();  // buckets are dead from here on: res[] may be written
   PRS_STAMP(5);
+  if (PERSIST && next_frame < a.b.batch) {
+    fetch_coords(next_frame);  // in flight while this frame is scored, chained and emitted
+  }
 
   const float max_dist  = a.p.maximum_descriptor_distance;
   const float max_ratio = a.p.maximum_distance_ratio_to_second_best;
@@ -654,6 +689,10 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
       a.b.n_fixed[frame] = fixed_base;
     }
   }
+  if (PERSIST) {
+    __syncthreads();  // the LDS arrays are rewritten by the next frame
+  }
+  }  // frames of this workgroup
 }
 
 // TriangulatorRigidStereo::compute on a flat device array (mapping/triangulator_rigid_stereo.cpp:7-85)
@@ -690,7 +729,16 @@ static hipError_t launch_variant(const StereoArgs& a, size_t lds, hipStream_t st
   if (e != hipSuccess) {
     return e;
   }
-  hipLaunchKernelGGL(kernel, dim3(a.b.batch), dim3(kStereoThreads), lds, stream, a);
+  int grid = a.b.batch;
+  if (STAGE) {
+    // persistent: one workgroup per CU (the LDS footprint allows no more), frames strided over them
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 &&
+        cus < grid) {
+      grid = cus;
+    }
+  }
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kStereoThreads), lds, stream, a);
   return hipGetLastError();
 }
 
