@@ -37,13 +37,16 @@ struct StereoArgs {
   int epilogue;
   int sort_cap;  // entries of each sorted / bucket array (>= stride, >= image_rows + 1)
   uint32_t off_desc_l, off_desc_r, off_sorted_l, off_sorted_r, off_bucket, off_rowstart_l, off_rowstart_r;
-  uint32_t off_rowcnt, off_bits, off_misc;
+  uint32_t off_rowcnt, off_bits, off_misc, off_tab;
+  // exact integer form of `best < max_distance && best / second < max_ratio` (epipolar_impl.cpp:171-173),
+  // evaluated on the host with the reference's float operations (fill_accept_table)
+  int best_lim;        // accept iff best < best_lim ...
+  int16_t bmax[258];   // ... and best <= bmax[second] (257 = no second candidate)
   unsigned long long* stamps;  // diagnostic: [batch][16] shader-clock stamps of thread 0 (NULL = off)
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kStereoThreads = 1024;
-constexpr float kFloatMax    = 3.402823466e+38f;
 constexpr uint32_t kNone16   = 0xffffu;
 
 #define PRS_STAMP(i)                                                        \
@@ -151,6 +154,7 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
   uint32_t* bitsK    = bitsR + nwords;                                  // epilogue: match index kept
   uint16_t* prefK    = reinterpret_cast<uint16_t*>(bitsK + nwords);     // epilogue: kept matches before word w
   int* misc          = reinterpret_cast<int*>(smem + a.off_misc);       // [0] error, [1] pass matches, [2] pass kept
+  int16_t* tab       = reinterpret_cast<int16_t*>(smem + a.off_tab);    // Lowe acceptance table
   uint32_t* histL    = sortedL;  // the histograms die before the sorted arrays are born
   uint32_t* histR    = sortedR;
 
@@ -179,6 +183,9 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
       cRn[k]      = fkR[i < fr ? i : (fr > 0 ? fr - 1 : 0)];
     }
   };
+  for (int i = tid; i < 258; i += kStereoThreads) {
+    tab[i] = a.bmax[i];  // published by the first barrier of the frame
+  }
   if (PERSIST && (int) blockIdx.x < a.b.batch) {
     fetch_coords((int) blockIdx.x);
   }
@@ -369,8 +376,7 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
     fetch_coords(next_frame);  // in flight while this frame is scored, chained and emitted
   }
 
-  const float max_dist  = a.p.maximum_descriptor_distance;
-  const float max_ratio = a.p.maximum_distance_ratio_to_second_best;
+  const int best_lim    = a.best_lim;
   const int max_disp    = a.p.maximum_disparity_pixels;
   const int thickness   = a.p.epipolar_line_thickness_pixels > 0 ? a.p.epipolar_line_thickness_pixels : 0;
   const int n_offsets   = 1 + 2 * thickness;
@@ -533,9 +539,8 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
               }
             }
             if (best != kNone16) {
-              const float fb = (float) best;
-              const float fs = second == kNone16 ? kFloatMax : (float) second;
-              if (fb < max_dist && fb / fs < max_ratio) {  // epipolar_impl.cpp:171-173
+              // epipolar_impl.cpp:171-173 through the host-evaluated table (no float division in the chain)
+              if ((int) best < best_lim && (int) best <= (int) tab[second == kNone16 ? 257u : second]) {
                 outrec = make_uint2((sortedR[best_q] & 0xffffu) | (best << 16), (uint32_t) cnt | ((uint32_t) (o + 1) << 16));
                 ++cnt;
                 c = (int) best_q + 1;  // epipolar_impl.cpp:181
@@ -773,6 +778,7 @@ int stereo_match_batch_launch(prs_context* ctx, const prs_stereo_params* params,
   } else {
     a.tri = prs_triangulator_params{1.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   }
+  fill_accept_table(params, &a.best_lim, a.bmax);
   a.stamps              = ctx_stamps(ctx, (size_t) batch->batch * 16 * sizeof(unsigned long long));
   const int kpt         = stride <= 1024 ? 1 : (stride <= 2048 ? 2 : (stride <= 4096 ? 4 : 8));
   const uint32_t rows1  = (uint32_t) params->image_rows + 1;
@@ -792,6 +798,7 @@ int stereo_match_batch_launch(prs_context* ctx, const prs_stereo_params* params,
     s.off_rowcnt     = off; off = align_up(off + (rows1 + 1) * 2, 16);
     s.off_bits       = off; off = align_up(off + nwords * (3 * 4 + 2), 16);
     s.off_misc       = off; off = align_up(off + 16, 16);
+    s.off_tab        = off; off = align_up(off + 258 * 2, 16);
     return off;
   };
   const size_t lds_limit = 160 * 1024;
