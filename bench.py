@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--binned-matcher", action="store_true", help="use the second-generation (row, column-block) binned matcher kernel")
     ap.add_argument("--all-iterations", action="store_true", help="disable the exact fixed-point early exit of the GN loop")
+    ap.add_argument("--cpu-all-cores", type=int, default=-1,
+                    help="worker processes of the all-core CPU figure (one independent sequence per core, SURVEY 8d); "
+                         "-1 = min(host cores, 256), 0 = skip")
+    ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)  # internal: frames to time in a CPU-only child
     return ap.parse_args()
 
 
@@ -115,6 +119,36 @@ def cpu_baseline(cfg, frames, n_frames):
 
 
 
+def cpu_worker(args):
+    """child process of the all-core CPU leg: never touches the GPU; prints the frames/s of its own sequence"""
+    from srrg2_proslam_amd import configs, synthetic as syn
+    cfg = configs.get("kitti")
+    frames = make_unique_frames(cfg, 4, args.keypoints, args.moving, syn.seed_for(1, 0) + 7000 + os.getpid() % 1000)
+    fps, dt, _ = cpu_baseline(cfg, frames, args.cpu_worker)
+    print(json.dumps({"fps": fps, "seconds": dt}))
+
+
+def cpu_all_cores(args, n_workers, frames_each):
+    """the oracle on every host core at once, one independent sequence per process"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(frames_each), "--keypoints", str(args.keypoints),
+           "--moving", str(args.moving)]
+    env = dict(os.environ)
+    env["HIP_VISIBLE_DEVICES"] = ""
+    env["OMP_NUM_THREADS"] = "1"
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env) for _ in range(n_workers)]
+    total, ok = 0.0, 0
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=240)
+            total += json.loads(out.decode().strip().splitlines()[-1])["fps"]
+            ok += 1
+        except Exception:
+            pr.kill()
+    return total, ok, time.perf_counter() - t0
+
+
 def pmc_traffic_bytes(kernel_substrings, frames_per_launch):
     """HBM bytes per bench step of the named kernels (= per launch for the matcher) from the committed rocprofv3 PMC passes of this same
     command (profiles/rNN/rocprof_summary.json, written by tools/profile_round.sh: FETCH_SIZE and
@@ -143,6 +177,9 @@ def pmc_traffic_bytes(kernel_substrings, frames_per_launch):
 
 def main():
     args = parse()
+    if args.cpu_worker > 0:
+        cpu_worker(args)
+        return
     import torch
     import torch.distributed as dist
 
@@ -336,6 +373,14 @@ def main():
         }
         out["parity_on_bench_inputs"] = {"pose_rel_frobenius_max": worst, "correspondences_bit_exact": exact_corr,
                                          "frames_checked": min(len(uniq), B)}
+        n_workers = args.cpu_all_cores if args.cpu_all_cores >= 0 else min(os.cpu_count() or 1, 256)
+        if n_workers > 0:
+            total, ok, wall = cpu_all_cores(args, n_workers, 48)
+            out["cpu_baseline_all_cores"] = {
+                "value": total, "unit": "frames/s", "cores": ok, "kind": "port",
+                "sample": "%d worker processes (one independent sequence each, 48 frames per worker) of the same oracle, "
+                          "sum of the per-worker rates, %.1f s wall" % (ok, wall),
+            }
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
