@@ -542,6 +542,13 @@ typedef struct {
 
 PRS_API int prs_merge_batch_run(prs_context* ctx, const prs_merger_params* params, const prs_merge_batch* batch);
 
+/* pose bookkeeping between the aligner and the merger / next clip, on the device:
+ * pose_out[b] = prediction[b] * X[b]^-1.  The clipper expresses the local map in the predicted sensor
+ * frame (scene_clipper_projective_3d.cpp:46-53), so the aligner's estimate X (moving in fixed) is the
+ * motion relative to the prediction; the tracker's new sensor pose in the map is prediction * X^-1.
+ * All pointers are device arrays of [batch][16] row-major float; pose_out may alias prediction. */
+PRS_API int prs_pose_compose_batch(prs_context* ctx, int32_t batch, const float* prediction, const float* X, float* pose_out);
+
 #ifdef __cplusplus
 }
 #endif

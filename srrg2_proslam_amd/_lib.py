@@ -268,6 +268,7 @@ SYMBOLS = {
     "prs_triangulate_dev": (C.c_int, [_vp, C.POINTER(TriangulatorParams), _vp, C.c_int64, _vp]),
     "prs_bruteforce_match_batch": (C.c_int, [_vp, C.POINTER(BruteforceParams), C.POINTER(BruteforceBatch)]),
     "prs_bruteforce_match": (C.c_int, [_vp, C.POINTER(BruteforceParams), _vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
+    "prs_pose_compose_batch": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),
     "prs_merge_batch_run": (C.c_int, [_vp, C.POINTER(MergerParams), C.POINTER(MergeBatch)]),
     "prs_scene_clip_batch": (C.c_int, [_vp, C.POINTER(Projector), _vp, C.POINTER(ClipBatch)]),
     "prs_scene_clip": (C.c_int, [_vp, C.POINTER(Projector), _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, C.c_int32, _i32p]),

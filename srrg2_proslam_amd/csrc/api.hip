@@ -625,4 +625,12 @@ int prs_merge_batch_run(prs_context* ctx, const prs_merger_params* params, const
   return merge_batch_launch(ctx, params, batch);
 }
 
+int prs_pose_compose_batch(prs_context* ctx, int32_t batch, const float* prediction, const float* X, float* pose_out) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  (void) hipSetDevice(ctx->device);
+  return pose_compose_launch(ctx, batch, prediction, X, pose_out);
+}
+
 }  // extern "C"

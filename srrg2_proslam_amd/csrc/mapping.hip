@@ -1008,4 +1008,40 @@ int merge_batch_launch(prs_context* ctx, const prs_merger_params* params, const 
   return PRS_OK;
 }
 
+// pose_out = prediction * X^-1 (tracker pose update between aligner and merger)
+__global__ __launch_bounds__(256) void pose_compose_kernel(int batch, const float* __restrict__ prediction, const float* __restrict__ X,
+                                                           float* __restrict__ pose_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) {
+    return;
+  }
+  float P[16], Xm[16], Xi[16], R[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    P[i]  = prediction[(size_t) b * 16 + i];
+    Xm[i] = X[(size_t) b * 16 + i];
+  }
+  se3_inverse(Xm, Xi);
+  se3_mul(P, Xi, R);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    pose_out[(size_t) b * 16 + i] = R[i];
+  }
+}
+
+int pose_compose_launch(prs_context* ctx, int batch, const float* prediction, const float* X, float* pose_out) {
+  if (!prediction || !X || !pose_out) {
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_pose_compose_batch: pose arrays not set");
+  }
+  if (batch <= 0) {
+    return PRS_OK;
+  }
+  hipLaunchKernelGGL(pose_compose_kernel, dim3((batch + 255) / 256), dim3(256), 0, ctx_stream(ctx), batch, prediction, X, pose_out);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_pose_compose_batch launch");
+  }
+  return PRS_OK;
+}
+
 }  // namespace prs

@@ -648,3 +648,11 @@ def merge_batch(ctx, params, maps):
     rc = _lib.load().prs_merge_batch_run(ctx._h, C.byref(params), C.byref(d))
     _check(ctx, rc, "prs_merge_batch_run")
     return rc
+
+
+def pose_compose_batch(ctx, prediction, X, pose_out):
+    """pose_out[b] = prediction[b] * X[b]^-1 on device tensors of shape [B, 16] / [B, 4, 4] (asynchronous)"""
+    batch = int(prediction.shape[0])
+    rc = _lib.load().prs_pose_compose_batch(ctx._h, batch, prediction.data_ptr(), X.data_ptr(), pose_out.data_ptr())
+    _check(ctx, rc, "prs_pose_compose_batch")
+    return rc

@@ -3,7 +3,7 @@
    projective finder + GN aligner -> merger (estimator updates + binned additions) -> map for frame k+1.
 Device buffers are chained without host copies (the matcher's fixed cloud feeds the aligner and the merger,
 the map arrays feed the clipper, the clipper's cloud is the aligner's moving cloud, the aligner's
-correspondence vector and the clipper's index map feed the merger); only the 4x4 pose update (prediction * X^-1) runs on the host.
+correspondence vector and the clipper's index map feed the merger); the pose update (prediction * X^-1) is a device kernel too; the host only mirrors it for the oracle chain.
 Every stage must equal the oracle bit for bit, and the estimated trajectory must follow the truth."""
 import numpy as np
 import pytest
@@ -62,6 +62,7 @@ def test_tracking_loop_matches_the_oracle_chain(oracle, hip_ctx, estimator):
         rng = np.random.default_rng(900 + b)
         worlds.append((rng, syn.sample_landmarks(rng, cam, cfg["depth"], 520), syn.random_descriptors(rng, 520)))
     est_pose = [I4.copy() for _ in range(B)]
+    dev_pose = torch.eye(4, dtype=torch.float32, device="cuda").repeat(B, 1, 1).contiguous()
     zero_corr = np.zeros(0, oracle.CORR_DTYPE)
 
     for k in range(n_frames):
@@ -82,8 +83,8 @@ def test_tracking_loop_matches_the_oracle_chain(oracle, hip_ctx, estimator):
             fixed_o.append((fixed, fr["desc_left"][src]))
         if k > 0:
             # 2. scene clipper with the previous pose as the prediction; 3. finder + aligner
+            clip.robot_in_local_map.copy_(dev_pose)  # prediction = previous pose (device to device)
             for b in range(B):
-                clip.robot_in_local_map[b] = torch.from_numpy(est_pose[b]).cuda()
                 # the clipped cloud is expressed in the predicted sensor frame (scene_clipper_projective_3d.cpp:46-53),
                 # so the aligner estimates the motion relative to the prediction, starting from the identity
                 aframes.X[b] = torch.from_numpy(I4.reshape(16).copy()).cuda()
@@ -91,6 +92,8 @@ def test_tracking_loop_matches_the_oracle_chain(oracle, hip_ctx, estimator):
             aframes.inputs_changed.fill_(1)
             ops.scene_clip_batch(hip_ctx, proj, I4, clip)
             ops.align_batch(hip_ctx, ops.pcf_params(cfg), ops.aligner_params(cfg), aframes)
+            # the tracker's pose update stays on the device as well: pose = prediction * X^-1
+            ops.pose_compose_batch(hip_ctx, clip.robot_in_local_map, aframes.X, dev_pose)
             torch.cuda.synchronize()
         corr_o, imap_o = [zero_corr] * B, [None] * B
         for b in range(B):
@@ -115,16 +118,16 @@ def test_tracking_loop_matches_the_oracle_chain(oracle, hip_ctx, estimator):
             assert np.array_equal(_bits(Xr).ravel(), _bits(aframes.X[b].cpu().numpy()).ravel()), (k, b, "pose")
             assert res.status == 1 and len(rcorr) > 100
             est_pose[b] = oracle.se3_mul(est_pose[b], oracle.se3_inverse(Xr))  # prediction * (moving in fixed)^-1
+            assert np.array_equal(_bits(est_pose[b]).ravel(), _bits(dev_pose[b].cpu().numpy()).ravel()), (k, b, "pose update")
             # the merger's own orientation: fixed -> scene (through the clipper's index map), moving -> measurement
             sw = rcorr.copy()
             sw["fixed_idx"], sw["moving_idx"] = rcorr["moving_idx"], rcorr["fixed_idx"]
             corr_o[b] = sw
             imap_o[b] = np.concatenate([gi, np.zeros(cap - len(gi), np.int32)])
         # 4. merger
-        for b in range(B):
-            maps.measurement_in_world[b] = torch.from_numpy(est_pose[b]).cuda()
-            maps.measurement_in_scene[b] = torch.from_numpy(est_pose[b]).cuda()
-            maps.frame[b] = k
+        maps.measurement_in_world.copy_(dev_pose)
+        maps.measurement_in_scene.copy_(dev_pose)
+        maps.frame.fill_(k)
         if k == 0:
             maps.n_corr = torch.zeros((B,), dtype=torch.int32, device="cuda")
         else:
