@@ -34,7 +34,7 @@ struct MergeArgs {
   prs_merge_batch b;
   float row_w, col_w;  // bin widths in pixels (merger_projective_impl.cpp:30-33)
   int nbr, nbc;        // bin table extent
-  uint32_t off_owner, off_first, off_best, off_seen, off_sh, off_wave;
+  uint32_t off_owner, off_first, off_best, off_seen, off_sh, off_wave, off_pose_cache;
 };
 
 struct MergeShared {
@@ -489,8 +489,11 @@ __device__ void solve3_full_pivot(const float* A_in, const float* rhs, float* x)
   }
 }
 
-__device__ int estimate_smoother(const prs_estimator_params& P, const MergeShared& sh, const prs_frame_pose* poses, int frame, int max_measurements,
-                                 const Landmark& l, const float* measurement, const float* landmark_in_sensor) {
+// pose_cache: per frame of the map's pose table 21 floats in LDS: world_in_sensor (3x4) and camera_matrix * R (3x3, the
+// "jacobian_linear" of :89, which depends on the frame only) -- evaluated once per workgroup instead of once per
+// measurement and iteration, with the same operations in the same order
+__device__ int estimate_smoother(const prs_estimator_params& P, const MergeShared& sh, const prs_frame_pose* poses, const float* pose_cache, int frame,
+                                 int max_measurements, const Landmark& l, const float* measurement, const float* landmark_in_sensor) {
   *l.inlier = 0;  // :13
   if (!l.meas || *l.n_meas >= (uint32_t) max_measurements) {
     return PRS_ERR_HISTORY;
@@ -542,7 +545,8 @@ __device__ int estimate_smoother(const prs_estimator_params& P, const MergeShare
     uint32_t number_of_outliers = 0;
     for (uint32_t k = 0; k < n; ++k) {
       float omega[3] = {1.0f, 1.0f, 10.0f};  // :59-60
-      const float* W = poses[M[k].frame].world_in_sensor;
+      const float* W  = pose_cache + 21 * M[k].frame;
+      const float* Jl = W + 12;
       float pc[3];
       apply_pose(W, world, pc);  // :63
       if (pc[2] <= 0.0f) {
@@ -568,14 +572,7 @@ __device__ int estimate_smoother(const prs_estimator_params& P, const MergeShare
         omega[2] *= s;
         ++number_of_outliers;
       }
-      float Jl[9], Jh[9], J[9];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {  // K * R (:89)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          Jl[3 * i + j] = (Km[3 * i + 0] * W[0 + j] + Km[3 * i + 1] * W[4 + j]) + Km[3 * i + 2] * W[8 + j];
-        }
-      }
+      float Jh[9], J[9];
       Jh[0] = inv_c; Jh[1] = 0.0f;  Jh[2] = -ph[0] * inv_c2;  // :94-98
       Jh[3] = 0.0f;  Jh[4] = inv_c; Jh[5] = -ph[1] * inv_c2;
       Jh[6] = 0.0f;  Jh[7] = 0.0f;  Jh[8] = 1.0f;
@@ -651,6 +648,9 @@ __device__ __forceinline__ uint32_t float_key(float v) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// EST / DIM are compile-time so that an instantiation only carries the registers of its own estimator
+// (the double-precision EKF would otherwise set the occupancy of the float estimators too)
+template <int EST, int DIM>
 __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* owner   = reinterpret_cast<uint32_t*>(smem + a.off_owner);  // first correspondence reaching the bin
@@ -659,6 +659,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
   uint32_t* seen    = reinterpret_cast<uint32_t*>(smem + a.off_seen);   // scene indices already referenced
   MergeShared& sh   = *reinterpret_cast<MergeShared*>(smem + a.off_sh);
   int* wave_tot     = reinterpret_cast<int*>(smem + a.off_wave);
+  float* pose_cache = reinterpret_cast<float*>(smem + a.off_pose_cache);  // smoother: [max_frames][21]
   const int tid     = threadIdx.x;
   const int lane    = tid & 63;
   const int wave    = tid >> 6;
@@ -718,6 +719,27 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
       B.result[map].status   = sh.error;
     }
     return;
+  }
+
+  if (EST == PRS_EST_SMOOTHER) {
+    // every frame of the pose table (this frame's row was written above): world_in_sensor and camera_matrix * R
+    for (int f = tid; f < B.max_frames; f += kMergeThreads) {
+      const float* W  = f == frame ? sh.world_in_sensor : poses[f].world_in_sensor;
+      const float* Km = P.estimator.camera_matrix;
+      float* c        = pose_cache + 21 * f;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        c[i] = W[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {  // landmark_estimator_pose_based_smoother_impl.cpp:89
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          c[12 + 3 * i + j] = (Km[3 * i + 0] * W[0 + j] + Km[3 * i + 1] * W[4 + j]) + Km[3 * i + 2] * W[8 + j];
+        }
+      }
+    }
+    __syncthreads();
   }
 
   // ---- correspondences: inlier reset, appearance gate, first-come bin blocking (:59-122) --------------
@@ -785,13 +807,12 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
     const Landmark l   = landmark_at(B, map, s);
     const float zv[4]  = {z.x, z.y, z.z, z.w};
     int ok;
-    if (P.estimator.type == PRS_EST_WEIGHTED_MEAN) {
+    if (EST == PRS_EST_WEIGHTED_MEAN) {
       ok = estimate_weighted_mean(P.estimator, sh, l, lis);
-    } else if (P.estimator.type == PRS_EST_EKF) {
-      ok = P.estimator.measurement_dim == 4 ? estimate_ekf<4>(P.estimator, sh, l, zv)
-                                            : (P.estimator.measurement_dim == 3 ? estimate_ekf<3>(P.estimator, sh, l, zv) : estimate_ekf<2>(P.estimator, sh, l, zv));
+    } else if (EST == PRS_EST_EKF) {
+      ok = estimate_ekf<DIM>(P.estimator, sh, l, zv);
     } else {
-      ok = estimate_smoother(P.estimator, sh, poses, frame, B.max_measurements, l, zv, lis);
+      ok = estimate_smoother(P.estimator, sh, poses, pose_cache, frame, B.max_measurements, l, zv, lis);
     }
     if (ok < 0) {
       sh.error = ok;
@@ -991,16 +1012,30 @@ int merge_batch_launch(prs_context* ctx, const prs_merger_params* params, const 
   a.off_seen  = off; off = mg_align16(off + ((uint32_t) b.capacity + 31) / 32 * 4);
   a.off_sh    = off; off = mg_align16(off + (uint32_t) sizeof(MergeShared));
   a.off_wave  = off; off = mg_align16(off + kMergeWaves * 4);
+  a.off_pose_cache = off; off = mg_align16(off + (e.type == PRS_EST_SMOOTHER ? (uint32_t) b.max_frames * 21 * 4 : 0));
   if (off > 160u * 1024u) {
     return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_merge_batch_run: bin table / scene do not fit the 160 KiB LDS");
   }
   hipError_t e2 = hipSuccess;
-  if (off > 64u * 1024u) {
-    e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) off);
-  }
-  if (e2 == hipSuccess) {
-    hipLaunchKernelGGL(merge_kernel, dim3(b.batch), dim3(kMergeThreads), off, ctx_stream(ctx), a);
-    e2 = hipGetLastError();
+  auto launch = [&](auto kernel) {
+    if (off > 64u * 1024u) {
+      e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) off);
+    }
+    if (e2 == hipSuccess) {
+      hipLaunchKernelGGL(kernel, dim3(b.batch), dim3(kMergeThreads), off, ctx_stream(ctx), a);
+      e2 = hipGetLastError();
+    }
+  };
+  if (e.type == PRS_EST_WEIGHTED_MEAN) {
+    launch(merge_kernel<PRS_EST_WEIGHTED_MEAN, 4>);
+  } else if (e.type == PRS_EST_SMOOTHER) {
+    launch(merge_kernel<PRS_EST_SMOOTHER, 4>);
+  } else if (e.measurement_dim == 4) {
+    launch(merge_kernel<PRS_EST_EKF, 4>);
+  } else if (e.measurement_dim == 3) {
+    launch(merge_kernel<PRS_EST_EKF, 3>);
+  } else {
+    launch(merge_kernel<PRS_EST_EKF, 2>);
   }
   if (e2 != hipSuccess) {
     return ctx_fail_hip(ctx, e2, "prs_merge_batch_run launch");
