@@ -35,6 +35,7 @@ struct MergeArgs {
   float row_w, col_w;  // bin widths in pixels (merger_projective_impl.cpp:30-33)
   int nbr, nbc;        // bin table extent
   uint32_t off_owner, off_first, off_best, off_seen, off_sh, off_wave, off_pose_cache;
+  void* work;          // smoother: [batch][2][corr_stride] work items (two lists, swapped every round)
 };
 
 struct MergeShared {
@@ -45,6 +46,7 @@ struct MergeShared {
   int error;
   int n_merged;
   int base;
+  int n_work, n_next;  // smoother work items of this / the next round
 };
 
 __device__ __forceinline__ void apply_rows(const float* T, const float* p, float* out) {
@@ -491,9 +493,25 @@ __device__ void solve3_full_pivot(const float* A_in, const float* rhs, float* x)
 
 // pose_cache: per frame of the map's pose table 21 floats in LDS: world_in_sensor (3x4) and camera_matrix * R (3x3, the
 // "jacobian_linear" of :89, which depends on the frame only) -- evaluated once per workgroup instead of once per
-// measurement and iteration, with the same operations in the same order
-__device__ int estimate_smoother(const prs_estimator_params& P, const MergeShared& sh, const prs_frame_pose* poses, const float* pose_cache, int frame,
-                                 int max_measurements, const Landmark& l, const float* measurement, const float* landmark_in_sensor) {
+// measurement and iteration, with the same operations in the same order.
+//
+// The Gauss-Newton loop of a landmark either repeats its chi2 after a handful of iterations or runs all
+// maximum_number_of_iterations (kitti.conf's delta of 1e-6 is below the float resolution of the chi2 sums), so
+// one lane per landmark for the whole loop would make every wave as slow as its slowest lane.  The loop state
+// therefore lives in a work item; lanes run a few iterations per round and the unfinished items are compacted
+// between rounds, so that only as many waves as there are unfinished landmarks keep iterating.
+struct SmootherItem {
+  int s, m;               // scene index, measurement index
+  float world[3];         // the variable being optimised (:26)
+  float total_previous;   // :46
+  uint32_t it;            // iterations done
+  uint32_t n_inliers;     // of the last iteration (:110)
+};
+
+// everything before the loop (:13-43).  Returns < 0 on error, 0 / 1 when the landmark is finished already
+// (fewer measurements than minimum_number_of_measurements_for_optimization: averaging), 2 when `item` is ready to iterate
+__device__ int smoother_begin(const prs_estimator_params& P, const MergeShared& sh, const prs_frame_pose* poses, int frame, int max_measurements,
+                              const Landmark& l, const float* measurement, const float* landmark_in_sensor, SmootherItem& item) {
   *l.inlier = 0;  // :13
   if (!l.meas || *l.n_meas >= (uint32_t) max_measurements) {
     return PRS_ERR_HISTORY;
@@ -530,11 +548,27 @@ __device__ int estimate_smoother(const prs_estimator_params& P, const MergeShare
     }
     return *l.inlier;
   }
+  item.world[0]       = world[0];
+  item.world[1]       = world[1];
+  item.world[2]       = world[2];
+  item.total_previous = 0.0f;  // :46
+  item.it             = 0;
+  item.n_inliers      = 0;
+  return 2;
+}
+
+// up to `budget` iterations of the loop (:49-119); true when the loop has ended (converged or out of iterations)
+__device__ bool smoother_iterate(const prs_estimator_params& P, const float* pose_cache, const Landmark& l, SmootherItem& item, int budget) {
+  const prs_camera_measurement* M = l.meas;
+  const uint32_t n           = *l.n_meas;
   const float* Km            = P.camera_matrix;
   const float max_kernel     = P.maximum_reprojection_error_pixels_squared;
-  float total_previous       = 0.0f;  // :46
-  uint32_t number_of_inliers = 0;
-  for (uint32_t it = 0; it < P.maximum_number_of_iterations; ++it) {
+  float world[3]             = {item.world[0], item.world[1], item.world[2]};
+  float total_previous       = item.total_previous;
+  uint32_t number_of_inliers = item.n_inliers;
+  uint32_t it                = item.it;
+  bool ended                 = it >= P.maximum_number_of_iterations;
+  while (!ended && budget > 0) {
     float H[9], b[3];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -599,16 +633,32 @@ __device__ int estimate_smoother(const prs_estimator_params& P, const MergeShare
     world[1] += dx[1];
     world[2] += dx[2];
     number_of_inliers = n - number_of_outliers;
+    ++it;
+    --budget;
     if (fabsf(total_error_squared - total_previous) < P.convergence_criterion_minimum_chi2_delta) {  // :113-117
-      break;
+      ended = true;
+    } else {
+      total_previous = total_error_squared;
+      ended          = it >= P.maximum_number_of_iterations;
     }
-    total_previous = total_error_squared;
   }
-  if (number_of_inliers > *l.n_opt) {  // :122-127
+  item.world[0]       = world[0];
+  item.world[1]       = world[1];
+  item.world[2]       = world[2];
+  item.total_previous = total_previous;
+  item.n_inliers      = number_of_inliers;
+  item.it             = it;
+  return ended;
+}
+
+// everything after the loop (:121-138)
+__device__ int smoother_finish(const MergeShared& sh, const prs_frame_pose* poses, const Landmark& l, const SmootherItem& item) {
+  float world[3] = {item.world[0], item.world[1], item.world[2]};
+  if (item.n_inliers > *l.n_opt) {  // :122-127
     add_optimization_result(l, world, nullptr);
     *l.inlier = 1;
   } else {  // :130-135
-    mean_in_world(M, n, poses, world);
+    mean_in_world(l.meas, *l.n_meas, poses, world);
     l.state[0] = world[0];
     l.state[1] = world[1];
     l.state[2] = world[2];
@@ -676,6 +726,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
   const prs_corr* __restrict__ corr = B.corr ? B.corr + (size_t) map * B.corr_stride : nullptr;
   const int32_t* __restrict__ imap  = B.scene_index_map ? B.scene_index_map + (size_t) map * B.capacity : nullptr;
   prs_frame_pose* poses = B.poses + (size_t) map * B.max_frames;
+  SmootherItem* work    = EST == PRS_EST_SMOOTHER ? static_cast<SmootherItem*>(a.work) + (size_t) map * 2 * B.corr_stride : nullptr;
 
   // ---- setTransforms (landmark_estimator_base.hpp:47-56) + this frame's row of the pose table ---------
   if (tid == 0) {
@@ -695,6 +746,8 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
     sh.error    = (frame < 0 || frame >= B.max_frames || n_points < 0 || n_points > B.capacity) ? PRS_ERR_RANGE : 0;
     sh.n_merged = 0;
     sh.base     = 0;
+    sh.n_work   = 0;
+    sh.n_next   = 0;
     if (!sh.error) {
       for (int i = 0; i < 12; ++i) {
         poses[frame].sensor_in_world[i] = Tw[i];
@@ -812,7 +865,14 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
     } else if (EST == PRS_EST_EKF) {
       ok = estimate_ekf<DIM>(P.estimator, sh, l, zv);
     } else {
-      ok = estimate_smoother(P.estimator, sh, poses, pose_cache, frame, B.max_measurements, l, zv, lis);
+      SmootherItem item;
+      item.s = s;
+      item.m = m;
+      ok     = smoother_begin(P.estimator, sh, poses, frame, B.max_measurements, l, zv, lis, item);
+      if (ok == 2) {
+        work[atomicAdd(&sh.n_work, 1)] = item;  // iterated below, in rounds
+        continue;
+      }
     }
     if (ok < 0) {
       sh.error = ok;
@@ -825,6 +885,39 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
     }
   }
   __syncthreads();
+  if (EST == PRS_EST_SMOOTHER) {
+    constexpr int kRoundIterations = 8;
+    SmootherItem* cur = work;
+    SmootherItem* nxt = work + B.corr_stride;
+    int n_work        = sh.n_work;
+    while (n_work > 0) {  // block-uniform
+      for (int i = tid; i < n_work; i += kMergeThreads) {
+        SmootherItem item = cur[i];
+        const Landmark l  = landmark_at(B, map, item.s);
+        if (smoother_iterate(P.estimator, pose_cache, l, item, kRoundIterations)) {
+          if (smoother_finish(sh, poses, l, item)) {  // merger_projective_impl.cpp:203-207
+            const uint4* src = reinterpret_cast<const uint4*>(zdesc + 32 * (size_t) item.m);
+            uint4* dst       = reinterpret_cast<uint4*>(l.desc);
+            dst[0]           = src[0];
+            dst[1]           = src[1];
+            atomicAdd(&sh.n_merged, 1);
+          }
+        } else {
+          nxt[atomicAdd(&sh.n_next, 1)] = item;
+        }
+      }
+      __syncthreads();
+      n_work = sh.n_next;
+      __syncthreads();
+      if (tid == 0) {
+        sh.n_next = 0;
+      }
+      SmootherItem* t = cur;
+      cur             = nxt;
+      nxt             = t;
+      __syncthreads();
+    }
+  }
   const int n_merged = sh.n_merged;
   int status         = 0;
   if (n_corr > 0) {  // :137-150
@@ -1015,6 +1108,18 @@ int merge_batch_launch(prs_context* ctx, const prs_merger_params* params, const 
   a.off_pose_cache = off; off = mg_align16(off + (e.type == PRS_EST_SMOOTHER ? (uint32_t) b.max_frames * 21 * 4 : 0));
   if (off > 160u * 1024u) {
     return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_merge_batch_run: bin table / scene do not fit the 160 KiB LDS");
+  }
+  a.work = nullptr;
+  if (e.type == PRS_EST_SMOOTHER) {
+    if (!b.corr || b.corr_stride <= 0) {
+      // no correspondences at all: nothing to iterate, but the pointer must be valid
+      a.work = ctx_device_scratch_slot(ctx, 0, 64);
+    } else {
+      a.work = ctx_device_scratch_slot(ctx, 0, (size_t) b.batch * 2 * (size_t) b.corr_stride * sizeof(SmootherItem));
+    }
+    if (!a.work) {
+      return ctx_fail(ctx, PRS_ERR_HIP, "prs_merge_batch_run: smoother work list allocation failed");
+    }
   }
   hipError_t e2 = hipSuccess;
   auto launch = [&](auto kernel) {
