@@ -18,6 +18,8 @@
 //   phase 3: the levels in ascending order: pool membership, uniqueness counts, registration;
 //   phase 4: emit ordered by (distance, fixed index) -- the canonical order this build defines for the
 //            reference's unstable std::sort by response only (:94-97).
+#include <type_traits>
+
 #include "prs_device.h"
 #include "prs_host.h"
 
@@ -38,7 +40,13 @@ struct BfArgs {
   uint32_t* bitmaps;   // [grid][(fixed_stride + moving_stride) * nw]
   // LDS carve (bytes)
   uint32_t off_cnt_f, off_cnt_m, off_reg_f, off_reg_m, off_acc, off_hist;
+  // few cloud pairs: the dense phase is spread over `chunks` workgroups per pair (each takes a slice of the
+  // moving cloud) that accumulate into global memory; one workgroup per pair then registers the candidates
+  int chunks;
+  uint32_t* g_acc;     // [batch][fixed_stride + moving_stride + 256 + 8]: candidates per fixed, per moving, per level, total
 };
+
+enum { kBfFused = 0, kBfDense = 1, kBfRegister = 2 };
 
 // Lowe's ratio against the sorted distance list of one index (bruteforce_impl.cpp:157-199):
 // a single-entry list passes (:181-184); otherwise the first strictly larger distance is the second
@@ -67,7 +75,7 @@ __device__ __forceinline__ bool lowe_ok(uint32_t* bm, int nw, uint32_t count, in
   return (float) d / (float) second < max_ratio;
 }
 
-template <int KPT>
+template <int KPT, int MODE>
 __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* cnt_f  = reinterpret_cast<uint32_t*>(smem + a.off_cnt_f);   // candidates per fixed; later pool counts
@@ -83,12 +91,21 @@ __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) 
   const int tid    = threadIdx.x;
   const int lane   = tid & 63;
   const int wave   = tid >> 6;
-  uint2* __restrict__ cand     = a.cand + (size_t) blockIdx.x * a.cap;
-  uint2* __restrict__ by_level = a.by_level + (size_t) blockIdx.x * a.cap;
-  uint32_t* __restrict__ bm_f  = a.bitmaps + (size_t) blockIdx.x * (size_t) (a.b.fixed_stride + a.b.moving_stride) * a.nw;
+  // scratch rows: per workgroup when fused (workgroups loop over pairs), per pair in the split shape
+  const int scratch_row        = MODE == kBfDense ? (int) blockIdx.y : (int) blockIdx.x;
+  uint2* __restrict__ cand     = a.cand + (size_t) scratch_row * a.cap;
+  uint2* __restrict__ by_level = a.by_level + (size_t) scratch_row * a.cap;
+  uint32_t* __restrict__ bm_f  = a.bitmaps + (size_t) scratch_row * (size_t) (a.b.fixed_stride + a.b.moving_stride) * a.nw;
   uint32_t* __restrict__ bm_m  = bm_f + (size_t) a.b.fixed_stride * a.nw;
+  const size_t acc_row         = (size_t) (a.b.fixed_stride + a.b.moving_stride + kBfLevels + 8);
+  uint32_t* __restrict__ g_cnt_f = MODE == kBfFused ? nullptr : a.g_acc + (size_t) scratch_row * acc_row;
+  uint32_t* __restrict__ g_cnt_m = MODE == kBfFused ? nullptr : g_cnt_f + a.b.fixed_stride;
+  uint32_t* __restrict__ g_hist  = MODE == kBfFused ? nullptr : g_cnt_m + a.b.moving_stride;
+  uint32_t* __restrict__ g_total = MODE == kBfFused ? nullptr : g_hist + kBfLevels;
 
-  for (int frame = blockIdx.x; frame < a.b.batch; frame += gridDim.x) {
+  const int frame_first = MODE == kBfDense ? (int) blockIdx.y : (int) blockIdx.x;
+  const int frame_step  = MODE == kBfFused ? (int) gridDim.x : a.b.batch;  // split shapes: exactly one pair per workgroup
+  for (int frame = frame_first; frame < a.b.batch; frame += frame_step) {
     int nf = a.b.n_fixed[frame];
     int nm = a.b.n_moving[frame];
     nf     = nf < 0 ? 0 : (nf > a.b.fixed_stride ? a.b.fixed_stride : nf);
@@ -103,24 +120,31 @@ __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) 
     const_u32* gdm = (const_u32*) (uintptr_t) (a.b.moving_desc + (size_t) frame * a.b.moving_stride * PRS_DESC_BYTES);
 
     // ---- reset ----------------------------------------------------------------------------------
-    for (int i = tid; i < nf; i += kBfThreads) {
-      cnt_f[i] = 0;
-      reg_f[i] = 0;
-      acc[i]   = 0xffffffffu;
+    if (MODE != kBfDense) {
+      for (int i = tid; i < nf; i += kBfThreads) {
+        cnt_f[i] = MODE == kBfRegister ? g_cnt_f[i] : 0u;
+        reg_f[i] = 0;
+        acc[i]   = 0xffffffffu;
+      }
+      for (int i = tid; i < nm; i += kBfThreads) {
+        cnt_m[i] = MODE == kBfRegister ? g_cnt_m[i] : 0u;
+        reg_m[i] = 0;
+      }
+      if (MODE == kBfFused) {
+        for (int i = tid; i < (nf + nm) * a.nw; i += kBfThreads) {
+          // fixed rows first, moving rows behind them (bm_m = bm_f + fixed_stride * nw)
+          const int idx = i < nf * a.nw ? i : (a.b.fixed_stride * a.nw + (i - nf * a.nw));
+          bm_f[idx]     = 0;
+        }
+      }
+      for (int i = tid; i < 4 * kBfLevels + 8; i += kBfThreads) {
+        hist[i] = (MODE == kBfRegister && i < kBfLevels) ? g_hist[i] : 0u;
+      }
+      __syncthreads();
+      if (MODE == kBfRegister && tid == 0) {
+        misc[0] = g_total[0];
+      }
     }
-    for (int i = tid; i < nm; i += kBfThreads) {
-      cnt_m[i] = 0;
-      reg_m[i] = 0;
-    }
-    for (int i = tid; i < (nf + nm) * a.nw; i += kBfThreads) {
-      // fixed rows first, moving rows behind them (bm_m = bm_f + fixed_stride * nw)
-      const int idx = i < nf * a.nw ? i : (a.b.fixed_stride * a.nw + (i - nf * a.nw));
-      bm_f[idx]     = 0;
-    }
-    for (int i = tid; i < 4 * kBfLevels + 8; i += kBfThreads) {
-      hist[i] = 0;
-    }
-    __syncthreads();
 
     // ---- phase 1: all pairs (bruteforce_impl.cpp:32-79) ----------------------------------------
     uint32_t fd[KPT][8];
@@ -133,16 +157,26 @@ __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) 
         fd[k][w] = nf > 0 ? gdf[8 * fc + w] : 0u;
       }
     }
+    // the slice of the moving cloud this workgroup scores
+    int m_begin = 0, m_end = nm;
+    if (MODE == kBfDense) {
+      const int per = (nm + a.chunks - 1) / a.chunks;
+      m_begin       = (int) blockIdx.x * per;
+      m_end         = m_begin + per < nm ? m_begin + per : nm;
+    }
+    if (MODE == kBfRegister) {
+      m_begin = m_end = 0;
+    }
     uint32_t md_next[8];
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
-      md_next[w] = nm > 0 ? gdm[w] : 0u;
+      md_next[w] = m_begin < m_end ? gdm[8 * m_begin + w] : 0u;
     }
-    for (int m = 0; m < nm; ++m) {
+    for (int m = m_begin; m < m_end; ++m) {
       // uniform address: the row travels through the scalar cache into SGPRs; the next row is
       // requested before this one is scored
       uint32_t md[8];
-      const int mn = m + 1 < nm ? m + 1 : m;
+      const int mn = m + 1 < m_end ? m + 1 : m;
 #pragma unroll
       for (int w = 0; w < 8; ++w) {
         md[w]      = md_next[w];
@@ -157,18 +191,27 @@ __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) 
         }
         const int f = k * kBfThreads + tid;
         if (d < a.lim && f < nf) {  // :52
-          const uint32_t slot = atomicAdd(&misc[0], 1u);
+          const uint32_t slot = MODE == kBfDense ? atomicAdd(g_total, 1u) : atomicAdd(&misc[0], 1u);
           if (slot < (uint32_t) a.cap) {
             cand[slot] = make_uint2((uint32_t) f | ((uint32_t) m << 16), (uint32_t) d);
           }
           const uint32_t bit = 1u << (d & 31);
           atomicOr(&bm_f[f * a.nw + (d >> 5)], bit);
           atomicOr(&bm_m[m * a.nw + (d >> 5)], bit);
-          atomicAdd(&cnt_f[f], 1u);
-          atomicAdd(&cnt_m[m], 1u);
-          atomicAdd(&hist[d], 1u);
+          if (MODE == kBfDense) {
+            atomicAdd(&g_cnt_f[f], 1u);
+            atomicAdd(&g_cnt_m[m], 1u);
+            atomicAdd(&g_hist[d], 1u);
+          } else {
+            atomicAdd(&cnt_f[f], 1u);
+            atomicAdd(&cnt_m[m], 1u);
+            atomicAdd(&hist[d], 1u);
+          }
         }
       }
+    }
+    if (MODE == kBfDense) {
+      continue;  // the registration launch takes over
     }
     __threadfence_block();
     __syncthreads();
@@ -368,11 +411,20 @@ int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* param
     }
   }
   const int grid = batch->batch < cus ? batch->batch : cus;
+  // few pairs: spread the dense phase of each pair over several workgroups (slices of >= 64 moving rows)
+  a.chunks = 1;
+  if (batch->batch * 2 <= cus && batch->moving_stride >= 256) {
+    int c = cus / batch->batch;
+    const int most = batch->moving_stride / 64;
+    a.chunks = c < most ? c : most;
+  }
   const size_t b_cand = (size_t) grid * a.cap * sizeof(uint2);
   const size_t b_bm   = (size_t) grid * (size_t) (batch->fixed_stride + batch->moving_stride) * a.nw * sizeof(uint32_t);
+  const size_t b_acc  = a.chunks > 1 ? (size_t) batch->batch * (size_t) (batch->fixed_stride + batch->moving_stride + kBfLevels + 8) * sizeof(uint32_t) : 0;
   a.cand     = static_cast<uint2*>(ctx_device_scratch_slot(ctx, 0, b_cand));
   a.by_level = static_cast<uint2*>(ctx_device_scratch_slot(ctx, 1, b_cand));
-  a.bitmaps  = static_cast<uint32_t*>(ctx_device_scratch_slot(ctx, 2, b_bm));
+  a.bitmaps  = static_cast<uint32_t*>(ctx_device_scratch_slot(ctx, 2, b_bm + b_acc));
+  a.g_acc    = a.bitmaps ? a.bitmaps + b_bm / sizeof(uint32_t) : nullptr;
   if (!a.cand || !a.by_level || !a.bitmaps) {
     return ctx_fail(ctx, PRS_ERR_HIP, "prs_bruteforce_match: scratch allocation failed");
   }
@@ -389,23 +441,41 @@ int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* param
   const int kpt = (batch->fixed_stride + kBfThreads - 1) / kBfThreads;
   hipStream_t stream = ctx_stream(ctx);
   hipError_t e       = hipSuccess;
-  auto launch = [&](auto kernel) {
+  auto launch = [&](auto kernel, dim3 g) {
     if (off > 64u * 1024u) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) off);
     }
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBfThreads), off, stream, a);
+      hipLaunchKernelGGL(kernel, g, dim3(kBfThreads), off, stream, a);
       e = hipGetLastError();
     }
   };
-  if (kpt <= 1) {
-    launch(bruteforce_kernel<1>);
-  } else if (kpt <= 2) {
-    launch(bruteforce_kernel<2>);
-  } else if (kpt <= 4) {
-    launch(bruteforce_kernel<4>);
+  auto launch_mode = [&](auto mode, dim3 g) {
+    constexpr int M = decltype(mode)::value;
+    if (kpt <= 1) {
+      launch(bruteforce_kernel<1, M>, g);
+    } else if (kpt <= 2) {
+      launch(bruteforce_kernel<2, M>, g);
+    } else if (kpt <= 4) {
+      launch(bruteforce_kernel<4, M>, g);
+    } else {
+      launch(bruteforce_kernel<8, M>, g);
+    }
+  };
+  if (a.chunks > 1) {
+    const size_t acc_bytes = (size_t) batch->batch * (size_t) (batch->fixed_stride + batch->moving_stride + kBfLevels + 8) * sizeof(uint32_t);
+    e = hipMemsetAsync(a.g_acc, 0, acc_bytes, stream);
+    if (e == hipSuccess) {
+      e = hipMemsetAsync(a.bitmaps, 0, b_bm, stream);
+    }
+    if (e == hipSuccess) {
+      launch_mode(std::integral_constant<int, kBfDense>{}, dim3(a.chunks, batch->batch));
+    }
+    if (e == hipSuccess) {
+      launch_mode(std::integral_constant<int, kBfRegister>{}, dim3(batch->batch));
+    }
   } else {
-    launch(bruteforce_kernel<8>);
+    launch_mode(std::integral_constant<int, kBfFused>{}, dim3(grid));
   }
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_bruteforce_match launch");
