@@ -191,8 +191,6 @@ int prs_context_create(int device_id, prs_context** out) {
   ctx->stream          = ctx->own;
   const char* unstaged = getenv("PRS_FORCE_UNSTAGED");
   ctx->force_unstaged  = unstaged && unstaged[0] == '1';
-  const char* abl      = getenv("PRS_ABLATE");
-  ctx->ablate          = abl ? atoi(abl) : 0;
   const char* v3       = getenv("PRS_MATCHER_V3");
   ctx->matcher_v3      = v3 && v3[0] == '1';
   const char* fused    = getenv("PRS_FUSED_ALIGN");

@@ -14,7 +14,6 @@ struct prs_context {
   hipStream_t own       = nullptr;  // stream created (and destroyed) by the context
   std::string last_error;
   bool fused_align      = false;    // PRS_FUSED_ALIGN=1: one fused kernel per frame loop instead of the split search/GN pipeline
-  int ablate            = 0;        // PRS_ABLATE=<mask>: diagnostic phase skipping (wrong results, timing only)
   bool matcher_v3       = false;    // PRS_MATCHER_V3=1: always use the first-generation matcher kernel
   bool force_unstaged   = false;    // test hook: PRS_FORCE_UNSTAGED=1 selects the no-LDS-staging variant
   // reusable device scratch for the host-pointer entry points
@@ -40,9 +39,6 @@ inline hipStream_t ctx_stream(prs_context* ctx) {
 }
 inline bool ctx_fused_align(const prs_context* ctx) {
   return ctx->fused_align;
-}
-inline int ctx_ablate(const prs_context* ctx) {
-  return ctx->ablate;
 }
 inline bool ctx_matcher_v3(const prs_context* ctx) {
   return ctx->matcher_v3;
