@@ -189,3 +189,40 @@ def rgbd_frame(rng, cfg, n_keypoints=1000, visible_fraction=0.7, flip_p=0.04):
 def perturb(rng, T, sigma_t, sigma_r):
     """initial guess = truth composed with a small error (stand-in for the constant-velocity prediction)"""
     return (make_transform(rng.normal(0, sigma_t, 3), rng.normal(0, sigma_r, 3)) @ T).astype(np.float32)
+
+
+def stereo_images(rng, cfg, n_rectangles=140, max_disparity=90):
+    """a rectified stereo pair of 8-bit images: a blocky random background at disparity 2 and large rectangles with
+    their own 8-px block texture at integer disparities, painted far to near.  Corners inside a surface see the same
+    neighbourhood in both images (their descriptors agree bit for bit); corners at depth discontinuities do not.
+    Returns (left, right, rectangles) with rectangles = [(x, y, w, h, disparity)] in painting order."""
+    cam = cfg["camera"]
+    rows, cols = int(cam["rows"]), int(cam["cols"])
+
+    def blocks(h, w, size):
+        b = rng.integers(20, 236, ((h + size - 1) // size, (w + size - 1) // size)).astype(np.uint8)
+        t = np.kron(b, np.ones((size, size), np.uint8))[:h, :w].copy()
+        # small high-contrast squares: the corner-like structures a FAST detector answers to
+        n_blobs = max(h * w // 220, 1)
+        ys, xs = rng.integers(0, max(h - 4, 1), n_blobs), rng.integers(0, max(w - 4, 1), n_blobs)
+        gs = rng.integers(0, 2, n_blobs) * 255
+        for y, x, g in zip(ys, xs, gs):
+            t[y: y + 4, x: x + 4] = g
+        return t
+
+    world = blocks(rows, cols + 4, 16)
+    left = np.ascontiguousarray(world[:, 2: cols + 2])   # left[x] = world[x + 2]
+    right = np.ascontiguousarray(world[:, 4: cols + 4])  # right[x] = world[x + 4] = left[x + 2]: uL - uR = 2
+    d = np.sort(rng.integers(3, max_disparity, n_rectangles))
+    rects = []
+    for k in range(n_rectangles):
+        w, h = int(rng.integers(60, 220)), int(rng.integers(40, 140))
+        x, y = int(rng.integers(0, cols - w)), int(rng.integers(0, rows - h))
+        tex = blocks(h, w, 8)
+        left[y: y + h, x: x + w] = tex
+        xr = x - int(d[k])
+        x0, x1 = max(xr, 0), min(xr + w, cols)
+        if x1 > x0:
+            right[y: y + h, x0: x1] = tex[:, x0 - xr: x1 - xr]
+        rects.append((x, y, w, h, int(d[k])))
+    return left, right, rects
