@@ -549,6 +549,46 @@ PRS_API int prs_merge_batch_run(prs_context* ctx, const prs_merger_params* param
  * All pointers are device arrays of [batch][16] row-major float; pose_out may alias prediction. */
 PRS_API int prs_pose_compose_batch(prs_context* ctx, int32_t batch, const float* prediction, const float* X, float* pose_out);
 
+/* ================================================================================================
+ * Intensity feature extraction
+ * replaces IntensityFeatureExtractorBinned_::compute (sensor_processing/feature_extractors/
+ * intensity_feature_extractor_binned.cpp:7-208, intensity_feature_extractor_base.cpp:56-95): FAST
+ * keypoints with non-maximum suppression, the detection-region grid with "keep all below the
+ * per-region target, else the best by response" (:47-196, in-repo, restated exactly), then one
+ * 256-bit binary descriptor per keypoint.
+ * The two OpenCV calls of the reference (cv::FastFeatureDetector, cv::ORB / BRIEF) are NOT part of the
+ * reference tree: the detector here is the published FAST-9 segment test on the 16-pixel circle of
+ * radius 3 with the arc-minimum response and strict 8-neighbour non-maximum suppression (outermost
+ * 3 pixels not examined, raster order); the descriptor is BUILD-DEFINED -- 256 comparisons of 5x5 box
+ * sums at point pairs inside a 31x31 patch (fixed table), keypoints closer than 17 px to the border get
+ * none and are dropped.  It is not bit-compatible with cv::ORB; a map must be built and tracked with the
+ * same extractor.  Outputs have the layout of prs_stereo_batch's inputs.
+ * Status per image: PRS_WARN_NO_MATCHES (no keypoints, :126-131), PRS_ERR_CAPACITY (more than 8192
+ * raw detections or more features than `stride`).
+ * ============================================================================================== */
+typedef struct {
+  int32_t detector_threshold;             /* intensity_feature_extractor_base.h:36-40; in [1, 254] */
+  int32_t enable_non_maximum_suppression; /* :48-52 */
+  int32_t target_number_of_keypoints;     /* :54-58 */
+  int32_t number_of_detectors_vertical;   /* intensity_feature_extractor_binned.h:17-22 */
+  int32_t number_of_detectors_horizontal; /* :23-28 */
+} prs_extractor_params;
+
+typedef struct {
+  int32_t batch;
+  int32_t rows, cols;     /* image size */
+  int32_t pitch;          /* bytes between image rows (>= cols) */
+  const uint8_t* images;  /* [batch][rows][pitch] 8-bit intensity */
+  int32_t stride;         /* feature capacity per image = row stride of the outputs */
+  prs_kp2* keypoints;     /* out [batch][stride] (u, v) = (column, row) */
+  float* intensity;       /* out [batch][stride] or NULL */
+  uint8_t* descriptors;   /* out [batch][stride][32] */
+  int32_t* n_features;    /* out [batch] */
+  int32_t* status;        /* out [batch] */
+} prs_extract_batch;
+
+PRS_API int prs_extract_features_batch(prs_context* ctx, const prs_extractor_params* params, const prs_extract_batch* batch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -233,6 +233,20 @@ class MergeBatch(C.Structure):
                 ("frame", C.c_void_p), ("result", C.c_void_p), ("corr_from_aligner", C.c_int32)]
 
 
+class ExtractorParams(C.Structure):
+    """prs_extractor_params"""
+    _fields_ = [("detector_threshold", C.c_int32), ("enable_non_maximum_suppression", C.c_int32),
+                ("target_number_of_keypoints", C.c_int32), ("number_of_detectors_vertical", C.c_int32),
+                ("number_of_detectors_horizontal", C.c_int32)]
+
+
+class ExtractBatch(C.Structure):
+    """prs_extract_batch (device pointers)"""
+    _fields_ = [("batch", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("pitch", C.c_int32), ("images", C.c_void_p),
+                ("stride", C.c_int32), ("keypoints", C.c_void_p), ("intensity", C.c_void_p), ("descriptors", C.c_void_p),
+                ("n_features", C.c_void_p), ("status", C.c_void_p)]
+
+
 MODE_ALIGN, MODE_FINDER, MODE_LINEARIZE = 0, 1, 2
 
 # every symbol include/proslam_hip.h declares: (restype, argtypes)
@@ -268,6 +282,7 @@ SYMBOLS = {
     "prs_triangulate_dev": (C.c_int, [_vp, C.POINTER(TriangulatorParams), _vp, C.c_int64, _vp]),
     "prs_bruteforce_match_batch": (C.c_int, [_vp, C.POINTER(BruteforceParams), C.POINTER(BruteforceBatch)]),
     "prs_bruteforce_match": (C.c_int, [_vp, C.POINTER(BruteforceParams), _vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
+    "prs_extract_features_batch": (C.c_int, [_vp, C.POINTER(ExtractorParams), C.POINTER(ExtractBatch)]),
     "prs_pose_compose_batch": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),
     "prs_merge_batch_run": (C.c_int, [_vp, C.POINTER(MergerParams), C.POINTER(MergeBatch)]),
     "prs_scene_clip_batch": (C.c_int, [_vp, C.POINTER(Projector), _vp, C.POINTER(ClipBatch)]),

@@ -631,4 +631,12 @@ int prs_pose_compose_batch(prs_context* ctx, int32_t batch, const float* predict
   return pose_compose_launch(ctx, batch, prediction, X, pose_out);
 }
 
+int prs_extract_features_batch(prs_context* ctx, const prs_extractor_params* params, const prs_extract_batch* batch) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  (void) hipSetDevice(ctx->device);
+  return extract_features_launch(ctx, params, batch);
+}
+
 }  // extern "C"

@@ -1,0 +1,460 @@
+// features.hip -- intensity feature extraction on the device:
+// IntensityFeatureExtractorBinned_::computeKeypoints + compute
+// (sensor_processing/feature_extractors/intensity_feature_extractor_binned.cpp:7-208,
+//  intensity_feature_extractor_base.cpp:56-95) around the two OpenCV calls the reference makes:
+// FAST detection with non-maximum suppression (:121-123) and a 256-bit binary descriptor (:139-170).
+// OpenCV is not part of the reference tree: the detector is the published FAST-9 segment test with the
+// arc-minimum response, the descriptor is BUILD-DEFINED (BRIEF-style comparisons of 5x5 box sums, pair
+// table from a fixed linear congruential sequence) -- see include/proslam_hip.h.  The region grid and the
+// per-region selection by response follow the in-repo code line by line.
+//
+// Three launches per batch of images:
+//   fast_box_kernel    one 64x16 pixel tile per workgroup (tile + halo in LDS): FAST response map (u8)
+//                      and 5x5 box-sum map (u16); HBM-bound apart from the segment test itself
+//   nms_compact_kernel one workgroup per image: non-maximum suppression + ordered (raster) compaction
+//   select_describe_kernel one workgroup per image: region histogram, one bitonic sort of
+//                      (region, response, order) keys in LDS, per-region selection, border filter,
+//                      256 box-sum comparisons per kept keypoint
+#include "prs_device.h"
+#include "prs_host.h"
+
+namespace prs {
+
+constexpr int kTileW = 64, kTileH = 16, kFastThreads = 256;
+constexpr int kTilePitch = kTileW + 8;  // 3-px halo on both sides, padded
+constexpr int kNmsThreads = 1024, kSelThreads = 1024;
+constexpr int kMaxRaw = 8192;           // raw detections per image the selection sort can hold
+constexpr int kFeatureBorder = 17;      // keypoints closer to the border get no descriptor
+constexpr int kMaxRegions = 256;
+
+struct FeatureArgs {
+  prs_extractor_params p;
+  prs_extract_batch b;
+  uint8_t* score;     // [batch][rows][cols]
+  uint16_t* box;      // [batch][rows][cols] 5x5 sums
+  uint32_t* raw;      // [batch][kMaxRaw] response << 24 | pixel index, raster order
+  int32_t* n_raw;     // [batch]
+  int8_t pattern[1024];
+  float rows_per, cols_per;
+  int target_per, regions;
+};
+
+// FAST-9: does a 16-bit circular mask contain 9 contiguous set bits?
+__device__ __forceinline__ bool has_arc9(uint32_t m) {
+  m |= m << 16;  // unroll the circle
+  uint32_t x = m & (m >> 1);
+  x &= x >> 2;   // runs of 4
+  x &= x >> 4;   // runs of 8
+  x &= m >> 8;   // runs of 9
+  return (x & 0xffffu) != 0u;
+}
+
+__global__ __launch_bounds__(kFastThreads) void fast_box_kernel(const FeatureArgs a) {
+  __shared__ uint8_t tile[(kTileH + 6) * kTilePitch];
+  const int rows = a.b.rows, cols = a.b.cols, pitch = a.b.pitch;
+  const int img  = blockIdx.z;
+  const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+  const uint8_t* __restrict__ src = a.b.images + (size_t) img * rows * pitch;
+  const int tid = threadIdx.x;
+  // tile + 3-px halo, clamped at the image border (clamped pixels never reach an output)
+  for (int i = tid; i < (kTileH + 6) * (kTileW + 6); i += kFastThreads) {
+    const int ty = i / (kTileW + 6), tx = i - ty * (kTileW + 6);
+    int gy = y0 + ty - 3, gx = x0 + tx - 3;
+    gy     = gy < 0 ? 0 : (gy >= rows ? rows - 1 : gy);
+    gx     = gx < 0 ? 0 : (gx >= cols ? cols - 1 : gx);
+    tile[ty * kTilePitch + tx] = src[(size_t) gy * pitch + gx];
+  }
+  __syncthreads();
+  const int t = a.p.detector_threshold;
+  const int lx = tid & 63;
+  uint8_t* __restrict__ score = a.score + (size_t) img * rows * cols;
+  uint16_t* __restrict__ box  = a.box + (size_t) img * rows * cols;
+#pragma unroll
+  for (int k = 0; k < kTileH / 4; ++k) {
+    const int ly = (tid >> 6) + 4 * k;
+    const int gx = x0 + lx, gy = y0 + ly;
+    if (gx >= cols || gy >= rows) {
+      continue;
+    }
+    const uint8_t* c = tile + (ly + 3) * kTilePitch + (lx + 3);
+    // ---- 5x5 box sum -----------------------------------------------------------------------
+    int sum = 0;
+    if (gx >= 2 && gx < cols - 2 && gy >= 2 && gy < rows - 2) {
+#pragma unroll
+      for (int dy = -2; dy <= 2; ++dy) {
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx) {
+          sum += c[dy * kTilePitch + dx];
+        }
+      }
+    }
+    box[(size_t) gy * cols + gx] = (uint16_t) sum;
+    // ---- FAST-9 on the radius-3 circle, clockwise from 12 o'clock ----------------------------
+    int s = 0;
+    if (gx >= 3 && gx < cols - 3 && gy >= 3 && gy < rows - 3) {
+      const int v = c[0];
+      int d[16];
+      d[0]  = c[-3 * kTilePitch + 0];
+      d[1]  = c[-3 * kTilePitch + 1];
+      d[2]  = c[-2 * kTilePitch + 2];
+      d[3]  = c[-1 * kTilePitch + 3];
+      d[4]  = c[3];
+      d[5]  = c[1 * kTilePitch + 3];
+      d[6]  = c[2 * kTilePitch + 2];
+      d[7]  = c[3 * kTilePitch + 1];
+      d[8]  = c[3 * kTilePitch + 0];
+      d[9]  = c[3 * kTilePitch - 1];
+      d[10] = c[2 * kTilePitch - 2];
+      d[11] = c[1 * kTilePitch - 3];
+      d[12] = c[-3];
+      d[13] = c[-1 * kTilePitch - 3];
+      d[14] = c[-2 * kTilePitch - 2];
+      d[15] = c[-3 * kTilePitch - 1];
+      uint32_t brighter = 0, darker = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        d[i] -= v;
+        brighter |= (d[i] > t ? 1u : 0u) << i;
+        darker |= (d[i] < -t ? 1u : 0u) << i;
+      }
+      if (has_arc9(brighter) || has_arc9(darker)) {
+        // response = largest threshold that still detects = (max over arcs of the arc minimum) - 1
+        int best = -256;
+#pragma unroll
+        for (int sign = 0; sign < 2; ++sign) {
+          int e[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            e[i] = sign ? -d[i] : d[i];
+          }
+          int m2[16], m4[16], m8[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            m2[i] = min(e[i], e[(i + 1) & 15]);
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            m4[i] = min(m2[i], m2[(i + 2) & 15]);
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            m8[i] = min(m4[i], m4[(i + 4) & 15]);
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            best = max(best, min(m8[i], e[(i + 8) & 15]));  // minimum over the arc i .. i+8
+          }
+        }
+        s = best > t ? best - 1 : 0;
+      }
+    }
+    score[(size_t) gy * cols + gx] = (uint8_t) s;
+  }
+}
+
+// non-maximum suppression (strictly greater than the 8 neighbours) + raster-order compaction
+__global__ __launch_bounds__(kNmsThreads) void nms_compact_kernel(const FeatureArgs a) {
+  __shared__ int wave_tot[kNmsThreads / 64];
+  const int rows = a.b.rows, cols = a.b.cols;
+  const int img  = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint8_t* __restrict__ score = a.score + (size_t) img * rows * cols;
+  uint32_t* __restrict__ raw        = a.raw + (size_t) img * kMaxRaw;
+  const int n_pix = rows * cols;
+  int running     = 0;
+  bool overflow   = false;
+  for (int base = 0; base < n_pix; base += 4 * kNmsThreads) {
+    const int i0 = base + 4 * tid;
+    uint32_t found[4] = {0u, 0u, 0u, 0u};
+    int cnt           = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = i0 + j;
+      if (i < n_pix) {
+        const int s = score[i];
+        if (s) {
+          bool keep = true;
+          if (a.p.enable_non_maximum_suppression) {
+            // responses are zero on the outermost 3 pixels, so a non-zero response has all 8 neighbours inside
+            const uint8_t* q = score + i;
+            keep = q[-cols - 1] < s && q[-cols] < s && q[-cols + 1] < s && q[-1] < s && q[1] < s && q[cols - 1] < s && q[cols] < s &&
+                   q[cols + 1] < s;
+          }
+          if (keep) {
+            const uint32_t rec = ((uint32_t) s << 24) | (uint32_t) i;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // static register indexing
+              if (q == cnt) {
+                found[q] = rec;
+              }
+            }
+            ++cnt;
+          }
+        }
+      }
+    }
+    // exclusive prefix of the per-thread counts: thread order = raster order
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) {
+        incl += v;
+      }
+    }
+    if (lane == 63) {
+      wave_tot[wave] = incl;
+    }
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kNmsThreads / 64; ++w) {
+      before += w < wave ? wave_tot[w] : 0;
+      total += wave_tot[w];
+    }
+    const int slot = running + before + incl - cnt;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < cnt && slot + j < kMaxRaw) {
+        raw[slot + j] = found[j];
+      }
+    }
+    running += total;
+    overflow = overflow || running > kMaxRaw;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    a.n_raw[img] = overflow ? -1 : running;
+  }
+}
+
+__global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const FeatureArgs a) {
+  __shared__ uint32_t keys[kMaxRaw];
+  __shared__ uint32_t count[kMaxRegions + 1];
+  __shared__ uint32_t start[kMaxRegions + 1];
+  __shared__ int8_t pattern[1024];
+  __shared__ int wave_tot[kSelThreads / 64];
+  const int rows = a.b.rows, cols = a.b.cols;
+  const int img  = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t* __restrict__ raw = a.raw + (size_t) img * kMaxRaw;
+  const uint16_t* __restrict__ box = a.box + (size_t) img * rows * cols;
+  const uint8_t* __restrict__ src  = a.b.images + (size_t) img * rows * a.b.pitch;
+  const int n = a.n_raw[img];
+  if (n < 0) {  // more raw detections than the selection can hold: loud per-image error
+    if (tid == 0) {
+      a.b.n_features[img] = 0;
+      a.b.status[img]     = PRS_ERR_CAPACITY;
+    }
+    return;
+  }
+  for (int i = tid; i < 1024; i += kSelThreads) {
+    pattern[i] = a.pattern[i];
+  }
+  for (int i = tid; i <= a.regions; i += kSelThreads) {
+    count[i] = 0;
+  }
+  __syncthreads();
+  // ---- region of every keypoint (intensity_feature_extractor_binned.cpp:85-92) + region sizes ------------
+  uint32_t my_region[kMaxRaw / kSelThreads];
+#pragma unroll
+  for (int k = 0; k < kMaxRaw / kSelThreads; ++k) {
+    const int i  = k * kSelThreads + tid;
+    my_region[k] = 0;
+    if (i < n) {
+      const uint32_t pix = raw[i] & 0xffffffu;
+      const int r = (int) (pix / (uint32_t) cols), c = (int) (pix - (uint32_t) r * (uint32_t) cols);
+      const int region = (int) floorf((float) r / a.rows_per) * a.p.number_of_detectors_horizontal + (int) ((float) c / a.cols_per);
+      my_region[k]     = (uint32_t) (region < a.regions ? region : a.regions - 1);
+      atomicAdd(&count[my_region[k]], 1u);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (int g = 0; g < a.regions; ++g) {
+      start[g] = run;
+      run += count[g];
+    }
+    start[a.regions] = run;
+  }
+  // ---- keys: (region, sort field, detection order); a region below its target keeps detection order (:174-178),
+  //      the others are ordered by decreasing response (:179-195), ties by detection order
+#pragma unroll
+  for (int k = 0; k < kMaxRaw / kSelThreads; ++k) {
+    const int i = k * kSelThreads + tid;
+    uint32_t key = 0xffffffffu;
+    if (i < n) {
+      const uint32_t s     = raw[i] >> 24;
+      const uint32_t field = count[my_region[k]] < (uint32_t) a.target_per ? 0u : 255u - s;
+      key                  = (my_region[k] << 21) | (field << 13) | (uint32_t) i;
+    }
+    keys[i] = key;
+  }
+  __syncthreads();
+  // ---- bitonic sort of the 8192 keys in LDS -------------------------------------------------------------------
+  int n_sort = 1024;
+  while (n_sort < n) {
+    n_sort <<= 1;
+  }
+  for (int size = 2; size <= n_sort; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (n_sort >> 1); t += kSelThreads) {
+        const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const uint32_t x = keys[lo], y = keys[hi];
+        if ((x > y) == up) {
+          keys[lo] = y;
+          keys[hi] = x;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- selection + border filter + ordered output, 1024 sorted positions at a time ----------------------------
+  prs_kp2* __restrict__ out_kp   = a.b.keypoints + (size_t) img * a.b.stride;
+  float* __restrict__ out_int    = a.b.intensity ? a.b.intensity + (size_t) img * a.b.stride : nullptr;
+  uint8_t* __restrict__ out_desc = a.b.descriptors + (size_t) img * a.b.stride * PRS_DESC_BYTES;
+  int running   = 0;
+  bool overflow = false;
+  for (int p0 = 0; p0 < n; p0 += kSelThreads) {
+    const int p = p0 + tid;
+    bool keep   = false;
+    int r = 0, c = 0;
+    if (p < n) {
+      const uint32_t key    = keys[p];
+      const uint32_t region = key >> 21;
+      const uint32_t rank   = (uint32_t) p - start[region];
+      const uint32_t pix    = raw[key & 0x1fffu] & 0xffffffu;
+      r                     = (int) (pix / (uint32_t) cols);
+      c                     = (int) (pix - (uint32_t) r * (uint32_t) cols);
+      keep = (count[region] < (uint32_t) a.target_per || rank < (uint32_t) a.target_per) && r >= kFeatureBorder &&
+             r < rows - kFeatureBorder && c >= kFeatureBorder && c < cols - kFeatureBorder;
+    }
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) {
+      wave_tot[wave] = __popcll(bal);
+    }
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kSelThreads / 64; ++w) {
+      before += w < wave ? wave_tot[w] : 0;
+      total += wave_tot[w];
+    }
+    if (keep) {
+      const int slot = running + before + __popcll(bal & ((1ull << lane) - 1ull));
+      if (slot < a.b.stride) {
+        // 256 comparisons of 5x5 box sums at the pair table's offsets; bit t lands in byte t / 8, bit t % 8
+        uint32_t w32[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          uint32_t bits = 0;
+          for (int t = 0; t < 32; ++t) {
+            const int8_t* pp = pattern + 4 * (32 * w + t);
+            const uint32_t s1 = box[(size_t) (r + pp[1]) * cols + (c + pp[0])];
+            const uint32_t s2 = box[(size_t) (r + pp[3]) * cols + (c + pp[2])];
+            bits |= (s1 < s2 ? 1u : 0u) << t;
+          }
+          w32[w] = bits;
+        }
+        uint32_t* d = reinterpret_cast<uint32_t*>(out_desc + (size_t) slot * PRS_DESC_BYTES);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          d[w] = w32[w];
+        }
+        out_kp[slot] = prs_kp2{(float) c, (float) r};
+        if (out_int) {
+          out_int[slot] = (float) src[(size_t) r * a.b.pitch + c];  // intensity_feature_extractor_base.cpp:80
+        }
+      } else {
+        overflow = true;
+      }
+    }
+    running += total;
+    __syncthreads();
+  }
+  if (__syncthreads_or(overflow ? 1 : 0)) {
+    if (tid == 0) {
+      a.b.n_features[img] = 0;
+      a.b.status[img]     = PRS_ERR_CAPACITY;
+    }
+    return;
+  }
+  if (tid == 0) {
+    a.b.n_features[img] = running;
+    a.b.status[img]     = running == 0 ? PRS_WARN_NO_MATCHES : PRS_OK;  // :126-131 "no keypoints detected"
+  }
+}
+
+// 256 point pairs (x1, y1, x2, y2) in [-13, 13]: fixed linear congruential sequence, roughly bell shaped
+void fill_brief_pattern(int8_t* pattern) {
+  uint32_t x = 0x12345678u;
+  int n      = 0;
+  while (n < 256) {
+    int v[4];
+    for (int k = 0; k < 4; ++k) {
+      x    = x * 1664525u + 1013904223u;
+      v[k] = (int) ((x >> 8) % 9u) - 4 + (int) ((x >> 16) % 9u) - 4 + (int) ((x >> 24) % 11u) - 5;
+    }
+    if (v[0] == v[2] && v[1] == v[3]) {
+      continue;
+    }
+    for (int k = 0; k < 4; ++k) {
+      pattern[4 * n + k] = (int8_t) v[k];
+    }
+    ++n;
+  }
+}
+
+int extract_features_launch(prs_context* ctx, const prs_extractor_params* params, const prs_extract_batch* batch) {
+  if (!params || !batch || !batch->images) {
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_extract_features_batch: image not set");
+  }
+  if (!batch->keypoints || !batch->descriptors || !batch->n_features || !batch->status) {
+    // intensity_feature_extractor_base.cpp:59-64: "target feature buffer not set"
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_extract_features_batch: target feature buffer not set");
+  }
+  if (batch->batch <= 0) {
+    return PRS_OK;
+  }
+  const int regions = params->number_of_detectors_vertical * params->number_of_detectors_horizontal;
+  if (params->number_of_detectors_vertical <= 0 || params->number_of_detectors_horizontal <= 0) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_extract_features_batch: invalid number of detectors");  // binned.cpp:13-20
+  }
+  if (batch->rows < 7 || batch->cols < 7 || batch->pitch < batch->cols || (size_t) batch->rows * batch->cols >= (1u << 24) ||
+      regions > kMaxRegions || params->detector_threshold < 1 || params->detector_threshold > 254 || batch->stride <= 0) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED,
+                    "prs_extract_features_batch: image below 7x7 or above 2^24 pixels, more than 256 regions, or threshold outside [1,254]");
+  }
+  FeatureArgs a;
+  a.p = *params;
+  a.b = *batch;
+  const size_t npix = (size_t) batch->rows * batch->cols;
+  a.score = static_cast<uint8_t*>(ctx_device_scratch_slot(ctx, 0, (size_t) batch->batch * npix));
+  a.box   = static_cast<uint16_t*>(ctx_device_scratch_slot(ctx, 1, (size_t) batch->batch * npix * 2));
+  uint32_t* rawbuf = static_cast<uint32_t*>(ctx_device_scratch_slot(ctx, 2, (size_t) batch->batch * (kMaxRaw + 1) * 4));
+  if (!a.score || !a.box || !rawbuf) {
+    return ctx_fail(ctx, PRS_ERR_HIP, "prs_extract_features_batch: scratch allocation failed");
+  }
+  a.raw   = rawbuf;
+  a.n_raw = reinterpret_cast<int32_t*>(rawbuf + (size_t) batch->batch * kMaxRaw);
+  fill_brief_pattern(a.pattern);
+  a.rows_per   = (float) batch->rows / (float) params->number_of_detectors_vertical;   // binned.cpp:52-55
+  a.cols_per   = (float) batch->cols / (float) params->number_of_detectors_horizontal;
+  a.regions    = regions;
+  a.target_per = (int) ((float) params->target_number_of_keypoints / (float) regions);  // :72-76
+  hipStream_t stream = ctx_stream(ctx);
+  const dim3 tiles((batch->cols + kTileW - 1) / kTileW, (batch->rows + kTileH - 1) / kTileH, batch->batch);
+  hipLaunchKernelGGL(fast_box_kernel, tiles, dim3(kFastThreads), 0, stream, a);
+  hipLaunchKernelGGL(nms_compact_kernel, dim3(batch->batch), dim3(kNmsThreads), 0, stream, a);
+  hipLaunchKernelGGL(select_describe_kernel, dim3(batch->batch), dim3(kSelThreads), 0, stream, a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_extract_features_batch launch");
+  }
+  return PRS_OK;
+}
+
+}  // namespace prs

@@ -66,6 +66,7 @@ int stereo_match_batch_launch(prs_context* ctx, const prs_stereo_params* params,
 int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs_aligner_params* aligner, const prs_align_batch* batch, int mode);
 int gn_step_launch(prs_context* ctx, const float* dH, const float* db, float damping, float* dX, int* dok);
 int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* params, const prs_bruteforce_batch* batch);
+int extract_features_launch(prs_context* ctx, const prs_extractor_params* params, const prs_extract_batch* batch);
 int pose_compose_launch(prs_context* ctx, int batch, const float* prediction, const float* X, float* pose_out);
 int merge_batch_launch(prs_context* ctx, const prs_merger_params* params, const prs_merge_batch* batch);
 int scene_clip_launch(prs_context* ctx, const prs_projector* projector, const float* sensor_in_robot, const prs_clip_batch* batch);

@@ -656,3 +656,24 @@ def pose_compose_batch(ctx, prediction, X, pose_out):
     rc = _lib.load().prs_pose_compose_batch(ctx._h, batch, prediction.data_ptr(), X.data_ptr(), pose_out.data_ptr())
     _check(ctx, rc, "prs_pose_compose_batch")
     return rc
+
+
+# ---- intensity feature extraction (sensor_processing/feature_extractors) ----
+def extractor_params(threshold=15, nms=1, target=1000, vertical=3, horizontal=3):
+    """defaults of configurations/kitti.conf:229-255"""
+    return _lib.ExtractorParams(threshold, nms, target, vertical, horizontal)
+
+
+def extract_features_batch(ctx, params, images, keypoints, descriptors, n_features, status, intensity=None):
+    """images: uint8 device tensor [B, rows, cols(pitch)]; outputs are device tensors laid out like the stereo
+    matcher's inputs (keypoints [B, stride, 2] f32, descriptors [B, stride, 32] u8, n_features [B] i32)."""
+    d = _lib.ExtractBatch()
+    d.batch, d.rows, d.cols, d.pitch = int(images.shape[0]), int(images.shape[1]), int(images.shape[2]), int(images.stride(1))
+    d.images = images.data_ptr()
+    d.stride = int(keypoints.shape[1])
+    d.keypoints, d.descriptors = keypoints.data_ptr(), descriptors.data_ptr()
+    d.intensity = intensity.data_ptr() if intensity is not None else None
+    d.n_features, d.status = n_features.data_ptr(), status.data_ptr()
+    rc = _lib.load().prs_extract_features_batch(ctx._h, C.byref(params), C.byref(d))
+    _check(ctx, rc, "prs_extract_features_batch")
+    return rc
