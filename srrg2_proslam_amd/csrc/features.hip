@@ -21,7 +21,7 @@
 namespace prs {
 
 constexpr int kTileW = 64, kTileH = 16, kFastThreads = 256;
-constexpr int kTilePitch = kTileW + 8;  // 3-px halo on both sides, padded
+constexpr int kTilePitch = kTileW + 8;  // 4-px halo on both sides
 constexpr int kNmsThreads = 1024, kSelThreads = 1024;
 constexpr int kMaxRaw = 8192;           // raw detections per image the selection sort can hold
 constexpr int kFeatureBorder = 17;      // keypoints closer to the border get no descriptor
@@ -49,23 +49,110 @@ __device__ __forceinline__ bool has_arc9(uint32_t m) {
   return (x & 0xffffu) != 0u;
 }
 
+// FAST-9 response of the pixel at `c` (LDS tile pointer, row pitch kTilePitch): largest threshold that still
+// detects, 0 = no corner at threshold t
+__device__ __forceinline__ int fast_response(const uint8_t* c, int t) {
+  const int v = c[0];
+  int d[16];
+  d[0]  = c[-3 * kTilePitch + 0];
+  d[1]  = c[-3 * kTilePitch + 1];
+  d[2]  = c[-2 * kTilePitch + 2];
+  d[3]  = c[-1 * kTilePitch + 3];
+  d[4]  = c[3];
+  d[5]  = c[1 * kTilePitch + 3];
+  d[6]  = c[2 * kTilePitch + 2];
+  d[7]  = c[3 * kTilePitch + 1];
+  d[8]  = c[3 * kTilePitch + 0];
+  d[9]  = c[3 * kTilePitch - 1];
+  d[10] = c[2 * kTilePitch - 2];
+  d[11] = c[1 * kTilePitch - 3];
+  d[12] = c[-3];
+  d[13] = c[-1 * kTilePitch - 3];
+  d[14] = c[-2 * kTilePitch - 2];
+  d[15] = c[-3 * kTilePitch - 1];
+  uint32_t brighter = 0, darker = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    d[i] -= v;
+    brighter |= (d[i] > t ? 1u : 0u) << i;
+    darker |= (d[i] < -t ? 1u : 0u) << i;
+  }
+  const bool cb = has_arc9(brighter), cd = has_arc9(darker);
+  if (!cb && !cd) {
+    return 0;
+  }
+  // response = (max over arcs of the arc minimum of |difference|) - 1.  An arc can only be all brighter or
+  // all darker than the centre; when just one polarity fires the other cannot hold the maximum above t
+  int best = -256;
+#pragma unroll
+  for (int sign = 0; sign < 2; ++sign) {
+    if (sign == 0 ? !cb : !cd) {
+      continue;
+    }
+    int e[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      e[i] = sign ? -d[i] : d[i];
+    }
+    int m2[16], m4[16], m8[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      m2[i] = min(e[i], e[(i + 1) & 15]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      m4[i] = min(m2[i], m2[(i + 2) & 15]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      m8[i] = min(m4[i], m4[(i + 4) & 15]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      best = max(best, min(m8[i], e[(i + 8) & 15]));  // minimum over the arc i .. i+8
+    }
+  }
+  return best > t ? best - 1 : 0;
+}
+
+// image tile (+ 4-px halo) -> responses of the tile + 1-px ring -> non-maximum suppression in LDS -> the response
+// map holds a non-zero value only at surviving keypoints; 5x5 box sums of the tile on the side
 __global__ __launch_bounds__(kFastThreads) void fast_box_kernel(const FeatureArgs a) {
-  __shared__ uint8_t tile[(kTileH + 6) * kTilePitch];
+  constexpr int kHalo = 4;
+  constexpr int kSW = kTileW + 2, kSH = kTileH + 2;  // response tile with its 1-px ring
+  __shared__ uint8_t tile[(kTileH + 2 * kHalo) * kTilePitch];
+  __shared__ uint8_t resp[kSH * kSW];
+  __shared__ uint16_t hsum[(kTileH + 4) * kTileW];  // horizontal 5-sums of the tile rows -2 .. kTileH+1
   const int rows = a.b.rows, cols = a.b.cols, pitch = a.b.pitch;
   const int img  = blockIdx.z;
   const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
   const uint8_t* __restrict__ src = a.b.images + (size_t) img * rows * pitch;
   const int tid = threadIdx.x;
-  // tile + 3-px halo, clamped at the image border (clamped pixels never reach an output)
-  for (int i = tid; i < (kTileH + 6) * (kTileW + 6); i += kFastThreads) {
-    const int ty = i / (kTileW + 6), tx = i - ty * (kTileW + 6);
-    int gy = y0 + ty - 3, gx = x0 + tx - 3;
+  // tile + halo, clamped at the image border (clamped pixels never reach an output)
+  for (int i = tid; i < (kTileH + 2 * kHalo) * (kTileW + 2 * kHalo); i += kFastThreads) {
+    const int ty = i / (kTileW + 2 * kHalo), tx = i - ty * (kTileW + 2 * kHalo);
+    int gy = y0 + ty - kHalo, gx = x0 + tx - kHalo;
     gy     = gy < 0 ? 0 : (gy >= rows ? rows - 1 : gy);
     gx     = gx < 0 ? 0 : (gx >= cols ? cols - 1 : gx);
     tile[ty * kTilePitch + tx] = src[(size_t) gy * pitch + gx];
   }
   __syncthreads();
   const int t = a.p.detector_threshold;
+  for (int i = tid; i < kSH * kSW; i += kFastThreads) {
+    const int sy = i / kSW, sx = i - sy * kSW;
+    const int gx = x0 + sx - 1, gy = y0 + sy - 1;
+    int s = 0;
+    if (gx >= 3 && gx < cols - 3 && gy >= 3 && gy < rows - 3) {  // the outermost 3 pixels are not examined
+      s = fast_response(tile + (sy - 1 + kHalo) * kTilePitch + (sx - 1 + kHalo), t);
+    }
+    resp[i] = (uint8_t) s;
+  }
+  for (int i = tid; i < (kTileH + 4) * kTileW; i += kFastThreads) {  // separable 5x5 box sum, horizontal pass
+    const int hy = i >> 6, hx = i & 63;
+    const uint8_t* c = tile + (hy - 2 + kHalo) * kTilePitch + (hx + kHalo);
+    hsum[i]          = (uint16_t) (((int) c[-2] + (int) c[-1]) + ((int) c[0] + (int) c[1]) + (int) c[2]);
+  }
+  __syncthreads();
   const int lx = tid & 63;
   uint8_t* __restrict__ score = a.score + (size_t) img * rows * cols;
   uint16_t* __restrict__ box  = a.box + (size_t) img * rows * cols;
@@ -76,83 +163,32 @@ __global__ __launch_bounds__(kFastThreads) void fast_box_kernel(const FeatureArg
     if (gx >= cols || gy >= rows) {
       continue;
     }
-    const uint8_t* c = tile + (ly + 3) * kTilePitch + (lx + 3);
-    // ---- 5x5 box sum -----------------------------------------------------------------------
     int sum = 0;
     if (gx >= 2 && gx < cols - 2 && gy >= 2 && gy < rows - 2) {
-#pragma unroll
-      for (int dy = -2; dy <= 2; ++dy) {
-#pragma unroll
-        for (int dx = -2; dx <= 2; ++dx) {
-          sum += c[dy * kTilePitch + dx];
-        }
-      }
+      const uint16_t* h = hsum + (ly + 2) * kTileW + lx;  // vertical pass (integer sums: any order gives the same value)
+      sum = ((int) h[-2 * kTileW] + (int) h[-kTileW]) + ((int) h[0] + (int) h[kTileW]) + (int) h[2 * kTileW];
     }
     box[(size_t) gy * cols + gx] = (uint16_t) sum;
-    // ---- FAST-9 on the radius-3 circle, clockwise from 12 o'clock ----------------------------
-    int s = 0;
-    if (gx >= 3 && gx < cols - 3 && gy >= 3 && gy < rows - 3) {
-      const int v = c[0];
-      int d[16];
-      d[0]  = c[-3 * kTilePitch + 0];
-      d[1]  = c[-3 * kTilePitch + 1];
-      d[2]  = c[-2 * kTilePitch + 2];
-      d[3]  = c[-1 * kTilePitch + 3];
-      d[4]  = c[3];
-      d[5]  = c[1 * kTilePitch + 3];
-      d[6]  = c[2 * kTilePitch + 2];
-      d[7]  = c[3 * kTilePitch + 1];
-      d[8]  = c[3 * kTilePitch + 0];
-      d[9]  = c[3 * kTilePitch - 1];
-      d[10] = c[2 * kTilePitch - 2];
-      d[11] = c[1 * kTilePitch - 3];
-      d[12] = c[-3];
-      d[13] = c[-1 * kTilePitch - 3];
-      d[14] = c[-2 * kTilePitch - 2];
-      d[15] = c[-3 * kTilePitch - 1];
-      uint32_t brighter = 0, darker = 0;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        d[i] -= v;
-        brighter |= (d[i] > t ? 1u : 0u) << i;
-        darker |= (d[i] < -t ? 1u : 0u) << i;
-      }
-      if (has_arc9(brighter) || has_arc9(darker)) {
-        // response = largest threshold that still detects = (max over arcs of the arc minimum) - 1
-        int best = -256;
-#pragma unroll
-        for (int sign = 0; sign < 2; ++sign) {
-          int e[16];
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            e[i] = sign ? -d[i] : d[i];
-          }
-          int m2[16], m4[16], m8[16];
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            m2[i] = min(e[i], e[(i + 1) & 15]);
-          }
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            m4[i] = min(m2[i], m2[(i + 2) & 15]);
-          }
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            m8[i] = min(m4[i], m4[(i + 4) & 15]);
-          }
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            best = max(best, min(m8[i], e[(i + 8) & 15]));  // minimum over the arc i .. i+8
-          }
-        }
-        s = best > t ? best - 1 : 0;
-      }
+    const uint8_t* q = resp + (ly + 1) * kSW + (lx + 1);
+    int s            = q[0];
+    if (s && a.p.enable_non_maximum_suppression) {
+      // strictly greater than the 8 neighbours; a non-zero response never sits on the outermost 3 pixels, so the
+      // ring values are real responses of real pixels
+      const bool keep = q[-kSW - 1] < s && q[-kSW] < s && q[-kSW + 1] < s && q[-1] < s && q[1] < s && q[kSW - 1] < s && q[kSW] < s && q[kSW + 1] < s;
+      s               = keep ? s : 0;
     }
     score[(size_t) gy * cols + gx] = (uint8_t) s;
   }
 }
 
-// non-maximum suppression (strictly greater than the 8 neighbours) + raster-order compaction
+// raster-order compaction of the (already suppressed) response map.
+// Every wave owns a contiguous range of the image; it counts its survivors, the 16 counts are scanned once,
+// then the wave rescans its range (response map still in L2) and writes at its offset: two barriers per image.
+__device__ __forceinline__ uint32_t nms_mask4(const FeatureArgs&, const uint8_t* __restrict__, int, int, uint32_t word) {
+  // the response map is already suppressed: survivors are its non-zero bytes
+  return ((word & 0xffu) ? 1u : 0u) | ((word & 0xff00u) ? 2u : 0u) | ((word & 0xff0000u) ? 4u : 0u) | ((word & 0xff000000u) ? 8u : 0u);
+}
+
 __global__ __launch_bounds__(kNmsThreads) void nms_compact_kernel(const FeatureArgs a) {
   __shared__ int wave_tot[kNmsThreads / 64];
   const int rows = a.b.rows, cols = a.b.cols;
@@ -161,70 +197,88 @@ __global__ __launch_bounds__(kNmsThreads) void nms_compact_kernel(const FeatureA
   const uint8_t* __restrict__ score = a.score + (size_t) img * rows * cols;
   uint32_t* __restrict__ raw        = a.raw + (size_t) img * kMaxRaw;
   const int n_pix = rows * cols;
-  int running     = 0;
-  bool overflow   = false;
-  for (int base = 0; base < n_pix; base += 4 * kNmsThreads) {
-    const int i0 = base + 4 * tid;
-    uint32_t found[4] = {0u, 0u, 0u, 0u};
-    int cnt           = 0;
-#pragma unroll
+  // ranges in units of 256 pixels (64 lanes x 4), so that every lane reads one aligned 32-bit word per step
+  const int n_chunks = (n_pix + 255) / 256;
+  const int per_wave = (n_chunks + kNmsThreads / 64 - 1) / (kNmsThreads / 64);
+  const int c_begin = wave * per_wave, c_end = min(c_begin + per_wave, n_chunks);
+  const bool aligned = (((size_t) score) & 3) == 0;
+  auto load4 = [&](int i) -> uint32_t {
+    if (aligned && i + 3 < n_pix) {
+      return *reinterpret_cast<const uint32_t*>(score + i);
+    }
+    uint32_t w = 0;
     for (int j = 0; j < 4; ++j) {
-      const int i = i0 + j;
-      if (i < n_pix) {
-        const int s = score[i];
-        if (s) {
-          bool keep = true;
-          if (a.p.enable_non_maximum_suppression) {
-            // responses are zero on the outermost 3 pixels, so a non-zero response has all 8 neighbours inside
-            const uint8_t* q = score + i;
-            keep = q[-cols - 1] < s && q[-cols] < s && q[-cols + 1] < s && q[-1] < s && q[1] < s && q[cols - 1] < s && q[cols] < s &&
-                   q[cols + 1] < s;
-          }
-          if (keep) {
-            const uint32_t rec = ((uint32_t) s << 24) | (uint32_t) i;
+      w |= (i + j < n_pix ? (uint32_t) score[i + j] : 0u) << (8 * j);
+    }
+    return w;
+  };
+  int mine = 0;
+  for (int ch = c_begin; ch < c_end; ch += 8) {  // eight independent loads in flight per lane
+    uint32_t word[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {  // static register indexing
-              if (q == cnt) {
-                found[q] = rec;
-              }
-            }
-            ++cnt;
+    for (int u = 0; u < 8; ++u) {
+      const int i = (ch + u) * 256 + 4 * lane;
+      word[u]     = (ch + u < c_end && i < n_pix) ? load4(i) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (word[u]) {
+        mine += __popc(nms_mask4(a, score, cols, (ch + u) * 256 + 4 * lane, word[u]));
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mine += __shfl_xor(mine, o, 64);
+  }
+  if (lane == 0) {
+    wave_tot[wave] = mine;
+  }
+  __syncthreads();
+  int offset = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kNmsThreads / 64; ++w) {
+    offset += w < wave ? wave_tot[w] : 0;
+    total += wave_tot[w];
+  }
+  if (total <= kMaxRaw) {
+    for (int ch0 = c_begin; ch0 < c_end; ch0 += 8) {
+      uint32_t words[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = (ch0 + u) * 256 + 4 * lane;
+        words[u]    = (ch0 + u < c_end && i < n_pix) ? load4(i) : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i         = (ch0 + u) * 256 + 4 * lane;
+        const uint32_t word = words[u];
+        const uint32_t keep = word ? nms_mask4(a, score, cols, i, word) : 0u;
+        if (__ballot(keep != 0u) == 0ull) {
+          continue;  // nothing in these 256 pixels (wave-uniform)
+        }
+        const int cnt = __popc(keep);
+        int incl      = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int v = __shfl_up(incl, o, 64);
+          if (lane >= o) {
+            incl += v;
           }
         }
+        int slot = offset + incl - cnt;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if ((keep >> j) & 1u) {
+            raw[slot++] = (((word >> (8 * j)) & 0xffu) << 24) | (uint32_t) (i + j);
+          }
+        }
+        offset += __shfl(incl, 63, 64);
       }
     }
-    // exclusive prefix of the per-thread counts: thread order = raster order
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(incl, o, 64);
-      if (lane >= o) {
-        incl += v;
-      }
-    }
-    if (lane == 63) {
-      wave_tot[wave] = incl;
-    }
-    __syncthreads();
-    int before = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < kNmsThreads / 64; ++w) {
-      before += w < wave ? wave_tot[w] : 0;
-      total += wave_tot[w];
-    }
-    const int slot = running + before + incl - cnt;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (j < cnt && slot + j < kMaxRaw) {
-        raw[slot + j] = found[j];
-      }
-    }
-    running += total;
-    overflow = overflow || running > kMaxRaw;
-    __syncthreads();
   }
   if (tid == 0) {
-    a.n_raw[img] = overflow ? -1 : running;
+    a.n_raw[img] = total > kMaxRaw ? -1 : total;
   }
 }
 
@@ -312,7 +366,7 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const Feat
       __syncthreads();
     }
   }
-  // ---- selection + border filter + ordered output, 1024 sorted positions at a time ----------------------------
+  // ---- selection + border filter + ordered output slots, 1024 sorted positions at a time ------------------------
   prs_kp2* __restrict__ out_kp   = a.b.keypoints + (size_t) img * a.b.stride;
   float* __restrict__ out_int    = a.b.intensity ? a.b.intensity + (size_t) img * a.b.stride : nullptr;
   uint8_t* __restrict__ out_desc = a.b.descriptors + (size_t) img * a.b.stride * PRS_DESC_BYTES;
@@ -321,14 +375,14 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const Feat
   for (int p0 = 0; p0 < n; p0 += kSelThreads) {
     const int p = p0 + tid;
     bool keep   = false;
-    int r = 0, c = 0;
+    uint32_t pix = 0;
     if (p < n) {
       const uint32_t key    = keys[p];
       const uint32_t region = key >> 21;
       const uint32_t rank   = (uint32_t) p - start[region];
-      const uint32_t pix    = raw[key & 0x1fffu] & 0xffffffu;
-      r                     = (int) (pix / (uint32_t) cols);
-      c                     = (int) (pix - (uint32_t) r * (uint32_t) cols);
+      pix                   = raw[key & 0x1fffu] & 0xffffffu;
+      const int r           = (int) (pix / (uint32_t) cols);
+      const int c           = (int) (pix - (uint32_t) r * (uint32_t) cols);
       keep = (count[region] < (uint32_t) a.target_per || rank < (uint32_t) a.target_per) && r >= kFeatureBorder &&
              r < rows - kFeatureBorder && c >= kFeatureBorder && c < cols - kFeatureBorder;
     }
@@ -343,37 +397,41 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const Feat
       before += w < wave ? wave_tot[w] : 0;
       total += wave_tot[w];
     }
+    __syncthreads();  // keys[p0 ..] have been read: the front of the array is reused for the kept list
     if (keep) {
       const int slot = running + before + __popcll(bal & ((1ull << lane) - 1ull));
       if (slot < a.b.stride) {
-        // 256 comparisons of 5x5 box sums at the pair table's offsets; bit t lands in byte t / 8, bit t % 8
-        uint32_t w32[8];
-#pragma unroll
-        for (int w = 0; w < 8; ++w) {
-          uint32_t bits = 0;
-          for (int t = 0; t < 32; ++t) {
-            const int8_t* pp = pattern + 4 * (32 * w + t);
-            const uint32_t s1 = box[(size_t) (r + pp[1]) * cols + (c + pp[0])];
-            const uint32_t s2 = box[(size_t) (r + pp[3]) * cols + (c + pp[2])];
-            bits |= (s1 < s2 ? 1u : 0u) << t;
-          }
-          w32[w] = bits;
-        }
-        uint32_t* d = reinterpret_cast<uint32_t*>(out_desc + (size_t) slot * PRS_DESC_BYTES);
-#pragma unroll
-        for (int w = 0; w < 8; ++w) {
-          d[w] = w32[w];
-        }
-        out_kp[slot] = prs_kp2{(float) c, (float) r};
-        if (out_int) {
-          out_int[slot] = (float) src[(size_t) r * a.b.pitch + c];  // intensity_feature_extractor_base.cpp:80
-        }
+        keys[slot] = pix;  // slot <= p: never overtakes the sorted positions still to be read
       } else {
         overflow = true;
       }
     }
     running += total;
     __syncthreads();
+  }
+  const int n_kept = running < a.b.stride ? running : a.b.stride;
+  // ---- descriptors: eight lanes per keypoint, one 32-bit word (32 comparisons of 5x5 box sums) each;
+  //      bit t of the descriptor lands in byte t / 8, bit t % 8
+  for (int job = tid; job < n_kept * 8; job += kSelThreads) {
+    const int slot = job >> 3, w = job & 7;
+    const uint32_t pix = keys[slot];
+    const int r = (int) (pix / (uint32_t) cols), c = (int) (pix - (uint32_t) r * (uint32_t) cols);
+    const uint16_t* __restrict__ centre = box + (size_t) r * cols + c;
+    uint32_t bits = 0;
+#pragma unroll 8
+    for (int t = 0; t < 32; ++t) {
+      const int8_t* pp = pattern + 4 * (32 * w + t);
+      const uint32_t s1 = centre[(int) pp[1] * cols + (int) pp[0]];
+      const uint32_t s2 = centre[(int) pp[3] * cols + (int) pp[2]];
+      bits |= (s1 < s2 ? 1u : 0u) << t;
+    }
+    reinterpret_cast<uint32_t*>(out_desc + (size_t) slot * PRS_DESC_BYTES)[w] = bits;
+    if (w == 0) {
+      out_kp[slot] = prs_kp2{(float) c, (float) r};
+      if (out_int) {
+        out_int[slot] = (float) src[(size_t) r * a.b.pitch + c];  // intensity_feature_extractor_base.cpp:80
+      }
+    }
   }
   if (__syncthreads_or(overflow ? 1 : 0)) {
     if (tid == 0) {

@@ -1,0 +1,53 @@
+"""feature extraction throughput: B synthetic KITTI-sized 8-bit images resident in HBM
+usage: python tools/bench_features.py [B]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from srrg2_proslam_amd import configs, ops, synthetic as syn  # noqa: E402
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+    cfg = configs.get("kitti")
+    uniq = []
+    for s in range(8):
+        l, r, _ = syn.stereo_images(np.random.default_rng(100 + s), cfg)
+        uniq += [l, r]
+    dev = torch.device("cuda", 0)
+    stage = torch.from_numpy(np.stack(uniq)).to(dev)
+    img = stage[torch.arange(B, device=dev) % len(uniq)].contiguous()
+    rows, cols = img.shape[1], img.shape[2]
+    stride = 1024
+    kp = torch.zeros((B, stride, 2), dtype=torch.float32, device=dev)
+    desc = torch.zeros((B, stride, 32), dtype=torch.uint8, device=dev)
+    n = torch.zeros((B,), dtype=torch.int32, device=dev)
+    st = torch.zeros((B,), dtype=torch.int32, device=dev)
+    ctx = ops.Context(0)
+    ctx.use_torch_stream()
+    p = ops.extractor_params()
+    for _ in range(2):
+        ops.extract_features_batch(ctx, p, img, kp, desc, n, st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    iters = 5
+    for _ in range(iters):
+        ops.extract_features_batch(ctx, p, img, kp, desc, n, st)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    assert int(st.min().item()) >= 0
+    nf = n.float().mean().item()
+    algo = B * (rows * cols + nf * 44)  # image read once + keypoints (8 B) + descriptors (32 B) + counters written
+    print("B=%d images %dx%d, %.0f features/image: %.3f ms/launch, %.2f M images/s, %.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (
+        B, cols, rows, nf, ms, B / ms / 1e3, algo / ms / 1e6, 100 * algo / ms / 1e6 / 8000))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
