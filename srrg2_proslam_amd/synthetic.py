@@ -226,3 +226,51 @@ def stereo_images(rng, cfg, n_rectangles=140, max_disparity=90):
             right[y: y + h, x0: x1] = tex[:, x0 - xr: x1 - xr]
         rects.append((x, y, w, h, int(d[k])))
     return left, right, rects
+
+
+def stereo_image_sequence(rng, cfg, n_frames, n_rectangles=140, max_disparity=88):
+    """rectified stereo image pairs of ONE static layered scene seen from a camera that steps sideways by a quarter of
+    the baseline per frame: every disparity is a multiple of 4, so a layer moves by disparity / 4 whole pixels from
+    frame to frame and patches stay identical pixel for pixel.  Returns ([(left, right)] per frame, step in metres):
+    camera k sits at x = k * step in the frame of camera 0."""
+    cam = cfg["camera"]
+    rows, cols = int(cam["rows"]), int(cam["cols"])
+    margin = (max_disparity // 4) * n_frames + max_disparity + 8  # content that scrolls into view
+
+    def blocks(h, w, size):
+        b = rng.integers(20, 236, ((h + size - 1) // size, (w + size - 1) // size)).astype(np.uint8)
+        t = np.kron(b, np.ones((size, size), np.uint8))[:h, :w].copy()
+        n_blobs = max(h * w // 220, 1)
+        ys, xs = rng.integers(0, max(h - 4, 1), n_blobs), rng.integers(0, max(w - 4, 1), n_blobs)
+        gs = rng.integers(0, 2, n_blobs) * 255
+        for y, x, g in zip(ys, xs, gs):
+            t[y: y + 4, x: x + 4] = g
+        return t
+
+    wide = cols + 2 * margin
+    background = blocks(rows, wide, 16)  # disparity 4: one pixel per frame
+    d = np.sort(rng.integers(2, max_disparity // 4 + 1, n_rectangles)) * 4
+    rects = []
+    for k in range(n_rectangles):
+        w, h = int(rng.integers(60, 220)), int(rng.integers(40, 140))
+        x, y = int(rng.integers(0, wide - w)), int(rng.integers(0, rows - h))
+        rects.append((x, y, blocks(h, w, 8), int(d[k])))
+
+    def render(shift_of):
+        """image whose layer with disparity dd is displaced by shift_of(dd) pixels to the left"""
+        img = np.empty((rows, cols), np.uint8)
+        s0 = shift_of(4)
+        img[:] = background[:, margin + s0: margin + s0 + cols]
+        for x, y, tex, dd in rects:  # far to near
+            xs = x - margin - shift_of(dd)
+            x0, x1 = max(xs, 0), min(xs + tex.shape[1], cols)
+            if x1 > x0:
+                img[y: y + tex.shape[0], x0: x1] = tex[:, x0 - xs: x1 - xs]
+        return img
+
+    frames = []
+    for k in range(n_frames):
+        left = render(lambda dd: k * dd // 4)
+        right = render(lambda dd: k * dd // 4 + dd)
+        frames.append((left, right))
+    return frames, float(cam["baseline_m"]) / 4.0
