@@ -123,6 +123,11 @@ __global__ __launch_bounds__(kFastThreads) void fast_box_kernel(const FeatureArg
   __shared__ uint8_t tile[(kTileH + 2 * kHalo) * kTilePitch];
   __shared__ uint8_t resp[kSH * kSW];
   __shared__ uint16_t hsum[(kTileH + 4) * kTileW];  // horizontal 5-sums of the tile rows -2 .. kTileH+1
+  __shared__ uint16_t cand[kSH * kSW];              // response-tile positions that pass the compass test
+  __shared__ int n_cand;
+  if (threadIdx.x == 0) {
+    n_cand = 0;
+  }
   const int rows = a.b.rows, cols = a.b.cols, pitch = a.b.pitch;
   const int img  = blockIdx.z;
   const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
@@ -138,14 +143,33 @@ __global__ __launch_bounds__(kFastThreads) void fast_box_kernel(const FeatureArg
   }
   __syncthreads();
   const int t = a.p.detector_threshold;
+  // Nine contiguous circle pixels always contain two ADJACENT compass points (circle indices 0, 4, 8, 12), so a
+  // pixel can only be a corner if two adjacent compass points are both brighter than v + t or both darker than
+  // v - t.  That four-read test runs for every pixel; the pixels that pass it are collected (order irrelevant) and
+  // the full segment test then runs on dense lanes.
   for (int i = tid; i < kSH * kSW; i += kFastThreads) {
     const int sy = i / kSW, sx = i - sy * kSW;
     const int gx = x0 + sx - 1, gy = y0 + sy - 1;
-    int s = 0;
+    bool candidate = false;
     if (gx >= 3 && gx < cols - 3 && gy >= 3 && gy < rows - 3) {  // the outermost 3 pixels are not examined
-      s = fast_response(tile + (sy - 1 + kHalo) * kTilePitch + (sx - 1 + kHalo), t);
+      const uint8_t* c = tile + (sy - 1 + kHalo) * kTilePitch + (sx - 1 + kHalo);
+      const int v = c[0];
+      const int n = (int) c[-3 * kTilePitch] - v, e = (int) c[3] - v, so = (int) c[3 * kTilePitch] - v, w = (int) c[-3] - v;
+      const uint32_t b = (n > t ? 1u : 0u) | (e > t ? 2u : 0u) | (so > t ? 4u : 0u) | (w > t ? 8u : 0u);
+      const uint32_t d = (n < -t ? 1u : 0u) | (e < -t ? 2u : 0u) | (so < -t ? 4u : 0u) | (w < -t ? 8u : 0u);
+      // adjacent pairs (N,E) (E,S) (S,W) (W,N): m & rotate-left-by-one(m) on four bits
+      candidate = ((b & ((b << 1) | (b >> 3))) | (d & ((d << 1) | (d >> 3)))) & 0xfu;
     }
-    resp[i] = (uint8_t) s;
+    resp[i] = 0;
+    if (candidate) {
+      cand[atomicAdd(&n_cand, 1)] = (uint16_t) i;
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < n_cand; j += kFastThreads) {
+    const int i  = cand[j];
+    const int sy = i / kSW, sx = i - sy * kSW;
+    resp[i] = (uint8_t) fast_response(tile + (sy - 1 + kHalo) * kTilePitch + (sx - 1 + kHalo), t);
   }
   for (int i = tid; i < (kTileH + 4) * kTileW; i += kFastThreads) {  // separable 5x5 box sum, horizontal pass
     const int hy = i >> 6, hx = i & 63;

@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--keypoints", type=int, default=2000)
     ap.add_argument("--cap", type=int, default=3072, help="landmark capacity of a local map")
     ap.add_argument("--check", type=int, default=2, help="sequences replayed on the CPU oracle (0 = skip)")
+    ap.add_argument("--from-images", action="store_true",
+                    help="start every frame from a rectified 8-bit stereo image pair (feature extraction on the device); "
+                         "the scene is a static layered world, the camera steps sideways (use a smaller --batch: the images stay resident)")
     args = ap.parse_args()
     import torch
     from bench_merge import merger_params
@@ -113,18 +116,30 @@ def main():
     cam = cfg["camera"]
     B, N, K, cap = args.batch, args.keypoints, args.frames, args.cap
     dev = torch.device("cuda", 0)
-    seqs = make_sequences(cfg, args.unique, K, N, syn.seed_for(1, 0) + 500000)
-    idx = torch.arange(B, device=dev) % len(seqs)
-    # per-frame inputs of every sequence, resident in HBM
-    inputs = []
-    stage = ops.StereoFrames(0, len(seqs), N, epilogue=False)
-    for k in range(K):
-        for u, frames in enumerate(seqs):
-            fr = frames[k]
-            stage.upload(u, fr["uv_left"], fr["desc_left"], fr["uv_right"], fr["desc_right"])
-        inputs.append(tuple(t.index_select(0, idx).contiguous() for t in (stage.left_kp, stage.left_desc, stage.right_kp, stage.right_desc, stage.n_left, stage.n_right)))
-    del stage
+    idx = torch.arange(B, device=dev) % args.unique
+    inputs, images, step_m = [], [], 0.0
+    if args.from_images:
+        N = 1024  # feature capacity per image (kitti.conf: target 1000)
+        img_seqs = [syn.stereo_image_sequence(np.random.default_rng(syn.seed_for(1, 0) + 600000 + u), cfg, K) for u in range(args.unique)]
+        step_m = img_seqs[0][1]
+        for k in range(K):
+            L = torch.from_numpy(np.stack([s[0][k][0] for s in img_seqs])).to(dev).index_select(0, idx).contiguous()
+            R = torch.from_numpy(np.stack([s[0][k][1] for s in img_seqs])).to(dev).index_select(0, idx).contiguous()
+            images.append((L, R))
+        seqs = img_seqs
+    else:
+        seqs = make_sequences(cfg, args.unique, K, N, syn.seed_for(1, 0) + 500000)
+        # per-frame inputs of every sequence, resident in HBM
+        stage = ops.StereoFrames(0, len(seqs), N, epilogue=False)
+        for k in range(K):
+            for u, frames in enumerate(seqs):
+                fr = frames[k]
+                stage.upload(u, fr["uv_left"], fr["desc_left"], fr["uv_right"], fr["desc_right"])
+            inputs.append(tuple(t.index_select(0, idx).contiguous() for t in (stage.left_kp, stage.left_desc, stage.right_kp, stage.right_desc, stage.n_left, stage.n_right)))
+        del stage
     sf = ops.StereoFrames(0, B, N, epilogue=True)
+    ext_status = torch.zeros((B,), dtype=torch.int32, device=dev)
+    ep = ops.extractor_params()
     max_meas = K + 1
     maps = ops.MapBatch(0, B, cap, max_meas, K + 1, N, N)
     maps.measurement, maps.measurement_desc, maps.n_measured = sf.fixed_uvuv, sf.fixed_desc, sf.n_fixed
@@ -149,7 +164,13 @@ def main():
     poses_log = []
 
     def frame(k, ev=None):
-        sf.left_kp, sf.left_desc, sf.right_kp, sf.right_desc, sf.n_left, sf.n_right = inputs[k]
+        if ev:
+            ev[5].record()
+        if args.from_images:
+            ops.extract_features_batch(ctx, ep, images[k][0], sf.left_kp, sf.left_desc, sf.n_left, ext_status)
+            ops.extract_features_batch(ctx, ep, images[k][1], sf.right_kp, sf.right_desc, sf.n_right, ext_status)
+        else:
+            sf.left_kp, sf.left_desc, sf.right_kp, sf.right_desc, sf.n_left, sf.n_right = inputs[k]
         if ev:
             ev[0].record()
         ops.stereo_match_batch(ctx, sp, sf, tp)
@@ -183,7 +204,7 @@ def main():
         frame(1)  # warm-up of the tracked path (its effects are kept: the timed region continues with frame 2)
         poses_log.append(pose[: len(seqs)].cpu().numpy().copy())
         torch.cuda.synchronize()
-        events = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(K)]
+        events = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(K)]
         t0 = time.perf_counter()
         for k in range(2, K):
             frame(k, events[k])
@@ -196,12 +217,17 @@ def main():
     tracked = K - 2
     ms = lambda a, b: float(np.mean([events[k][a].elapsed_time(events[k][b]) for k in range(2, K)]))  # noqa: E731
     truth = camera_pose(K - 1)
+    if args.from_images:
+        truth = np.eye(4, dtype=np.float32)
+        truth[0, 3] = (K - 1) * step_m
     err = float(np.max(np.linalg.norm(final_pose[:, :3, 3] - truth[:3, 3], axis=1)))
     out = {
         "metric": "tracked frames/sec, closed loop (matcher -> clipper -> finder/aligner -> pose update -> merger) on KITTI-shaped synthetic stereo",
         "value": B * tracked / elapsed, "unit": "frames/s", "n_gpus": 1,
         "frames_per_step": B, "tracked_frames_timed": tracked, "ms_per_frame_step": elapsed / tracked * 1e3,
-        "ms_per_stage": {"stereo_match": ms(0, 1), "scene_clip": ms(1, 2), "align": ms(2, 3), "pose_update+merge": ms(3, 4)},
+        "ms_per_stage": {"feature_extraction": ms(5, 0), "stereo_match": ms(0, 1), "scene_clip": ms(1, 2), "align": ms(2, 3),
+                         "pose_update+merge": ms(3, 4)},
+        "from_images": bool(args.from_images),
         "map_points_mean": float(maps.n_points.float().mean().item()),
         "merged_per_frame_mean": float(maps.result[:, 0].float().mean().item()),
         "added_per_frame_mean": float(maps.result[:, 1].float().mean().item()),
@@ -210,7 +236,7 @@ def main():
         "config": {"workload": "%d sequences x %d frames, %d keypoints per image, kitti.conf matcher / finder / aligner / merger (stereo "
                                "triangulation + pose-based smoother, 20 x 60 bins), map capacity %d" % (B, K, N, cap)},
     }
-    if args.check > 0:
+    if args.check > 0 and not args.from_images:
         worst, exact_n, cpu_s, cpu_frames = 0.0, True, 0.0, 0
         for u in range(min(args.check, len(seqs))):
             op, on, dt = oracle_chain(cfg, seqs[u], cap, max_meas)
