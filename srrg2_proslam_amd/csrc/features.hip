@@ -312,6 +312,7 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const Feat
   __shared__ uint32_t start[kMaxRegions + 1];
   __shared__ int8_t pattern[1024];
   __shared__ int wave_tot[kSelThreads / 64];
+  __shared__ uint16_t patch[(kSelThreads / 64) * 27 * 27];  // per wave: box sums around the keypoint being described
   const int rows = a.b.rows, cols = a.b.cols;
   const int img  = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -434,27 +435,58 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const Feat
     __syncthreads();
   }
   const int n_kept = running < a.b.stride ? running : a.b.stride;
-  // ---- descriptors: eight lanes per keypoint, one 32-bit word (32 comparisons of 5x5 box sums) each;
-  //      bit t of the descriptor lands in byte t / 8, bit t % 8
-  for (int job = tid; job < n_kept * 8; job += kSelThreads) {
-    const int slot = job >> 3, w = job & 7;
-    const uint32_t pix = keys[slot];
-    const int r = (int) (pix / (uint32_t) cols), c = (int) (pix - (uint32_t) r * (uint32_t) cols);
-    const uint16_t* __restrict__ centre = box + (size_t) r * cols + c;
-    uint32_t bits = 0;
-#pragma unroll 8
-    for (int t = 0; t < 32; ++t) {
-      const int8_t* pp = pattern + 4 * (32 * w + t);
-      const uint32_t s1 = centre[(int) pp[1] * cols + (int) pp[0]];
-      const uint32_t s2 = centre[(int) pp[3] * cols + (int) pp[2]];
-      bits |= (s1 < s2 ? 1u : 0u) << t;
+  // ---- descriptors: one wave per keypoint.  The 27x27 window of box sums the pair table can reach is staged in
+  //      LDS with row-contiguous reads (scattered 2-byte reads from global memory would serialise in the
+  //      texture addresser), then every lane evaluates four comparisons and a ballot IS eight bytes of the
+  //      descriptor: bit t lands in byte t / 8, bit t % 8
+  {
+    constexpr int kWin = 27;  // offsets -13 .. 13
+    int o1[4], o2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int8_t* pp = pattern + 4 * (64 * j + lane);
+      o1[j]            = ((int) pp[1] + 13) * kWin + ((int) pp[0] + 13);
+      o2[j]            = ((int) pp[3] + 13) * kWin + ((int) pp[2] + 13);
     }
-    reinterpret_cast<uint32_t*>(out_desc + (size_t) slot * PRS_DESC_BYTES)[w] = bits;
-    if (w == 0) {
-      out_kp[slot] = prs_kp2{(float) c, (float) r};
-      if (out_int) {
-        out_int[slot] = (float) src[(size_t) r * a.b.pitch + c];  // intensity_feature_extractor_base.cpp:80
+    uint16_t* win = patch + wave * (kWin * kWin);
+    for (int slot = wave; slot < n_kept; slot += kSelThreads / 64) {
+      const uint32_t pix = keys[slot];
+      const int r = (int) (pix / (uint32_t) cols), c = (int) (pix - (uint32_t) r * (uint32_t) cols);
+      const uint16_t* __restrict__ corner = box + (size_t) (r - 13) * cols + (c - 13);
+      uint16_t v[12];  // 12 x 64 >= 729: all loads are issued before the first one is consumed
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        const int e  = lane + 64 * u;
+        const int ec = e < kWin * kWin ? e : kWin * kWin - 1;
+        const int wr = ec / kWin, wc = ec - wr * kWin;
+        v[u]         = corner[(size_t) wr * cols + wc];
       }
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        const int e = lane + 64 * u;
+        if (e < kWin * kWin) {
+          win[e] = v[u];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      unsigned long long bits[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bits[j] = __ballot(win[o1[j]] < win[o2[j]]);
+      }
+      if (lane < 4) {
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(out_desc + (size_t) slot * PRS_DESC_BYTES);
+        d[lane]               = lane == 0 ? bits[0] : (lane == 1 ? bits[1] : (lane == 2 ? bits[2] : bits[3]));
+      }
+      if (lane == 4) {
+        out_kp[slot] = prs_kp2{(float) c, (float) r};
+        if (out_int) {
+          out_int[slot] = (float) src[(size_t) r * a.b.pitch + c];  // intensity_feature_extractor_base.cpp:80
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // the window is rewritten for the wave's next keypoint
     }
   }
   if (__syncthreads_or(overflow ? 1 : 0)) {
