@@ -229,7 +229,9 @@ __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const 
 
 // SPLIT = the search half of the split pipeline (mode kModeSplitSearch): a compile-time flag, so the
 // Gauss-Newton code (and its registers) is not part of that instantiation
-template <int T, bool SPLIT>
+// STYPE: the search pattern as a compile-time constant (-1 = read it from the parameters), so that the search
+// half only carries the code and registers of its own pattern
+template <int T, bool SPLIT, int STYPE>
 __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs g) {  // search half: <= 128 VGPRs = two workgroups per CU
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid   = threadIdx.x;
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
   float* terms        = reinterpret_cast<float*>(smem + g.off_terms);     // aliases the search-phase arrays
   AlignShared& sh     = *reinterpret_cast<AlignShared*>(smem + g.off_sh);
   const int R         = g.rows_table;
-  const int stype     = g.f.search_type;
+  const int stype     = STYPE >= 0 ? STYPE : g.f.search_type;
   const bool lattice  = stype != PRS_SEARCH_KDTREE;
 
   constexpr bool split_search = SPLIT;
@@ -1540,7 +1542,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   hipError_t e;
   const bool split = mode == PRS_MODE_ALIGN && !ctx_fused_align(ctx) && max_fixed <= kGnThreads * kGnSlots && !g.stamps;
   if (!split) {
-    auto kernel = align_kernel<kAlignThreads, false>;
+    auto kernel = align_kernel<kAlignThreads, false, -1>;
     e           = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     if (e != hipSuccess) {
       return ctx_fail_hip(ctx, e, "prs_align_batch_run attribute");
@@ -1569,7 +1571,12 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   AlignArgs gs = g;
   gs.mode      = kModeSplitSearch;
   const size_t lds_search = carve(gs, false);
-  auto skernel = align_kernel<kSearchThreads, true>;
+  auto skernel = finder->search_type == PRS_SEARCH_CIRCLE
+                   ? align_kernel<kSearchThreads, true, PRS_SEARCH_CIRCLE>
+                   : (finder->search_type == PRS_SEARCH_SQUARE
+                        ? align_kernel<kSearchThreads, true, PRS_SEARCH_SQUARE>
+                        : (finder->search_type == PRS_SEARCH_RHOMBUS ? align_kernel<kSearchThreads, true, PRS_SEARCH_RHOMBUS>
+                                                                     : align_kernel<kSearchThreads, true, PRS_SEARCH_KDTREE>));
   const size_t lds_gn = (size_t) kTerms * kGnRow * sizeof(float) + sizeof(GnShared) + 16;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(skernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_search);
   if (e != hipSuccess) {
