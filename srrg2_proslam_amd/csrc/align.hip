@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
 // registers (<= 4 per thread), so a workgroup needs only the 29 x 256 term matrix in LDS and many
 // frames share a CU.  Arithmetic and summation order are those of the fused kernel.
 constexpr int kGnThreads = 256;
-constexpr int kGnSlots   = 4;  // correspondences per thread: max_fixed <= 1024
+constexpr int kGnSlots   = 4;  // most correspondences per thread: max_fixed <= 1024 (the kernel is instantiated for 2, 3 and 4)
 // row stride of the term matrix in floats: +4 so that the 29 summing lanes (one row each, 16-B reads)
 // start 16 B apart in the bank space instead of all on the same four banks
 constexpr int kGnRow     = kGnThreads + 4;
@@ -1125,6 +1125,8 @@ struct GnShared {
   int converged, need_search, n_inl, n_out, n_inv, stop, flags;
 };
 
+// SLOTS = correspondences per thread the instantiation keeps in registers (ceil(max_fixed / 256))
+template <int SLOTS>
 __global__ __launch_bounds__(kGnThreads, 5) void gn_kernel(const AlignArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid   = threadIdx.x;
@@ -1168,9 +1170,9 @@ __global__ __launch_bounds__(kGnThreads, 5) void gn_kernel(const AlignArgs g) {
     sh.b[tid] = gres->b[tid];
   }
   // operands of this thread's correspondences stay in registers for the whole launch
-  float4 zf[kGnSlots], pm[kGnSlots];
+  float4 zf[SLOTS], pm[SLOTS];
 #pragma unroll
-  for (int k = 0; k < kGnSlots; ++k) {
+  for (int k = 0; k < SLOTS; ++k) {
     const int c = k * kGnThreads + tid;
     zf[k]       = c < nc ? gops[2 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
     pm[k]       = c < nc ? gops[2 * c + 1] : make_float4(0.f, 0.f, 1.f, 1.f);
@@ -1238,7 +1240,7 @@ __global__ __launch_bounds__(kGnThreads, 5) void gn_kernel(const AlignArgs g) {
     float run = 0.0f;
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kGnSlots; ++k) {
+    for (int k = 0; k < SLOTS; ++k) {
       const int c0 = k * kGnThreads;
       if (c0 < nc) {
         float tv[kTerms];
@@ -1592,7 +1594,13 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
     for (int r = 0; r < rounds_left; ++r) {
       (void) hipMemsetAsync(g.pending, 0, sizeof(int), stream);
       hipLaunchKernelGGL(skernel, dim3(batch->batch), dim3(kSearchThreads), lds_search, stream, gs);
-      hipLaunchKernelGGL(gn_kernel, dim3(batch->batch), dim3(kGnThreads), lds_gn, stream, g);
+      if (max_fixed <= 2 * kGnThreads) {
+        hipLaunchKernelGGL(gn_kernel<2>, dim3(batch->batch), dim3(kGnThreads), lds_gn, stream, g);
+      } else if (max_fixed <= 3 * kGnThreads) {
+        hipLaunchKernelGGL(gn_kernel<3>, dim3(batch->batch), dim3(kGnThreads), lds_gn, stream, g);
+      } else {
+        hipLaunchKernelGGL(gn_kernel<4>, dim3(batch->batch), dim3(kGnThreads), lds_gn, stream, g);
+      }
       ++total;
     }
     e = hipGetLastError();
