@@ -37,7 +37,7 @@ struct StereoArgs {
   int epilogue;
   int sort_cap;  // entries of each sorted / bucket array (>= stride, >= image_rows + 1)
   uint32_t off_desc_l, off_desc_r, off_sorted_l, off_sorted_r, off_bucket, off_rowstart_l, off_rowstart_r;
-  uint32_t off_rowcnt, off_bits, off_misc, off_tab;
+  uint32_t off_rowcnt, off_bits, off_misc, off_tab, off_kp_r;
   // exact integer form of `best < max_distance && best / second < max_ratio` (epipolar_impl.cpp:171-173),
   // evaluated on the host with the reference's float operations (fill_accept_table)
   int best_lim;        // accept iff best < best_lim ...
@@ -155,6 +155,7 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
   uint16_t* prefK    = reinterpret_cast<uint16_t*>(bitsK + nwords);     // epilogue: kept matches before word w
   int* misc          = reinterpret_cast<int*>(smem + a.off_misc);       // [0] error, [1] pass matches, [2] pass kept
   int16_t* tab       = reinterpret_cast<int16_t*>(smem + a.off_tab);    // Lowe acceptance table
+  prs_kp2* ldKR      = reinterpret_cast<prs_kp2*>(smem + a.off_kp_r);   // staged variant: right coordinates for the epilogue
   uint32_t* histL    = sortedL;  // the histograms die before the sorted arrays are born
   uint32_t* histR    = sortedR;
 
@@ -367,6 +368,7 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
       if (i < nR) {
         ldR[2 * i]     = dR[2 * k];
         ldR[2 * i + 1] = dR[2 * k + 1];
+        ldKR[i]        = cR[k];
       }
     }
   }
@@ -593,7 +595,7 @@ __global__ __launch_bounds__(kStereoThreads) void stereo_match_kernel(const Ster
           cr.response   = (float) (rec.x >> 16);
           out[out_base + m_out[k]] = cr;
           if (a.epilogue) {
-            m_kr[k] = kpR[m_idx_r[k]];
+            m_kr[k] = STAGE ? ldKR[m_idx_r[k]] : kpR[m_idx_r[k]];
             // raw_data_preprocessor_stereo_projective.cpp:117-125
             const float hd = cL[k].u - m_kr[k].u, vd = cL[k].v - m_kr[k].v;
             m_keep[k] = !(hd < 0.0f || vd < 0.0f);
@@ -768,6 +770,11 @@ int stereo_match_batch_launch(prs_context* ctx, const prs_stereo_params* params,
     if (rc4 != 1) {
       return rc4;
     }
+    // instruction-lean staged kernel for frames of <= 2048 keypoints (stereo_match_v5.hip)
+    const int rc5 = stereo_match_v5_launch(ctx, params, batch);
+    if (rc5 != 1) {
+      return rc5;
+    }
   }
   StereoArgs a;
   a.p        = *params;
@@ -799,6 +806,7 @@ int stereo_match_batch_launch(prs_context* ctx, const prs_stereo_params* params,
     s.off_bits       = off; off = align_up(off + nwords * (3 * 4 + 2), 16);
     s.off_misc       = off; off = align_up(off + 16, 16);
     s.off_tab        = off; off = align_up(off + 258 * 2, 16);
+    s.off_kp_r       = off; off = align_up(off + (stage ? (uint32_t) stride * 8 : 0), 16);
     return off;
   };
   const size_t lds_limit = 160 * 1024;
