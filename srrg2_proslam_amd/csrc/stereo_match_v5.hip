@@ -6,8 +6,8 @@
 // bounds that kernel (profiles/r01/matcher_pmc_diag.json: the four SIMDs issue ~40 k wave-instructions per
 // frame, memory and LDS are far from busy and a second resident workgroup does not shorten a frame):
 //   * every epipolar row of the bucket / sorted arrays is padded to a multiple of four entries with
-//     0xffffffff sentinels, so in-row ranks and disparity-window bounds are counted with 16-byte LDS reads
-//     and one compare + add-with-carry per entry (no per-entry length test, no binary search);
+//     0x7fffffff sentinels, so in-row ranks and disparity-window bounds are counted with 16-byte LDS reads
+//     and a subtract + funnel shift per entry (no per-entry length test, no binary search, no VCC);
 //   * the scoring phase (all lanes busy) also evaluates, for every possible cursor position inside the
 //     window, whether the keypoint would match and with which candidate (a 4 x 3 bit table, built by one
 //     backwards sweep over the <= 4 candidates); the serial cursor chain (one lane per row, 6 of 16
@@ -40,10 +40,12 @@ struct Args5 {
 typedef unsigned int q32 __attribute__((ext_vector_type(4)));
 constexpr int kT                = 1024;
 constexpr uint32_t kNone        = 0xffffu;
-constexpr uint32_t kOverflow    = 7u;
+constexpr uint32_t kOverflow    = 1u << 31;
 // candidate record of a sorted-left position (written by the scoring phase):
-//   x = four 8-bit distances of candidates lo .. lo+3 (255 = none / pruned / >= 255: never accepted, best_lim <= 255)
-//   y = verdict[0..3] (4 bit each) | lo << 16 (13 bit) | n << 29 (0..4, 7 = more than four candidates)
+//   res[p].x  = verdict[0..3], 4 bit each (bits 16..19 stay zero: "cursor beyond the window")
+//   res[p].y  = lo (13 bit: sorted position of the first in-window candidate) | more-than-four-candidates << 31
+//   dist4[p]  = four 8-bit distances of candidates lo .. lo+3 (255 = none / pruned / >= 255: never accepted,
+//               best_lim <= 255); for a more-than-four record: the left keypoint's (col << 16 | index) key
 // verdict[m] = accepted << 3 | candidate << 1 | kept: what the chain does once its cursor consumed m candidates
 // chain output per sorted-left position: verdict << 28 | rescored << 27 | kept-before-in-row << 12 | matches-before-in-row
 constexpr uint32_t kOutRescored = 1u << 27;
@@ -67,9 +69,23 @@ __device__ __forceinline__ uint32_t hamming5(const q32& a0, const q32& a1, const
   return d;
 }
 
-// number of entries of the quad that are smaller than key (sentinels never are)
-__device__ __forceinline__ int below(const q32& q, uint32_t key) {
-  return (q.x < key ? 1 : 0) + (q.y < key ? 1 : 0) + (q.z < key ? 1 : 0) + (q.w < key ? 1 : 0);
+// Keys are (col << 16 | index) with col < 32768: 31-bit values, and so are the compare bounds.  For such
+// a, b the top bit of a - b says a < b, which needs no compare-to-VCC round trip (every VALU write of
+// VCC costs wait states before the next VALU read of it on gfx950): below_bits shifts the four sign bits
+// of a quad into a mask whose population count is the number of entries below the bound.  The sentinel
+// 0x7fffffff pads the rows; it is above every key and never below a bound.
+constexpr uint32_t kSentinel = 0x7fffffffu;
+__device__ __forceinline__ uint32_t below_bits(uint32_t mask, const q32& q, uint32_t bound) {
+  mask = __builtin_amdgcn_alignbit(mask, q.x - bound, 31);
+  mask = __builtin_amdgcn_alignbit(mask, q.y - bound, 31);
+  mask = __builtin_amdgcn_alignbit(mask, q.z - bound, 31);
+  return __builtin_amdgcn_alignbit(mask, q.w - bound, 31);
+}
+__device__ __forceinline__ int below3(const q32& q0, const q32& q1, const q32& q2, uint32_t bound) {
+  return __popc(below_bits(below_bits(below_bits(0u, q0, bound), q1, bound), q2, bound));
+}
+__device__ __forceinline__ int below(const q32& q, uint32_t bound) {
+  return __popc(below_bits(0u, q, bound));
 }
 
 // ONE wave: start[r] = sum over r' < r of the count rounded up to a multiple of four, len[r] = count
@@ -186,8 +202,8 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
 
   q32* ldR          = reinterpret_cast<q32*>(smem + a.off_desc_r);          // right descriptor rows by unsorted index
   prs_kp2* ldKR     = reinterpret_cast<prs_kp2*>(smem + a.off_kp_r);        // right coordinates by unsorted index
-  uint32_t* sortedL = reinterpret_cast<uint32_t*>(smem + a.off_sorted_l);   // (col << 16 | index), rows padded to 4
-  uint32_t* sortedR = reinterpret_cast<uint32_t*>(smem + a.off_sorted_r);
+  uint32_t* dist4   = reinterpret_cast<uint32_t*>(smem + a.off_sorted_l);   // candidate distances per sorted-left position
+  uint32_t* sortedR = reinterpret_cast<uint32_t*>(smem + a.off_sorted_r);   // (col << 16 | index), rows padded to 4
   uint32_t* bucketL = reinterpret_cast<uint32_t*>(smem + a.off_bucket);     // same layout, arbitrary order inside a row
   uint32_t* bucketR = bucketL + cap + 4;
   uint2* res        = reinterpret_cast<uint2*>(smem + a.off_bucket);        // candidate records, alias both buckets after the sort
@@ -231,7 +247,7 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
   if ((int) blockIdx.x < a.b.batch) {
     fetch_coords((int) blockIdx.x);
   }
-  const q32 ones = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  const q32 ones = {kSentinel, kSentinel, kSentinel, kSentinel};
 
   for (int frame = blockIdx.x; frame < a.b.batch; frame += gridDim.x) {
     PRS5_STAMP(0);
@@ -392,8 +408,8 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
         const q32 r0 = *reinterpret_cast<const q32*>(bucketR + sR[k]);
         const q32 r1 = *reinterpret_cast<const q32*>(bucketR + (nrowR[k] > 4 ? sR[k] + 4 : cap));
         const q32 r2 = *reinterpret_cast<const q32*>(bucketR + (nrowR[k] > 8 ? sR[k] + 8 : cap));
-        int rankL    = below(l0, keyL[k]) + below(l1, keyL[k]) + below(l2, keyL[k]);
-        int rankR    = below(r0, keyR[k]) + below(r1, keyR[k]) + below(r2, keyR[k]);
+        int rankL    = below3(l0, l1, l2, keyL[k]);
+        int rankR    = below3(r0, r1, r2, keyR[k]);
         for (int j = 12; j < nrowL[k]; j += 4) {
           rankL += below(*reinterpret_cast<const q32*>(bucketL + sL[k] + j), keyL[k]);
         }
@@ -401,8 +417,7 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
           rankR += below(*reinterpret_cast<const q32*>(bucketR + sR[k] + j), keyR[k]);
         }
         if (rowL[k] >= 0) {
-          posL[k]          = sL[k] + rankL;
-          sortedL[posL[k]] = keyL[k];
+          posL[k] = sL[k] + rankL;  // the sorted left keys themselves are never needed
         }
         if (rowR[k] >= 0) {
           sortedR[sR[k] + rankR] = keyR[k];
@@ -436,6 +451,7 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
         }
         const int p       = posL[k];
         uint2 r           = make_uint2(0u, 0u);
+        uint32_t d4       = 0;
         const int rr      = rowL[k] + off;
         const bool pruned = multipass && ((bitsL[p >> 5] >> (p & 31)) & 1u);
         if (rr >= 0 && rr < rows && !pruned) {
@@ -447,12 +463,13 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
           //   hi = first q with col_r >  col_l              (epipolar_impl.cpp:141-143)
           const int col_min  = col_l - max_disp;
           const uint32_t klo = (uint32_t) (col_min > 0 ? col_min : 0) << 16;  // keys below it: col < col_min
-          const uint32_t khi = (uint32_t) (col_l + 1) << 16;                   // keys below it: col <= col_l
+          const uint32_t kh  = (uint32_t) (col_l + 1) << 16;                   // keys below it: col <= col_l
+          const uint32_t khi = kh < kSentinel ? kh : kSentinel;                // (col_l = 32767: every key, no sentinel)
           const q32 w0       = *reinterpret_cast<const q32*>(sortedR + (rn > 0 ? rs : cap));
           const q32 w1       = *reinterpret_cast<const q32*>(sortedR + (rn > 4 ? rs + 4 : cap));
           const q32 w2       = *reinterpret_cast<const q32*>(sortedR + (rn > 8 ? rs + 8 : cap));
-          int n_lo           = below(w0, klo) + below(w1, klo) + below(w2, klo);
-          int n_hi           = below(w0, khi) + below(w1, khi) + below(w2, khi);
+          int n_lo           = below3(w0, w1, w2, klo);
+          int n_hi           = below3(w0, w1, w2, khi);
           for (int j = 12; j < rn; j += 4) {
             const q32 w = *reinterpret_cast<const q32*>(sortedR + rs + j);
             n_lo += below(w, klo);
@@ -461,7 +478,8 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
           const int lo = rs + n_lo;
           const int n  = n_hi - n_lo;
           if (n > 4) {
-            r = make_uint2(0u, ((uint32_t) lo << 16) | (kOverflow << 29));
+            r  = make_uint2(0u, (uint32_t) lo | kOverflow);
+            d4 = keyL[k];
           } else if (n > 0) {
             const q32 d0 = dL[2 * k], d1 = dL[2 * k + 1];
             // kNone: no such candidate, or pruned by an earlier pass (epipolar_impl.cpp:197-205)
@@ -505,10 +523,12 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
             }
             const uint32_t b0 = dist[0] < 255u ? dist[0] : 255u, b1 = dist[1] < 255u ? dist[1] : 255u;
             const uint32_t b2 = dist[2] < 255u ? dist[2] : 255u, b3 = dist[3] < 255u ? dist[3] : 255u;
-            r = make_uint2(b0 | (b1 << 8) | (b2 << 16) | (b3 << 24), verdicts | ((uint32_t) lo << 16) | ((uint32_t) n << 29));
+            r  = make_uint2(verdicts, (uint32_t) lo);
+            d4 = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
           }
         }
-        res[p] = r;
+        res[p]   = r;
+        dist4[p] = d4;
       }
       __syncthreads();
       PRS5_STAMP(6);
@@ -529,17 +549,14 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
         }
         int c         = rsR[rr];
         const int re  = c + lenR[rr];
-        uint32_t cnt = 0, kept = 0;
-        bool overflow = false;
-        uint32_t y    = res[ls].y;  // (the arrays are padded: reading one record past the row is harmless)
+        uint32_t cnt = 0, kept = 0, flags = 0;
+        uint2 w = res[ls];  // (the arrays are padded: reading one record past the row is harmless)
         for (int p = ls; p < le; ++p) {
-          const uint32_t y_next = res[p + 1].y;
-          const uint32_t n      = y >> 29;
-          const int lo          = (int) ((y >> 16) & 0x1fffu);
-          uint32_t e            = 0;
-          if (kRescore && n == kOverflow) {
+          const uint2 w_next = res[p + 1];
+          const int lo       = (int) (w.y & 0x1fffu);
+          if (kRescore && (w.y & kOverflow)) {
             // more than four in-window candidates: score them here, from the cursor on
-            const uint32_t kl = sortedL[p];
+            const uint32_t kl = dist4[p];
             const int col_l   = (int) (kl >> 16);
             const int idx_l   = (int) (kl & 0xffffu);
             const q32 d0 = gdL[2 * idx_l], d1 = gdL[2 * idx_l + 1];
@@ -584,25 +601,26 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
               outv[p] = 0;
             }
           } else {
-            overflow = overflow || n == kOverflow;
+            flags |= w.y;
             // candidates left of the cursor were consumed by an earlier match (epipolar_impl.cpp:181);
-            // verdicts of candidates that do not exist are zero
-            const int m = c > lo ? c - lo : 0;
-            e           = m < 4 ? (y >> (4 * m)) & 15u : 0u;
-            const bool accepted = (e & 8u) != 0u;
+            // the verdicts of candidates that do not exist, and the fifth one, are zero
+            int m = c - lo;
+            m     = m < 0 ? 0 : (m > 4 ? 4 : m);
+            const uint32_t e    = (w.x >> (4 * m)) & 15u;
+            const bool accepted = e >= 8u;
             const int q         = lo + (int) ((e >> 1) & 3u);
             outv[p]             = accepted ? (e << 28) | (kept << 12) | cnt : 0u;
             cnt += accepted ? 1u : 0u;
-            kept += accepted ? (e & 1u) : 0u;
+            kept += e & 1u;
             c = accepted ? q + 1 : c;  // epipolar_impl.cpp:181
             if (multipass && accepted) {
               atomicOr(&bitsL[p >> 5], 1u << (p & 31));
               atomicOr(&bitsR[q >> 5], 1u << (q & 31));
             }
           }
-          y = y_next;
+          w = w_next;
         }
-        return (!kRescore && overflow) ? 0xffffffffu : (cnt | (kept << 16));
+        return (!kRescore && (flags & kOverflow)) ? 0xffffffffu : (cnt | (kept << 16));
       };
       for (int r = tid; r < rows; r += kT) {
         const uint32_t sum = chain_row(r, std::false_type());
@@ -649,8 +667,8 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
             best  = rec.x >> 16;
           } else {
             const uint32_t j = (v >> 29) & 3u;
-            best             = (rec.x >> (8 * j)) & 255u;
-            idx_r            = sortedR[((rec.y >> 16) & 0x1fffu) + j] & 0xffffu;
+            best             = (dist4[posL[k]] >> (8 * j)) & 255u;
+            idx_r            = sortedR[(rec.y & 0x1fffu) + j] & 0xffffu;
           }
           const uint32_t before = rowsum[rowL[k]];
           prs_corr cr;
@@ -755,7 +773,7 @@ int stereo_match_v5_launch(prs_context* ctx, const prs_stereo_params* params, co
   const uint32_t rows2 = (uint32_t) rows + 2u;
   a.off_desc_r   = off; off = up16(off + (uint32_t) stride * PRS_DESC_BYTES);
   a.off_kp_r     = off; off = up16(off + (uint32_t) stride * 8u);
-  a.off_sorted_l = off; off = up16(off + (cap + 4u) * 4u);
+  a.off_sorted_l = off; off = up16(off + (cap + 4u) * 4u);  // dist4
   a.off_sorted_r = off; off = up16(off + (cap + 4u) * 4u);
   a.off_bucket   = off; off = up16(off + 2u * (cap + 4u) * 4u);  // bucketL | bucketR, later res[cap]
   a.off_hist     = off; off = up16(off + 2u * rows2 * 4u);
