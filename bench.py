@@ -162,7 +162,7 @@ def pmc_traffic_bytes(kernel_substrings, frames_per_launch):
             if int(summ.get("frames_per_launch", 0)) != int(frames_per_launch):
                 continue
             total = 0.0
-            steps = [v["FETCH_SIZE"]["launches"] for k, v in summ["pmc_fetch"].items() if "stereo_match_kernel" in k][0]
+            steps = [v["FETCH_SIZE"]["launches"] for k, v in summ["pmc_fetch"].items() if "stereo_match" in k][0]
             for sub in kernel_substrings:
                 f = [v["FETCH_SIZE"] for k, v in summ["pmc_fetch"].items() if sub in k]
                 w = [v["WRITE_SIZE"] for k, v in summ["pmc_write"].items() if sub in k]
@@ -293,7 +293,7 @@ def main():
     gbps_match = B * bytes_match / (ms_match * 1e-3) / 1e9
     gbps_align = B * bytes_align / (ms_align * 1e-3) / 1e9
     fps = world * B * args.steps / elapsed
-    traffic_match, traffic_src = pmc_traffic_bytes(["stereo_match_kernel"], B)
+    traffic_match, traffic_src = pmc_traffic_bytes(["stereo_match"], B)
     # all search + GN rounds of one step
     traffic_align, _ = pmc_traffic_bytes(["align_kernel", "gn_kernel"], B)
 
@@ -324,7 +324,7 @@ def main():
             "aligner_success_fraction": status_ok,
         },
         "roofline": {
-            "kernel": "stereo_match_kernel (the kernel BASELINE.json north_star prices; matcher + fused adaptor / triangulator epilogue)",
+            "kernel": "stereo_match5_kernel<2> (the kernel BASELINE.json north_star prices; matcher + fused adaptor / triangulator epilogue)",
             "bound": "hbm",
             "achieved": gbps_match,
             "peak": HBM_PEAK_GBPS,
@@ -350,7 +350,7 @@ def main():
             "algorithmic_bytes_per_frame": bytes_align,
             "frames_per_launch": B,
         },
-        "kernel_time_share": {"stereo_match_kernel": ms_match / (ms_match + ms_align), "align_kernel": ms_align / (ms_match + ms_align)},
+        "kernel_time_share": {"stereo_match5_kernel": ms_match / (ms_match + ms_align), "align_kernel": ms_align / (ms_match + ms_align)},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_frames > 0:

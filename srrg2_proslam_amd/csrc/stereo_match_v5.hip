@@ -21,7 +21,7 @@
 #include "prs_host.h"
 
 namespace prs {
-namespace {
+namespace v5 {  // (named: rocprofv3 summaries key on the kernel name up to its first parenthesis)
 
 struct Args5 {
   prs_stereo_params p;
@@ -752,7 +752,8 @@ hipError_t launch5(const Args5& a, size_t lds, hipStream_t stream) {
   return hipGetLastError();
 }
 
-}  // namespace
+}  // namespace v5
+using namespace v5;
 
 // returns 1 when the frame shape is outside this kernel's domain (the caller falls back to stereo_match_kernel)
 int stereo_match_v5_launch(prs_context* ctx, const prs_stereo_params* params, const prs_stereo_batch* batch) {
