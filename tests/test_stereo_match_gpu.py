@@ -170,3 +170,62 @@ def test_standalone_triangulator_bit_exact(oracle, hip_ctx):
     xyz, valid = ops.triangulate(hip_ctx, ops.triangulator_params(cfg), np.stack([u, v, ur, v], axis=1).astype(np.float32))
     rel = np.linalg.norm(xyz[good] - pts[good], axis=1) / np.linalg.norm(pts[good], axis=1)
     assert rel.max() < 5e-4
+
+
+def test_first_generation_kernel_and_domain_fallbacks(oracle, monkeypatch):
+    """stereo_match_v5.hip serves frames of <= 2048 keypoints; PRS_MATCHER_V3=1, distances above 255 and tall images
+    (more padded sorted positions than its 13-bit field holds) take stereo_match.hip: same answers everywhere"""
+    cfg, fr = kitti_frame(77, 1800, row_jitter_fraction=0.1)
+    ctx_default = ops.Context(0)
+    monkeypatch.setenv("PRS_MATCHER_V3", "1")
+    ctx_first = ops.Context(0)
+    monkeypatch.delenv("PRS_MATCHER_V3")
+    try:
+        for thickness in (0, 1):
+            m = dict(cfg["stereo_matcher"])
+            m["epipolar_line_thickness_pixels"] = thickness
+            ref, rflags, got, gflags = _both(oracle, ctx_default, fr, m, 376)
+            _, _, got1, gflags1 = _both(oracle, ctx_first, fr, m, 376)
+            assert len(ref) > 300 and corr_equal(ref, got) and corr_equal(ref, got1) and rflags == gflags == gflags1
+        # every distance is acceptable: outside the 8-bit distance records of the v5 kernel
+        m = dict(cfg["stereo_matcher"], maximum_descriptor_distance=300.0, maximum_distance_ratio_to_second_best=0.95)
+        ref, rflags, got, gflags = _both(oracle, ctx_default, fr, m, 376)
+        assert len(ref) > 300 and corr_equal(ref, got) and rflags == gflags
+        # 4000 image rows: 1800 + 3 * 1800 padded positions still fit; 2048 keypoints on 4000 rows do not
+        tall = dict(fr)
+        tall["uv_left"], tall["uv_right"] = fr["uv_left"].copy(), fr["uv_right"].copy()
+        tall["uv_left"][:, 1] *= 10.0
+        tall["uv_right"][:, 1] *= 10.0
+        ref, rflags, got, gflags = _both(oracle, ctx_default, tall, cfg["stereo_matcher"], 4000)
+        assert len(ref) > 300 and corr_equal(ref, got) and rflags == gflags
+        cfg2, big = kitti_frame(78, 2048)
+        big["uv_left"][:, 1] *= 10.0
+        big["uv_right"][:, 1] *= 10.0
+        ref, rflags, got, gflags = _both(oracle, ctx_default, big, cfg2["stereo_matcher"], 4000)
+        assert len(ref) > 300 and corr_equal(ref, got) and rflags == gflags
+    finally:
+        ctx_default.close()
+        ctx_first.close()
+
+
+def test_rightmost_columns_and_long_rows(oracle, hip_ctx):
+    """columns up to 32767 (the key's 15-bit column field) and epipolar rows of more than twelve keypoints
+    (the tail loops of the padded-row rank / window counts)"""
+    rng = np.random.default_rng(9)
+    n = 900
+    rows = rng.integers(0, 40, n)  # ~22 keypoints per row
+    ul = rng.integers(32000, 32768, n).astype(np.float32) + rng.random(n).astype(np.float32) * 0.9
+    disp = rng.integers(0, 60, n)
+    uvl = np.stack([ul, rows + 0.5], axis=1).astype(np.float32)
+    uvr = np.stack([ul - disp, rows + 0.25], axis=1).astype(np.float32)
+    base = syn.random_descriptors(rng, n)
+    dl = syn.flip_bits(rng, base, 0.02)
+    dr = syn.flip_bits(rng, base, 0.02)
+    perm = rng.permutation(n)
+    fr = {"uv_left": uvl, "desc_left": dl, "uv_right": uvr[perm], "desc_right": dr[perm]}
+    m = {"maximum_descriptor_distance": 100.0, "maximum_distance_ratio_to_second_best": 0.8,
+         "minimum_matching_ratio": 0.1, "maximum_disparity_pixels": 100, "epipolar_line_thickness_pixels": 0}
+    for thickness in (0, 1):
+        m["epipolar_line_thickness_pixels"] = thickness
+        ref, rflags, got, gflags = _both(oracle, hip_ctx, fr, m, 376)
+        assert len(ref) > 200 and corr_equal(ref, got) and rflags == gflags
