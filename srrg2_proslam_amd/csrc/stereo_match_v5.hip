@@ -613,7 +613,9 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
             cnt += accepted ? 1u : 0u;
             kept += e & 1u;
             c = accepted ? q + 1 : c;  // epipolar_impl.cpp:181
-            if (multipass && accepted) {
+            // (behind a more-than-four record the cursor of this sweep is not the chain's: the row is
+            // replayed by the second sweep and nothing may be marked on its behalf here)
+            if (multipass && accepted && !(flags & kOverflow)) {
               atomicOr(&bitsL[p >> 5], 1u << (p & 31));
               atomicOr(&bitsR[q >> 5], 1u << (q & 31));
             }

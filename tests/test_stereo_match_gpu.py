@@ -229,3 +229,14 @@ def test_rightmost_columns_and_long_rows(oracle, hip_ctx):
         m["epipolar_line_thickness_pixels"] = thickness
         ref, rflags, got, gflags = _both(oracle, hip_ctx, fr, m, 376)
         assert len(ref) > 200 and corr_equal(ref, got) and rflags == gflags
+
+
+def test_randomised_shapes_and_parameters(oracle, hip_ctx):
+    """a bounded run of tools/fuzz_matcher.py: crowded rows, duplicate pixels, ragged counts, every kernel variant"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_matcher
+    bad, matches = fuzz_matcher.run(60, 20200303, ctx=hip_ctx, oracle=oracle, verbose=False)
+    assert not bad, bad[:3]
+    assert matches > 2000
