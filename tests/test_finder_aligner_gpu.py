@@ -253,3 +253,14 @@ def test_split_pipeline_equals_fused_kernel(oracle, monkeypatch):
     of.set_moving(mp["xyz"], mp["desc"])
     res, rcorr = oracle.align_frame(of, oracle_aligner_params(oracle, cfg, mean_disparity=oracle.mean_disparity(fixed)), fixed, mp["xyz"], scale, X0)
     assert np.array_equal(_bits(np.array(res.X)), _bits(outs[0][0]).ravel()) and corr_equal(rcorr, outs[0][1])
+
+
+def test_randomised_configurations_through_the_batched_pipeline(oracle, hip_ctx):
+    """a bounded run of tools/fuzz_align.py: search patterns, finder / aligner parameters, cloud sizes, LDS bounds"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_align
+    bad, n_corr = fuzz_align.run(16, 20200304, ctx=hip_ctx, oracle=oracle, verbose=False)
+    assert not bad, bad[:3]
+    assert n_corr > 3000
