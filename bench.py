@@ -149,7 +149,7 @@ def cpu_all_cores(args, n_workers, frames_each):
     return total, ok, time.perf_counter() - t0
 
 
-def pmc_traffic_bytes(kernel_substrings, frames_per_launch):
+def pmc_traffic_bytes(kernel_substrings, frames_per_launch, keypoints):
     """HBM bytes per bench step of the named kernels (= per launch for the matcher) from the committed rocprofv3 PMC passes of this same
     command (profiles/rNN/rocprof_summary.json, written by tools/profile_round.sh: FETCH_SIZE and
     WRITE_SIZE collected in separate passes).  Per /opt/skills/guides/MI355X_MICROARCH.md the
@@ -159,7 +159,7 @@ def pmc_traffic_bytes(kernel_substrings, frames_per_launch):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "rocprof_summary.json")), reverse=True):
         try:
             summ = json.load(open(path))
-            if int(summ.get("frames_per_launch", 0)) != int(frames_per_launch):
+            if int(summ.get("frames_per_launch", 0)) != int(frames_per_launch) or int(summ.get("keypoints_per_image", 2000)) != int(keypoints):
                 continue
             total = 0.0
             steps = [v["FETCH_SIZE"]["launches"] for k, v in summ["pmc_fetch"].items() if "stereo_match" in k][0]
@@ -293,9 +293,9 @@ def main():
     gbps_match = B * bytes_match / (ms_match * 1e-3) / 1e9
     gbps_align = B * bytes_align / (ms_align * 1e-3) / 1e9
     fps = world * B * args.steps / elapsed
-    traffic_match, traffic_src = pmc_traffic_bytes(["stereo_match"], B)
+    traffic_match, traffic_src = pmc_traffic_bytes(["stereo_match"], B, N)
     # all search + GN rounds of one step
-    traffic_align, _ = pmc_traffic_bytes(["align_kernel", "gn_kernel"], B)
+    traffic_align, _ = pmc_traffic_bytes(["align_kernel", "gn_kernel"], B, N)
 
     out = {
         "metric": "tracked frames/sec on KITTI-00 stereo (1241x376, ~2k kp); SE(3) vs ref",
@@ -324,7 +324,7 @@ def main():
             "aligner_success_fraction": status_ok,
         },
         "roofline": {
-            "kernel": "stereo_match5_kernel<2> (the kernel BASELINE.json north_star prices; matcher + fused adaptor / triangulator epilogue)",
+            "kernel": "stereo_match5_kernel<%d> (the kernel BASELINE.json north_star prices; matcher + fused adaptor / triangulator epilogue)" % (1 if N <= 1024 else 2),
             "bound": "hbm",
             "achieved": gbps_match,
             "peak": HBM_PEAK_GBPS,
