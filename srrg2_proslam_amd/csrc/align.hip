@@ -124,107 +124,146 @@ __device__ __forceinline__ int hamming_regs(const au32x4& a0, const au32x4& a1, 
 struct PoseRegs {
   float R00, R01, R02, t0, R10, R11, R12, t1, R20, R21, R22, t2;
 };
-__device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const PoseRegs& X, const float4 z, const float4 p,
-                                             const float mean_dsp, float* tv, int& cls) {
+// factor_terms runs its arithmetic on every lane; a pose with a NaN / inf entry (every correspondence is then
+// invalid: no term, no update) is kept away from it by its callers
+__device__ __forceinline__ bool pose_is_finite(const PoseRegs& X) {
+  const float s = ((((X.R00 + X.R01) + (X.R02 + X.t0)) + ((X.R10 + X.R11) + (X.R12 + X.t1))) + ((X.R20 + X.R21) + (X.R22 + X.t2)));
+  return (s - s) == 0.0f;
+}
+__device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const PoseRegs& X, const float4 z, const float4 p_in,
+                                             const float mean_dsp, const bool active, float* tv, int& cls) {
+  // Straight-line on purpose: with `tv` live out of nested divergent branches the compiler re-materialises
+  // all 29 zeros at every nesting level (~150 v_mov per call, as many as the arithmetic).  A correspondence
+  // that is inactive (slot past the end) or invalid (behind the camera / outside the image) runs the same
+  // arithmetic on a harmless point with zero information: every term is then +-0, which leaves the ordered
+  // sums bit-identical to adding +0 (they start at +0 and x + (-0) = x).  Valid correspondences execute
+  // exactly the operations of the sequential evaluation.
   const float R00 = X.R00, R01 = X.R01, R02 = X.R02, t0 = X.t0;
   const float R10 = X.R10, R11 = X.R11, R12 = X.R12, t1 = X.t1;
   const float R20 = X.R20, R21 = X.R21, R22 = X.R22, t2 = X.t2;
   const float fx = a.fx, fy = a.fy, cx = a.cx, cy = a.cy;
   const int dim = a.factor_type;
-  cls = 0;
-    const float px = p.x, py = p.y, pz = p.z;
-    // explicit fused multiply-adds (one rounding each): the factor arithmetic is defined this way on
-    // both sides of the parity test
+  // explicit fused multiply-adds (one rounding each): the factor arithmetic is defined this way on
+  // both sides of the parity test
+  bool valid;
+  {
+    const float px = p_in.x, py = p_in.y, pz = p_in.z;
     const float pcx = fmaf(R02, pz, fmaf(R01, py, fmaf(R00, px, t0)));
     const float pcy = fmaf(R12, pz, fmaf(R11, py, fmaf(R10, px, t1)));
     const float pcz = fmaf(R22, pz, fmaf(R21, py, fmaf(R20, px, t2)));
     const float hx  = fmaf(fx, pcx, cx * pcz);
     const float hy  = fmaf(fy, pcy, cy * pcz);
-    const float hz  = pcz;
-    bool valid      = hz > 0.0f;
-    float iz = 0.0f, u_pred = 0.0f, v_pred = 0.0f;
-    if (valid) {
-      iz     = 1.0f / hz;
-      u_pred = hx * iz;
-      v_pred = hy * iz;
-      valid  = !(u_pred < 0.0f || u_pred > a.image_cols || v_pred < 0.0f || v_pred > a.image_rows);
+    const float iz  = 1.0f / pcz;
+    const float u_pred = hx * iz, v_pred = hy * iz;
+    valid = active && pcz > 0.0f && !(u_pred < 0.0f || u_pred > a.image_cols || v_pred < 0.0f || v_pred > a.image_rows);
+  }
+  // the harmless stand-in: the point (0, 0, 1) seen with zero information and zero error
+  const float px = valid ? p_in.x : 0.0f, py = valid ? p_in.y : 0.0f, pz = valid ? p_in.z : 1.0f;
+  const float pcx = fmaf(R02, pz, fmaf(R01, py, fmaf(R00, px, t0)));
+  const float pcy = fmaf(R12, pz, fmaf(R11, py, fmaf(R10, px, t1)));
+  const float pcz = fmaf(R22, pz, fmaf(R21, py, fmaf(R20, px, t2)));
+  const float hx  = fmaf(fx, pcx, cx * pcz);
+  const float hy  = fmaf(fy, pcy, cy * pcz);
+  const float hz  = pcz;
+  const float iz     = valid ? 1.0f / hz : 0.0f;
+  const float u_pred = hx * iz;
+  const float v_pred = hy * iz;
+  float e0 = u_pred - z.x, e1 = v_pred - z.y, e2 = 0.0f;
+  float hrx = hx;
+  if (dim == PRS_FACTOR_STEREO) {
+    hrx = hx + a.baseline_left_in_right_px[0];
+    e2  = fmaf(hrx, iz, -z.z);
+  } else if (dim == PRS_FACTOR_DEPTH) {
+    e2 = hz - z.z;
+  }
+  e0 = valid ? e0 : 0.0f;
+  e1 = valid ? e1 : 0.0f;
+  e2 = valid ? e2 : 0.0f;
+  float wt = 1.0f;
+  if (dim == PRS_FACTOR_STEREO && a.enable_inverse_depth_weighting) {
+    wt = (z.x - z.z) / mean_dsp;
+    if (wt < 0.01f) {
+      wt = 0.01f;
     }
-    if (!valid) {
-      cls = 2;
-    } else {
-      float e0 = u_pred - z.x, e1 = v_pred - z.y, e2 = 0.0f;
-      float hrx = hx;
-      if (dim == PRS_FACTOR_STEREO) {
-        hrx = hx + a.baseline_left_in_right_px[0];
-        e2  = fmaf(hrx, iz, -z.z);
-      } else if (dim == PRS_FACTOR_DEPTH) {
-        e2 = hz - z.z;
-      }
-      float wt = 1.0f;
-      if (dim == PRS_FACTOR_STEREO && a.enable_inverse_depth_weighting) {
-        wt = (z.x - z.z) / mean_dsp;
-        if (wt < 0.01f) {
-          wt = 0.01f;
-        }
-        if (wt > 1.0f) {
-          wt = 1.0f;
-        }
-      }
-      const float ax = 2.0f * px, ay = 2.0f * py, az = 2.0f * pz;
-      const float Rm[3][3] = {{R00, R01, R02}, {R10, R11, R12}, {R20, R21, R22}};
-      float Jp[3][6];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        Jp[r][0] = Rm[r][0] * wt;
-        Jp[r][1] = Rm[r][1] * wt;
-        Jp[r][2] = Rm[r][2] * wt;
-        Jp[r][3] = fmaf(Rm[r][2], ay, -(Rm[r][1] * az));
-        Jp[r][4] = fmaf(Rm[r][0], az, -(Rm[r][2] * ax));
-        Jp[r][5] = fmaf(Rm[r][1], ax, -(Rm[r][0] * ay));
-      }
-      const float hx_iz2 = (hx * iz) * iz;
-      const float hy_iz2 = (hy * iz) * iz;
-      const float hr_iz2 = (hrx * iz) * iz;
-      float J0[6], J1[6], J2[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const float a0 = fmaf(fx, Jp[0][k], cx * Jp[2][k]);
-        const float a1 = fmaf(fy, Jp[1][k], cy * Jp[2][k]);
-        const float a2 = Jp[2][k];
-        J0[k]          = fmaf(a0, iz, -(hx_iz2 * a2));
-        J1[k]          = fmaf(a1, iz, -(hy_iz2 * a2));
-        J2[k]          = dim == PRS_FACTOR_STEREO ? fmaf(a0, iz, -(hr_iz2 * a2)) : (dim == PRS_FACTOR_DEPTH ? a2 : 0.0f);
-      }
-      // Omega = diag(info) * scale(moving point) (aligner_slice_processor_projective.cpp:46-56)
-      const float s = p.w;
-      float o0 = a.diagonal_info[0] * s;
-      float o1 = a.diagonal_info[1] * s;
-      float o2 = dim == PRS_FACTOR_MONO ? 0.0f : a.diagonal_info[2] * s;
-      float chi = fmaf(o2 * e2, e2, fmaf(o1 * e1, e1, (o0 * e0) * e0));
-      if (chi > a.chi_threshold) {  // saturated kernel
-        const float scale = a.chi_threshold / chi;
-        o0 *= scale;
-        o1 *= scale;
-        o2 *= scale;
-        chi = a.chi_threshold;
-        cls = 1;
-      } else {
-        cls = 0;
-        tv[27] = chi;
-      }
-      tv[28] = chi;
-      int t  = 0;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        const float j0 = J0[r] * o0, j1 = J1[r] * o1, j2 = J2[r] * o2;
-#pragma unroll
-        for (int k = r; k < 6; ++k) {
-          tv[t++] = fmaf(j2, J2[k], fmaf(j1, J1[k], j0 * J0[k]));
-        }
-        tv[21 + r] = fmaf(j2, e2, fmaf(j1, e1, j0 * e0));
-      }
+    if (wt > 1.0f) {
+      wt = 1.0f;
     }
-
+    wt = valid ? wt : 1.0f;
+  }
+  const float ax = 2.0f * px, ay = 2.0f * py, az = 2.0f * pz;
+  const float Rm[3][3] = {{R00, R01, R02}, {R10, R11, R12}, {R20, R21, R22}};
+  // From here on the six columns of the Jacobian rows travel as three float pairs: the element-wise
+  // steps map onto v_pk_mul_f32 / v_pk_fma_f32 (IEEE per lane, same results as the scalar forms).
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  auto fma2 = [](f2 x, f2 y, f2 z2) -> f2 { return __builtin_elementwise_fma(x, y, z2); };
+  f2 Jp[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    Jp[r][0] = f2{Rm[r][0] * wt, Rm[r][1] * wt};
+    Jp[r][1] = f2{Rm[r][2] * wt, fmaf(Rm[r][2], ay, -(Rm[r][1] * az))};
+    Jp[r][2] = f2{fmaf(Rm[r][0], az, -(Rm[r][2] * ax)), fmaf(Rm[r][1], ax, -(Rm[r][0] * ay))};
+  }
+  const float hx_iz2 = (hx * iz) * iz;
+  const float hy_iz2 = (hy * iz) * iz;
+  const float hr_iz2 = (hrx * iz) * iz;
+  const f2 fx2 = {fx, fx}, fy2 = {fy, fy}, cx2 = {cx, cx}, cy2 = {cy, cy}, iz2 = {iz, iz};
+  const f2 hx2 = {hx_iz2, hx_iz2}, hy2 = {hy_iz2, hy_iz2}, hr2 = {hr_iz2, hr_iz2};
+  f2 J0[3], J1[3], J2[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const f2 a0 = fma2(fx2, Jp[0][k], cx2 * Jp[2][k]);
+    const f2 a1 = fma2(fy2, Jp[1][k], cy2 * Jp[2][k]);
+    const f2 a2 = Jp[2][k];
+    J0[k]       = fma2(a0, iz2, -(hx2 * a2));
+    J1[k]       = fma2(a1, iz2, -(hy2 * a2));
+    J2[k]       = dim == PRS_FACTOR_STEREO ? fma2(a0, iz2, -(hr2 * a2)) : (dim == PRS_FACTOR_DEPTH ? a2 : f2{0.0f, 0.0f});
+  }
+  // Omega = diag(info) * scale(moving point) (aligner_slice_processor_projective.cpp:46-56)
+  const float s = valid ? p_in.w : 0.0f;
+  float o0 = a.diagonal_info[0] * s;
+  float o1 = a.diagonal_info[1] * s;
+  float o2 = dim == PRS_FACTOR_MONO ? 0.0f : a.diagonal_info[2] * s;
+  float chi = fmaf(o2 * e2, e2, fmaf(o1 * e1, e1, (o0 * e0) * e0));
+  // saturated kernel: o *= threshold / chi (a factor of exactly 1 leaves the unsaturated weights untouched)
+  const bool saturated = valid && chi > a.chi_threshold;
+  const float ratio    = a.chi_threshold / chi;
+  const float scale    = saturated ? ratio : 1.0f;
+  o0 *= scale;
+  o1 *= scale;
+  o2 *= scale;
+  chi    = saturated ? a.chi_threshold : chi;
+  cls    = !active ? 3 : (!valid ? 2 : (saturated ? 1 : 0));
+  tv[27] = saturated ? 0.0f : chi;
+  tv[28] = chi;
+  const f2 o02 = {o0, o0}, o12 = {o1, o1}, o22 = {o2, o2}, e02 = {e0, e0}, e12 = {e1, e1}, e22 = {e2, e2};
+  f2 j0[3], j1[3], j2[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    j0[k] = J0[k] * o02;
+    j1[k] = J1[k] * o12;
+    j2[k] = J2[k] * o22;
+    const f2 bk    = fma2(j2[k], e22, fma2(j1[k], e12, j0[k] * e02));
+    tv[21 + 2 * k] = bk.x;
+    tv[22 + 2 * k] = bk.y;
+  }
+  // the upper triangle of J^T Omega J row by row; the full pair is computed where the triangle starts on
+  // the second element of a pair (its first element is the mirrored entry and is dropped)
+  int t = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    const float a0 = (r & 1) ? j0[r >> 1].y : j0[r >> 1].x;
+    const float a1 = (r & 1) ? j1[r >> 1].y : j1[r >> 1].x;
+    const float a2 = (r & 1) ? j2[r >> 1].y : j2[r >> 1].x;
+    const f2 r0 = {a0, a0}, r1 = {a1, a1}, r2 = {a2, a2};
+#pragma unroll
+    for (int k = r >> 1; k < 3; ++k) {
+      const f2 h = fma2(r2, J2[k], fma2(r1, J1[k], r0 * J0[k]));
+      if (2 * k >= r) {
+        tv[t++] = h.x;
+      }
+      tv[t++] = h.y;
+    }
+  }
 }
 
 // SPLIT = the search half of the split pipeline (mode kModeSplitSearch): a compile-time flag, so the
@@ -931,22 +970,22 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
     {
       const PoseRegs pose  = {sh.X[0], sh.X[1], sh.X[2], sh.X[3], sh.X[4], sh.X[5], sh.X[6], sh.X[7], sh.X[8], sh.X[9], sh.X[10], sh.X[11]};
       const float mean_dsp = sh.mean_disp;
+      // a pose with a NaN / inf entry: every correspondence is invalid, all sums stay zero
+      const bool pose_ok   = __all(pose_is_finite(pose));  // (uniform by construction; __all makes the branch scalar)
       if (tid == 0) {
-        sh.n_inl = sh.n_out = sh.n_inv = 0;
+        sh.n_inl = sh.n_out = 0;
+        sh.n_inv = pose_ok ? 0 : nc;
       }
       float run = 0.0f;  // lanes 0..28 of wave 0: running sum of their term in correspondence order
       __syncthreads();
-      for (int c0 = 0; c0 < nc; c0 += T) {
+      for (int c0 = 0; c0 < nc && pose_ok; c0 += T) {
         ALIGN_MARK();
         const int c = c0 + tid;
         float tv[kTerms];
-#pragma unroll
-        for (int t = 0; t < kTerms; ++t) {
-          tv[t] = 0.0f;
-        }
+        int cls;
+        const int cc = c < nc ? c : 0;
+        factor_terms(g.a, pose, cfix[cc], cmov[cc], mean_dsp, c < nc, tv, cls);
         if (c < nc) {
-          int cls;
-          factor_terms(g.a, pose, cfix[c], cmov[c], mean_dsp, tv, cls);
           atomicAdd(cls == 0 ? &sh.n_inl : (cls == 1 ? &sh.n_out : &sh.n_inv), 1);
         }
 #pragma unroll
@@ -1234,24 +1273,21 @@ __global__ __launch_bounds__(kGnThreads, 5) void gn_kernel(const AlignArgs g) {
       continue;
     }
     const PoseRegs pose = {sh.X[0], sh.X[1], sh.X[2], sh.X[3], sh.X[4], sh.X[5], sh.X[6], sh.X[7], sh.X[8], sh.X[9], sh.X[10], sh.X[11]};
+    // a pose with a NaN / inf entry: every correspondence is invalid, all sums stay zero
+    const bool pose_ok  = __all(pose_is_finite(pose));  // (uniform by construction; __all makes the branch scalar)
     if (tid == 0) {
-      sh.n_inl = sh.n_out = sh.n_inv = 0;
+      sh.n_inl = sh.n_out = 0;
+      sh.n_inv = pose_ok ? 0 : nc;
     }
     float run = 0.0f;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) {
       const int c0 = k * kGnThreads;
-      if (c0 < nc) {
+      if (c0 < nc && pose_ok) {
         float tv[kTerms];
-#pragma unroll
-        for (int t = 0; t < kTerms; ++t) {
-          tv[t] = 0.0f;
-        }
-        int cls = 3;
-        if (c0 + tid < nc) {
-          factor_terms(g.a, pose, zf[k], pm[k], mean_dsp, tv, cls);
-        }
+        int cls;
+        factor_terms(g.a, pose, zf[k], pm[k], mean_dsp, c0 + tid < nc, tv, cls);
         {
           // inlier / outlier / invalid counts: one LDS atomic per wave and class instead of one per lane
           const uint64_t m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
