@@ -1073,14 +1073,14 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
         X[i] = sh.X[i];
       }
       gn_step(H, b, g.a.damping, X);
-      bool same = true;
+      uint32_t changed_bits = 0;  // (bitwise, no short-circuit: sixteen compares would be sixteen branches)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        same    = same && (__float_as_uint(X[i]) == __float_as_uint(sh.X[i]));
+        changed_bits |= __float_as_uint(X[i]) ^ __float_as_uint(sh.X[i]);
         sh.X[i] = X[i];
       }
       // fixed point: finder latched + pose reproduced bit-for-bit => every later iteration repeats this one
-      sh.decision = (g.a.stop_at_fixed_point && same && sh.converged) ? 1 : 0;
+      sh.decision = (g.a.stop_at_fixed_point && changed_bits == 0u && sh.converged) ? 1 : 0;
     }
     __syncthreads();
     ALIGN_ACC(acc_solve);
@@ -1369,13 +1369,13 @@ __global__ __launch_bounds__(kGnThreads, 5) void gn_kernel(const AlignArgs g) {
         X[i] = sh.X[i];
       }
       gn_step(H, b, g.a.damping, X);
-      bool same = true;
+      uint32_t changed_bits = 0;  // (bitwise, no short-circuit: sixteen compares would be sixteen branches)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        same    = same && (__float_as_uint(X[i]) == __float_as_uint(sh.X[i]));
+        changed_bits |= __float_as_uint(X[i]) ^ __float_as_uint(sh.X[i]);
         sh.X[i] = X[i];
       }
-      sh.stop = (g.a.stop_at_fixed_point && same && sh.converged) ? 1 : 0;
+      sh.stop = (g.a.stop_at_fixed_point && changed_bits == 0u && sh.converged) ? 1 : 0;
     }
     __syncthreads();
     ++it_align;

@@ -148,6 +148,7 @@ __device__ __forceinline__ void tnq2t(const float* v6, float* T) {
 __device__ __forceinline__ bool gn_step(const float* H, const float* b, float damping, float* X) {
   // dense Cholesky with fused multiply-subtracts and one reciprocal per pivot
   float L[6][6], inv[6];
+  bool ok = true;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     float s = H[6 * j + j] + damping;
@@ -157,9 +158,7 @@ __device__ __forceinline__ bool gn_step(const float* H, const float* b, float da
         s = fmaf(-L[j][k], L[j][k], s);
       }
     }
-    if (!(s > 0.0f)) {
-      return false;
-    }
+    ok      = ok && s > 0.0f;  // (no early exit: a failed pivot only poisons values that are dropped below)
     L[j][j] = sqrtf(s);
     inv[j]  = 1.0f / L[j][j];
 #pragma unroll
@@ -204,9 +203,9 @@ __device__ __forceinline__ bool gn_step(const float* H, const float* b, float da
   se3_mul(X, D, Xn);
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    X[i] = Xn[i];
+    X[i] = ok ? Xn[i] : X[i];
   }
-  return true;
+  return ok;
 }
 
 }  // namespace prs
