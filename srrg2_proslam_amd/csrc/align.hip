@@ -1149,13 +1149,13 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
 // One 256-thread workgroup per frame runs aligner iterations (linearize + damped GN step, with the
 // finder's "nothing new" bookkeeping in between) until the finder needs a projective search again or
 // max_iterations is reached.  The per-correspondence operands written by the search kernel sit in
-// registers (<= 4 per thread), so a workgroup needs only the 29 x 256 term matrix in LDS and many
+// registers (<= 8 per thread), so a workgroup needs only the 29 x THREADS term matrix in LDS and many
 // frames share a CU.  Arithmetic and summation order are those of the fused kernel.
+// Instantiated for 128 threads x {4, 6, 8} correspondences per thread (the default) and 256 x {2, 3, 4}.
+// The row stride of the term matrix is THREADS + 4 floats, so that the 29 summing lanes (one row each,
+// 16-B reads) start 16 B apart in the bank space instead of all on the same four banks.
 constexpr int kGnThreads = 256;
-constexpr int kGnSlots   = 4;  // most correspondences per thread: max_fixed <= 1024 (the kernel is instantiated for 2, 3 and 4)
-// row stride of the term matrix in floats: +4 so that the 29 summing lanes (one row each, 16-B reads)
-// start 16 B apart in the bank space instead of all on the same four banks
-constexpr int kGnRow     = kGnThreads + 4;
+constexpr int kGnSlots   = 4;  // max_fixed <= 1024 either way
 
 struct GnShared {
   float X[16], T[16], Tprev[16], H[36], b[6];
@@ -1164,21 +1164,22 @@ struct GnShared {
   int converged, need_search, n_inl, n_out, n_inv, stop, flags;
 };
 
-// SLOTS = correspondences per thread the instantiation keeps in registers (ceil(max_fixed / 256))
-template <int SLOTS>
-__global__ __launch_bounds__(kGnThreads, 5) void gn_kernel(const AlignArgs g) {
+// THREADS per frame; SLOTS = correspondences per thread the instantiation keeps in registers (ceil(max_fixed / THREADS))
+template <int THREADS, int SLOTS>
+__global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(const AlignArgs g) {
+  constexpr int kRow = THREADS + 4;  // row stride of the term matrix (see kGnRow)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid   = threadIdx.x;
   const int frame = blockIdx.x;
   // the single-wave phases (ordered sums, 6x6 solve) run on a different wave -- hence a different
   // SIMD -- from frame to frame, so that the workgroups sharing a CU do not queue them on one SIMD
-  const int stid  = tid - 64 * (frame & (kGnThreads / 64 - 1));
+  const int stid  = tid - 64 * (frame & (THREADS / 64 - 1));
   FrameCtl* ctl   = g.ctl + frame;
   if (ctl->done || ctl->need_search) {
     return;  // finished, or waiting for the search kernel (block-uniform)
   }
   float* terms             = reinterpret_cast<float*>(smem);
-  GnShared& sh             = *reinterpret_cast<GnShared*>(smem + kTerms * kGnRow * sizeof(float));
+  GnShared& sh             = *reinterpret_cast<GnShared*>(smem + kTerms * kRow * sizeof(float));
   prs_pcf_state* gstate    = g.b.state + frame;
   prs_align_result* gres   = g.b.result + frame;
   const float4* gops       = g.ops + (size_t) frame * (size_t) g.max_fixed * 2;
@@ -1202,7 +1203,7 @@ __global__ __launch_bounds__(kGnThreads, 5) void gn_kernel(const AlignArgs g) {
     sh.chi_tot     = gres->chi_total;
     sh.stop        = 0;
   }
-  for (int i = tid; i < 36; i += kGnThreads) {
+  for (int i = tid; i < 36; i += THREADS) {
     sh.H[i] = gres->H[i];
   }
   if (tid < 6) {
@@ -1212,7 +1213,7 @@ __global__ __launch_bounds__(kGnThreads, 5) void gn_kernel(const AlignArgs g) {
   float4 zf[SLOTS], pm[SLOTS];
 #pragma unroll
   for (int k = 0; k < SLOTS; ++k) {
-    const int c = k * kGnThreads + tid;
+    const int c = k * THREADS + tid;
     zf[k]       = c < nc ? gops[2 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
     pm[k]       = c < nc ? gops[2 * c + 1] : make_float4(0.f, 0.f, 1.f, 1.f);
   }
@@ -1258,7 +1259,7 @@ __global__ __launch_bounds__(kGnThreads, 5) void gn_kernel(const AlignArgs g) {
         sh.n_inl = sh.n_out = sh.n_inv = 0;
         sh.chi_in = sh.chi_tot = 0.0f;
       }
-      for (int i = tid; i < 36; i += kGnThreads) {
+      for (int i = tid; i < 36; i += THREADS) {
         sh.H[i] = 0.0f;
       }
       if (tid < 6) {
@@ -1283,7 +1284,7 @@ __global__ __launch_bounds__(kGnThreads, 5) void gn_kernel(const AlignArgs g) {
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) {
-      const int c0 = k * kGnThreads;
+      const int c0 = k * THREADS;
       if (c0 < nc && pose_ok) {
         float tv[kTerms];
         int cls;
@@ -1299,12 +1300,12 @@ __global__ __launch_bounds__(kGnThreads, 5) void gn_kernel(const AlignArgs g) {
         }
 #pragma unroll
         for (int t = 0; t < kTerms; ++t) {
-          terms[t * kGnRow + tid] = tv[t];
+          terms[t * kRow + tid] = tv[t];
         }
         __syncthreads();
         if (stid >= 0 && stid < kTerms) {
-          const int cnt      = nc - c0 < kGnThreads ? nc - c0 : kGnThreads;
-          const float4* row4 = reinterpret_cast<const float4*>(terms + stid * kGnRow);
+          const int cnt      = nc - c0 < THREADS ? nc - c0 : THREADS;
+          const float4* row4 = reinterpret_cast<const float4*>(terms + stid * kRow);
           float4 n0 = row4[0], n1 = row4[1], n2 = row4[2], n3 = row4[3];
           for (int j = 0; j < cnt; j += 16) {
             const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
@@ -1391,7 +1392,7 @@ __global__ __launch_bounds__(kGnThreads, 5) void gn_kernel(const AlignArgs g) {
     gstate->local_map_in_sensor[tid]          = sh.T[tid];
     gstate->local_map_in_sensor_previous[tid] = sh.Tprev[tid];
   }
-  for (int i = tid; i < 36; i += kGnThreads) {
+  for (int i = tid; i < 36; i += THREADS) {
     gres->H[i] = sh.H[i];
   }
   if (tid < 6) {
@@ -1615,7 +1616,11 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
                         ? align_kernel<kSearchThreads, true, PRS_SEARCH_SQUARE>
                         : (finder->search_type == PRS_SEARCH_RHOMBUS ? align_kernel<kSearchThreads, true, PRS_SEARCH_RHOMBUS>
                                                                      : align_kernel<kSearchThreads, true, PRS_SEARCH_KDTREE>));
-  const size_t lds_gn = (size_t) kTerms * kGnRow * sizeof(float) + sizeof(GnShared) + 16;
+  // two waves per frame (eight frames resident per CU: the kernel is bound by its single-wave phases and by
+  // instruction issue, more independent frames fill the idle slots); PRS_GN_THREADS=256 selects the four-wave form
+  const char* gnt_env  = getenv("PRS_GN_THREADS");
+  const int gn_threads = (max_fixed <= 128 * 8 && !(gnt_env && atoi(gnt_env) == 256)) ? 128 : kGnThreads;
+  const size_t lds_gn  = (size_t) kTerms * (gn_threads + 4) * sizeof(float) + sizeof(GnShared) + 16;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(skernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_search);
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_align_batch_run attribute");
@@ -1630,12 +1635,20 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
     for (int r = 0; r < rounds_left; ++r) {
       (void) hipMemsetAsync(g.pending, 0, sizeof(int), stream);
       hipLaunchKernelGGL(skernel, dim3(batch->batch), dim3(kSearchThreads), lds_search, stream, gs);
-      if (max_fixed <= 2 * kGnThreads) {
-        hipLaunchKernelGGL(gn_kernel<2>, dim3(batch->batch), dim3(kGnThreads), lds_gn, stream, g);
+      if (gn_threads == 128) {
+        if (max_fixed <= 4 * 128) {
+          hipLaunchKernelGGL((gn_kernel<128, 4>), dim3(batch->batch), dim3(128), lds_gn, stream, g);
+        } else if (max_fixed <= 6 * 128) {
+          hipLaunchKernelGGL((gn_kernel<128, 6>), dim3(batch->batch), dim3(128), lds_gn, stream, g);
+        } else {
+          hipLaunchKernelGGL((gn_kernel<128, 8>), dim3(batch->batch), dim3(128), lds_gn, stream, g);
+        }
+      } else if (max_fixed <= 2 * kGnThreads) {
+        hipLaunchKernelGGL((gn_kernel<kGnThreads, 2>), dim3(batch->batch), dim3(kGnThreads), lds_gn, stream, g);
       } else if (max_fixed <= 3 * kGnThreads) {
-        hipLaunchKernelGGL(gn_kernel<3>, dim3(batch->batch), dim3(kGnThreads), lds_gn, stream, g);
+        hipLaunchKernelGGL((gn_kernel<kGnThreads, 3>), dim3(batch->batch), dim3(kGnThreads), lds_gn, stream, g);
       } else {
-        hipLaunchKernelGGL(gn_kernel<4>, dim3(batch->batch), dim3(kGnThreads), lds_gn, stream, g);
+        hipLaunchKernelGGL((gn_kernel<kGnThreads, 4>), dim3(batch->batch), dim3(kGnThreads), lds_gn, stream, g);
       }
       ++total;
     }
