@@ -38,9 +38,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=7680,
-                    help="independent sequences (frames per step) per GPU; 7680 = 30 per CU, a multiple of the 1 / 3 / 5 workgroups "
-                         "per CU the matcher / search / GN kernels keep resident (no partial last wave)")
+    ap.add_argument("--batch", type=int, default=18432,
+                    help="independent sequences (frames per step) per GPU; 18432 = 72 per CU, a multiple of the 1 / 3 / 8 workgroups "
+                         "per CU the matcher / search / GN kernels keep resident (no partial last wave); the five search + GN "
+                         "rounds of a step each end in a 4-byte readback, which larger batches amortise")
     ap.add_argument("--keypoints", type=int, default=2000, help="keypoints per image (KITTI config: ~2000)")
     ap.add_argument("--moving", type=int, default=2000, help="local-map points per frame")
     ap.add_argument("--max-fixed", type=int, default=896, help="LDS sizing bound on stereo matches per frame")

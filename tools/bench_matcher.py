@@ -17,7 +17,7 @@ from srrg2_proslam_amd import configs, ops, synthetic as syn  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=7680)
+    ap.add_argument("--batch", type=int, default=18432)
     ap.add_argument("--keypoints", type=int, default=2000)
     ap.add_argument("--unique", type=int, default=32)
     ap.add_argument("--iters", type=int, default=20)
