@@ -65,6 +65,7 @@ struct FrameCtl {
   int executed;
   int flags;        // OR of finder warnings over the frame loop
   int n_inl, n_out, n_inv;
+  int db_ready;     // the lattice of this frame's fixed cloud is in AlignArgs::dbcache (built by an earlier search launch)
 };
 constexpr int kModeSplitSearch = 100;  // internal: align_kernel<512> performing ONE finder.compute() for frames that wait for it
 constexpr int kSearchThreads   = 512;
@@ -81,6 +82,8 @@ struct AlignArgs {
   float4* ops;     // split pipeline: [batch][max_fixed][2] per-correspondence operands (fixed measurement, moving point)
   FrameCtl* ctl;   // split pipeline: [batch]
   int* pending;    // split pipeline: number of frames the last GN launch left unfinished
+  unsigned char* dbcache;  // split pipeline: [batch][db_blob] image of the LDS lattice (db | inv | cellstart)
+  uint32_t db_blob;        // bytes of that image (multiple of 16)
   unsigned long long* stamps;  // diagnostic: [batch][16] accumulated shader clocks per phase (NULL = off)
   int max_fixed;   // LDS capacity in fixed points (frames with more are rejected loudly)
   uint32_t off_db, off_inv, off_cellstart, off_cfix, off_cmov, off_sh;  // persistent for the whole frame loop
@@ -500,6 +503,17 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
 
         SUB_MARK();
         // -- the lattice lives in LDS: (re)build it on the first search of a launch and after every reset
+        if (!db_built && split_search && g.dbcache && ctl->db_ready) {
+          // the lattice only depends on the fixed cloud: the first search launch of a frame built it and left
+          // an image of the three LDS arrays in global memory; later launches copy it back (11 kB, coalesced)
+          const uint4* src = reinterpret_cast<const uint4*>(g.dbcache + (size_t) frame * g.db_blob);
+          uint4* dst       = reinterpret_cast<uint4*>(smem + g.off_db);
+          for (int i = tid; i < (int) (g.db_blob >> 4); i += T) {
+            dst[i] = src[i];
+          }
+          __syncthreads();
+          db_built = true;
+        }
         if (!db_built) {
           // _initializeDatabase (square_impl.cpp:8-31).  The reference scans a row-sorted vector; its
           // scan position only matters for tie-breaks ("first wins"), so every fixed point gets its
@@ -627,6 +641,16 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
           }
           __syncthreads();
           db_built = true;
+          if (split_search && g.dbcache) {
+            const uint4* src = reinterpret_cast<const uint4*>(smem + g.off_db);
+            uint4* dst       = reinterpret_cast<uint4*>(g.dbcache + (size_t) frame * g.db_blob);
+            for (int i = tid; i < (int) (g.db_blob >> 4); i += T) {
+              dst[i] = src[i];
+            }
+            if (tid == 0) {
+              ctl->db_ready = 1;  // read by the NEXT search launch of this frame
+            }
+          }
         }
 
         SUB_ACC(acc_db);
@@ -730,50 +754,61 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
               cb1 = cb1 > colmax ? colmax : cb1;
               if (r0 <= r1 && cb0 <= cb1) {
                 const int cx0 = cb0 >> g.cell_sx, cx1 = cb1 >> g.cell_sx;
+                // whether the lattice entry e lies inside the search pattern of this query
+                auto accepts = [&](const uint2 e) -> bool {
+                  const int drow = (int) (int16_t) (e.x & 0xffffu);
+                  const int dcol = (int) (int16_t) (e.x >> 16);
+                  if (!lattice) {
+                    // exact radius query (kdtree_impl.cpp:39-50)
+                    const float2 c = fuv[e.y & 0xffffu];
+                    const float du = c.x - u, dv = c.y - v;
+                    return !(du * du + dv * dv > r2f);
+                  } else if (stype == PRS_SEARCH_CIRCLE && circle_exact) {
+                    // rows [row - r, row + r] (circle_impl.cpp:25-26,40-47) and col - w < dcol < col + w with
+                    // w = int(sqrt(r^2 - h^2) + 1) (:51-56) is |dc| <= isqrt(r^2 - h^2), i.e. the integer test
+                    // dc^2 + h^2 <= r^2 (which also implies |h| <= r): no width table, no row compare
+                    const int h = drow - row, dc = dcol - col;
+                    return dc * dc + h * h <= rad2;
+                  } else if (drow < rmin || drow >= rmax) {
+                    return false;  // outside the scanned rows (circle_impl.cpp:40-47)
+                  } else if (stype == PRS_SEARCH_SQUARE) {
+                    return dcol > cmin && dcol < cmax;  // square_impl.cpp:80
+                  } else if (stype == PRS_SEARCH_CIRCLE) {
+                    const int h     = drow - row;
+                    const int li    = h + rad;
+                    const int width = li < g.lut_cap ? (int) lut[li] : isqrt_exact(rad * rad - h * h) + 1;
+                    return dcol > col - width && dcol < col + width;  // circle_impl.cpp:56
+                  } else {
+                    int width = (int) (int16_t) (drow - rmin + 1);  // rhombus_impl.cpp:49-52
+                    if (width > (int) (int16_t) rad) {
+                      width = (int) (int16_t) (rmax - drow);
+                    }
+                    return dcol > col - width && dcol < col + width;
+                  }
+                };
+                auto score = [&](const uint2 e) {
+                  const int fi     = (int) (e.y & 0xffffu);
+                  const uint32_t d = (uint32_t) hamming_regs(fdesc[2 * fi], fdesc[2 * fi + 1], q0, q1);
+                  // kdtree_impl.cpp:54: the best is initialised to maximum_descriptor_distance
+                  // best / second best (circle_impl.cpp:64-72) as min / second-min of unique keys
+                  const uint32_t key = (lattice || (float) d < max_dd) ? ((d << 16) | (e.y >> 16)) : kNoneU32;
+                  const uint32_t hi  = key > bestk ? key : bestk;
+                  seck               = hi < seck ? hi : seck;
+                  bestk              = key < bestk ? key : bestk;
+                };
                 for (int cy = r0 >> g.cell_sy; cy <= (r1 >> g.cell_sy); ++cy) {
                   const int seg0 = cellstart[cy * g.cell_ncx + cx0];
                   const int seg1 = cellstart[cy * g.cell_ncx + cx1 + 1];
-                  for (int pos = seg0; pos < seg1; ++pos) {
-                    const uint2 e  = db[pos];
-                    const int drow = (int) (int16_t) (e.x & 0xffffu);
-                    const int dcol = (int) (int16_t) (e.x >> 16);
-                    bool accept;
-                    if (!lattice) {
-                      // exact radius query (kdtree_impl.cpp:39-50)
-                      const float2 c = fuv[e.y & 0xffffu];
-                      const float du = c.x - u, dv = c.y - v;
-                      accept = !(du * du + dv * dv > r2f);
-                    } else if (stype == PRS_SEARCH_CIRCLE && circle_exact) {
-                      // rows [row - r, row + r] (circle_impl.cpp:25-26,40-47) and col - w < dcol < col + w with
-                      // w = int(sqrt(r^2 - h^2) + 1) (:51-56) is |dc| <= isqrt(r^2 - h^2), i.e. the integer test
-                      // dc^2 + h^2 <= r^2 (which also implies |h| <= r): no width table, no row compare
-                      const int h = drow - row, dc = dcol - col;
-                      accept      = dc * dc + h * h <= rad2;
-                    } else if (drow < rmin || drow >= rmax) {
-                      accept = false;  // outside the scanned rows (circle_impl.cpp:40-47)
-                    } else if (stype == PRS_SEARCH_SQUARE) {
-                      accept = dcol > cmin && dcol < cmax;  // square_impl.cpp:80
-                    } else if (stype == PRS_SEARCH_CIRCLE) {
-                      const int h     = drow - row;
-                      const int li    = h + rad;
-                      const int width = li < g.lut_cap ? (int) lut[li] : isqrt_exact(rad * rad - h * h) + 1;
-                      accept          = dcol > col - width && dcol < col + width;  // circle_impl.cpp:56
-                    } else {
-                      int width = (int) (int16_t) (drow - rmin + 1);  // rhombus_impl.cpp:49-52
-                      if (width > (int) (int16_t) rad) {
-                        width = (int) (int16_t) (rmax - drow);
-                      }
-                      accept = dcol > col - width && dcol < col + width;
+                  // two lattice entries per trip (the entry behind the last one of the segment is read but not used)
+                  for (int pos = seg0; pos < seg1; pos += 2) {
+                    const uint2 ea = db[pos], eb = db[pos + 1];
+                    const bool in_a = accepts(ea);
+                    const bool in_b = pos + 1 < seg1 && accepts(eb);
+                    if (in_a) {
+                      score(ea);
                     }
-                    if (accept) {
-                      const int fi     = (int) (e.y & 0xffffu);
-                      const uint32_t d = (uint32_t) hamming_regs(fdesc[2 * fi], fdesc[2 * fi + 1], q0, q1);
-                      // kdtree_impl.cpp:54: the best is initialised to maximum_descriptor_distance
-                      // best / second best (circle_impl.cpp:64-72) as min / second-min of unique keys
-                      const uint32_t key = (lattice || (float) d < max_dd) ? ((d << 16) | (e.y >> 16)) : kNoneU32;
-                      const uint32_t hi  = key > bestk ? key : bestk;
-                      seck               = hi < seck ? hi : seck;
-                      bestk              = key < bestk ? key : bestk;
+                    if (in_b) {
+                      score(eb);
                     }
                   }
                 }
@@ -1434,6 +1469,7 @@ __global__ void split_init_kernel(FrameCtl* ctl, prs_align_result* res, int* pen
     c.executed    = 0;
     c.flags       = 0;
     c.n_inl = c.n_out = c.n_inv = 0;
+    c.db_ready                  = 0;
     ctl[i]                      = c;
     prs_align_result r;
     for (int k = 0; k < 36; ++k) {
@@ -1577,9 +1613,14 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   g.ops     = nullptr;
   g.ctl     = nullptr;
   g.pending = nullptr;
+  g.dbcache = nullptr;
+  g.db_blob = 0;
   hipStream_t stream = ctx_stream(ctx);
   hipError_t e;
-  const bool split = mode == PRS_MODE_ALIGN && !ctx_fused_align(ctx) && max_fixed <= kGnThreads * kGnSlots && !g.stamps;
+  // diagnostic: PRS_STAMPS=1 times the phases of the fused kernel; with PRS_STAMPS_SPLIT=1 the split pipeline
+  // runs instead and the finder phases of every search launch are reported
+  const bool stamps_split = g.stamps && getenv("PRS_STAMPS_SPLIT") != nullptr;
+  const bool split = mode == PRS_MODE_ALIGN && !ctx_fused_align(ctx) && max_fixed <= kGnThreads * kGnSlots && (!g.stamps || stamps_split);
   if (!split) {
     auto kernel = align_kernel<kAlignThreads, false, -1>;
     e           = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
@@ -1610,6 +1651,12 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   AlignArgs gs = g;
   gs.mode      = kModeSplitSearch;
   const size_t lds_search = carve(gs, false);
+  // image of the lattice arrays (contiguous in LDS: db | inv | cellstart), kept per frame between search launches
+  gs.db_blob = align_up16(gs.off_cellstart + ((uint32_t) gs.ncells + 2) * 2) - gs.off_db;
+  gs.dbcache = static_cast<unsigned char*>(ctx_device_scratch_slot(ctx, 0, (size_t) batch->batch * gs.db_blob));
+  if (!gs.dbcache) {
+    return ctx_fail(ctx, PRS_ERR_HIP, "prs_align_batch_run: lattice cache allocation failed");
+  }
   auto skernel = finder->search_type == PRS_SEARCH_CIRCLE
                    ? align_kernel<kSearchThreads, true, PRS_SEARCH_CIRCLE>
                    : (finder->search_type == PRS_SEARCH_SQUARE
@@ -1635,6 +1682,9 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
     for (int r = 0; r < rounds_left; ++r) {
       (void) hipMemsetAsync(g.pending, 0, sizeof(int), stream);
       hipLaunchKernelGGL(skernel, dim3(batch->batch), dim3(kSearchThreads), lds_search, stream, gs);
+      if (stamps_split) {
+        ctx_report_stamps(ctx, batch->batch, 10, "search launch (split): - | - | - | - || lattice build | projection+search | second-best pass | filter | commit");
+      }
       if (gn_threads == 128) {
         if (max_fixed <= 4 * 128) {
           hipLaunchKernelGGL((gn_kernel<128, 4>), dim3(batch->batch), dim3(128), lds_gn, stream, g);
