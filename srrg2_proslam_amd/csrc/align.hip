@@ -1186,7 +1186,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
 // max_iterations is reached.  The per-correspondence operands written by the search kernel sit in
 // registers (<= 8 per thread), so a workgroup needs only the 29 x THREADS term matrix in LDS and many
 // frames share a CU.  Arithmetic and summation order are those of the fused kernel.
-// Instantiated for 128 threads x {4, 6, 8} correspondences per thread (the default) and 256 x {2, 3, 4}.
+// Instantiated for 128 threads x {4, 6, 7, 8} correspondences per thread (the default) and 256 x {2, 3, 4}.
 // The row stride of the term matrix is THREADS + 4 floats, so that the 29 summing lanes (one row each,
 // 16-B reads) start 16 B apart in the bank space instead of all on the same four banks.
 constexpr int kGnThreads = 256;
@@ -1690,6 +1690,8 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
           hipLaunchKernelGGL((gn_kernel<128, 4>), dim3(batch->batch), dim3(128), lds_gn, stream, g);
         } else if (max_fixed <= 6 * 128) {
           hipLaunchKernelGGL((gn_kernel<128, 6>), dim3(batch->batch), dim3(128), lds_gn, stream, g);
+        } else if (max_fixed <= 7 * 128) {
+          hipLaunchKernelGGL((gn_kernel<128, 7>), dim3(batch->batch), dim3(128), lds_gn, stream, g);
         } else {
           hipLaunchKernelGGL((gn_kernel<128, 8>), dim3(batch->batch), dim3(128), lds_gn, stream, g);
         }
