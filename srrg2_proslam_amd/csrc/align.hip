@@ -1197,6 +1197,7 @@ struct GnShared {
   float chi_in, chi_tot;
   unsigned long long it;
   int converged, need_search, n_inl, n_out, n_inv, stop, flags;
+  int pose_ok;  // every entry of X is finite (kept by whoever writes X)
 };
 
 // THREADS per frame; SLOTS = correspondences per thread the instantiation keeps in registers (ceil(max_fixed / THREADS))
@@ -1237,6 +1238,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
     sh.chi_in      = gres->chi_inliers;
     sh.chi_tot     = gres->chi_total;
     sh.stop        = 0;
+    const float* gx = g.b.X + (size_t) frame * 16;
+    const PoseRegs x0 = {gx[0], gx[1], gx[2], gx[3], gx[4], gx[5], gx[6], gx[7], gx[8], gx[9], gx[10], gx[11]};
+    sh.pose_ok        = pose_is_finite(x0) ? 1 : 0;
   }
   for (int i = tid; i < 36; i += THREADS) {
     sh.H[i] = gres->H[i];
@@ -1254,6 +1258,27 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
   }
   __syncthreads();
 
+  // where the lane that sums term `stid` puts its result: H (both triangles), b, chi_inliers, chi_total are
+  // consecutive floats of GnShared
+  int sum_dst0 = 0, sum_dst1 = 0;
+  if (stid >= 0 && stid < kTerms) {
+    if (stid < 21) {
+      int r = 0, firstk = 0;
+      while (stid >= firstk + (6 - r)) {
+        firstk += 6 - r;
+        ++r;
+      }
+      const int kk = r + (stid - firstk);
+      sum_dst0     = 6 * r + kk;
+      sum_dst1     = 6 * kk + r;
+    } else {
+      sum_dst0 = sum_dst1 = 36 + (stid - 21);  // b[0..5], chi_in, chi_tot
+    }
+  }
+  static_assert(offsetof(GnShared, b) == offsetof(GnShared, H) + 36 * sizeof(float) &&
+                  offsetof(GnShared, chi_in) == offsetof(GnShared, b) + 6 * sizeof(float) &&
+                  offsetof(GnShared, chi_tot) == offsetof(GnShared, chi_in) + sizeof(float),
+                "the ordered sums are written through sh.H");
   int it_align = ctl->it_align;
   int executed = ctl->executed;
   bool first   = true;
@@ -1310,7 +1335,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
     }
     const PoseRegs pose = {sh.X[0], sh.X[1], sh.X[2], sh.X[3], sh.X[4], sh.X[5], sh.X[6], sh.X[7], sh.X[8], sh.X[9], sh.X[10], sh.X[11]};
     // a pose with a NaN / inf entry: every correspondence is invalid, all sums stay zero
-    const bool pose_ok  = __all(pose_is_finite(pose));  // (uniform by construction; __all makes the branch scalar)
+    const bool pose_ok  = __builtin_amdgcn_readfirstlane(sh.pose_ok) != 0;
     if (tid == 0) {
       sh.n_inl = sh.n_out = 0;
       sh.n_inv = pose_ok ? 0 : nc;
@@ -1361,22 +1386,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
       }
     }
     if (stid >= 0 && stid < kTerms) {
-      if (stid < 21) {
-        int r = 0, firstk = 0;
-        while (stid >= firstk + (6 - r)) {
-          firstk += 6 - r;
-          ++r;
-        }
-        const int kk     = r + (stid - firstk);
-        sh.H[6 * r + kk] = run;
-        sh.H[6 * kk + r] = run;
-      } else if (stid < 27) {
-        sh.b[stid - 21] = run;
-      } else if (stid == 27) {
-        sh.chi_in = run;
-      } else {
-        sh.chi_tot = run;
-      }
+      sh.H[sum_dst0] = run;
+      sh.H[sum_dst1] = run;
     }
     __syncthreads();
     if (stid == 0) {
@@ -1412,6 +1423,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
         sh.X[i] = X[i];
       }
       sh.stop = (g.a.stop_at_fixed_point && changed_bits == 0u && sh.converged) ? 1 : 0;
+      const PoseRegs xn = {X[0], X[1], X[2], X[3], X[4], X[5], X[6], X[7], X[8], X[9], X[10], X[11]};
+      sh.pose_ok        = pose_is_finite(xn) ? 1 : 0;
     }
     __syncthreads();
     ++it_align;
