@@ -1632,7 +1632,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   hipError_t e;
   // diagnostic: PRS_STAMPS=1 times the phases of the fused kernel; with PRS_STAMPS_SPLIT=1 the split pipeline
   // runs instead and the finder phases of every search launch are reported
-  const bool stamps_split = g.stamps && getenv("PRS_STAMPS_SPLIT") != nullptr;
+  const bool stamps_split = g.stamps && ctx->stamps_split;
   const bool split = mode == PRS_MODE_ALIGN && !ctx_fused_align(ctx) && max_fixed <= kGnThreads * kGnSlots && (!g.stamps || stamps_split);
   if (!split) {
     auto kernel = align_kernel<kAlignThreads, false, -1>;
@@ -1678,8 +1678,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
                                                                      : align_kernel<kSearchThreads, true, PRS_SEARCH_KDTREE>));
   // two waves per frame (eight frames resident per CU: the kernel is bound by its single-wave phases and by
   // instruction issue, more independent frames fill the idle slots); PRS_GN_THREADS=256 selects the four-wave form
-  const char* gnt_env  = getenv("PRS_GN_THREADS");
-  const int gn_threads = (max_fixed <= 128 * 8 && !(gnt_env && atoi(gnt_env) == 256)) ? 128 : kGnThreads;
+  const int gn_threads = (max_fixed <= 128 * 8 && !ctx->gn_four_waves) ? 128 : kGnThreads;
   const size_t lds_gn  = (size_t) kTerms * (gn_threads + 4) * sizeof(float) + sizeof(GnShared) + 16;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(skernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_search);
   if (e != hipSuccess) {

@@ -232,13 +232,15 @@ def test_P13_finder_error_contract(oracle, hip_ctx):
 
 
 def test_split_pipeline_equals_fused_kernel(oracle, monkeypatch):
-    """PRS_MODE_ALIGN runs as a search-kernel / GN-kernel pipeline by default; PRS_FUSED_ALIGN=1 selects
-    the single fused kernel.  Both must give the oracle's answer bit for bit."""
+    """PRS_MODE_ALIGN runs as a search-kernel / GN-kernel pipeline by default (GN with two waves per frame;
+    PRS_GN_THREADS=256: four); PRS_FUSED_ALIGN=1 selects the single fused kernel.  All must give the oracle's
+    answer bit for bit."""
     cfg, fixed, dfix, mp, T, X0 = make_align_case("kitti", 91, 700, 800)
     scale = oracle.info_scale_from_nopt(mp["n_opt"])
     outs = []
-    for fused in ("0", "1"):
+    for fused, gn_threads in (("0", "128"), ("1", "128"), ("0", "256")):
         monkeypatch.setenv("PRS_FUSED_ALIGN", fused)
+        monkeypatch.setenv("PRS_GN_THREADS", gn_threads)
         ctx = ops.Context(0)
         gf = ops.ProjectiveFinder(ctx, ops.pcf_params(cfg))
         gf.set_fixed(fixed, dfix)
@@ -246,8 +248,9 @@ def test_split_pipeline_equals_fused_kernel(oracle, monkeypatch):
         X, corr, res, flags = gf.align(ops.aligner_params(cfg, stop_at_fixed_point=0), X0)
         outs.append((X.copy(), corr.copy(), res.num_inliers, res.iterations_executed, flags, gf.search_radius, gf.iteration))
         ctx.close()
-    assert np.array_equal(_bits(outs[0][0]), _bits(outs[1][0])) and corr_equal(outs[0][1], outs[1][1])
-    assert outs[0][2:] == outs[1][2:]
+    for other in outs[1:]:
+        assert np.array_equal(_bits(outs[0][0]), _bits(other[0])) and corr_equal(outs[0][1], other[1])
+        assert outs[0][2:] == other[2:]
     of = oracle.ProjectiveFinder(pcf_params_from_cfg(oracle, cfg))
     of.set_fixed(fixed, dfix)
     of.set_moving(mp["xyz"], mp["desc"])
