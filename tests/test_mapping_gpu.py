@@ -62,7 +62,11 @@ def _upload_frame(maps, b, fixed, desc, corr, Tw, Ts, frame):
 def _assert_map_equal(maps, b, m, poses, n_frames):
     n = m.n_points
     assert int(maps.n_points[b].item()) == n
-    bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
+    def bits(a):
+        # float32 bit patterns; every NaN counts as the same value (a degenerate landmark is NaN on both sides,
+        # sign / payload of the NaN are not part of the contract)
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        return np.where(np.isnan(a), np.uint32(0x7FC00000), a.view(np.uint32))
     assert np.array_equal(bits(maps.coords[b, :n, :3].cpu().numpy()), bits(m.coords[:n, :3])), "coords"
     assert np.array_equal(bits(maps.state[b, :n, :3].cpu().numpy()), bits(m.state[:n, :3])), "state"
     assert np.array_equal(bits(maps.covariance[b, :n].cpu().numpy()), bits(m.covariance[:n])), "covariance"
@@ -266,3 +270,14 @@ def test_batched_maps_and_loud_errors(oracle, hip_ctx):
     ops.merge_batch(hip_ctx, pg, maps2)
     hip_ctx.synchronize()
     assert int(maps2.result[0, 2].item()) == -9
+
+
+def test_randomised_sequences(oracle, hip_ctx):
+    """a bounded run of tools/fuzz_merge.py: estimators, binning grids, merge targets, history capacities, frame sizes"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_merge
+    bad, merges = fuzz_merge.run(12, 20200305, ctx=hip_ctx, verbose=False)
+    assert not bad, bad[:3]
+    assert merges > 200
