@@ -36,6 +36,7 @@ struct MergeArgs {
   int nbr, nbc;        // bin table extent
   uint32_t off_owner, off_first, off_best, off_seen, off_sh, off_wave, off_pose_cache;
   void* work;          // smoother: [batch][2][corr_stride] work items (two lists, swapped every round)
+  unsigned long long* stamps;  // diagnostic (PRS_STAMPS=1): [batch][16] shader-clock stamps of thread 0
 };
 
 struct MergeShared {
@@ -568,6 +569,20 @@ __device__ bool smoother_iterate(const prs_estimator_params& P, const float* pos
   uint32_t number_of_inliers = item.n_inliers;
   uint32_t it                = item.it;
   bool ended                 = it >= P.maximum_number_of_iterations;
+  // The history of the landmark does not change during the optimisation: its first measurements are read
+  // once per call (all loads in flight together) instead of once per iteration -- the loop is a serial
+  // per-lane chain and a global load inside it costs its full latency every time.
+  constexpr int kCached = 8;
+  float mu[kCached], mv[kCached], md[kCached];
+  int mf[kCached];
+#pragma unroll
+  for (int k = 0; k < kCached; ++k) {
+    const uint32_t kk = (uint32_t) k < n ? (uint32_t) k : 0u;
+    mu[k] = M[kk].point_in_image[0];
+    mv[k] = M[kk].point_in_image[1];
+    md[k] = M[kk].point_in_camera[2];
+    mf[k] = M[kk].frame;
+  }
   while (!ended && budget > 0) {
     float H[9], b[3];
 #pragma unroll
@@ -577,15 +592,16 @@ __device__ bool smoother_iterate(const prs_estimator_params& P, const float* pos
     b[0] = b[1] = b[2] = 0.0f;
     float total_error_squared   = 0.0f;
     uint32_t number_of_outliers = 0;
-    for (uint32_t k = 0; k < n; ++k) {
+    // one measurement (image point u, v, depth d, taken at `frame`): :59-104
+    auto accumulate = [&](const float u, const float v, const float d, const int frame) {
       float omega[3] = {1.0f, 1.0f, 10.0f};  // :59-60
-      const float* W  = pose_cache + 21 * M[k].frame;
+      const float* W  = pose_cache + 21 * frame;
       const float* Jl = W + 12;
       float pc[3];
       apply_pose(W, world, pc);  // :63
       if (pc[2] <= 0.0f) {
         ++number_of_outliers;
-        continue;
+        return;
       }
       float ph[3];
 #pragma unroll
@@ -596,7 +612,7 @@ __device__ bool smoother_iterate(const prs_estimator_params& P, const float* pos
       const float inv_c  = 1.0f / c;
       const float inv_c2 = inv_c * inv_c;
       const float pi0 = ph[0] / c, pi1 = ph[1] / c;  // :71
-      const float e[3] = {pi0 - M[k].point_in_image[0], pi1 - M[k].point_in_image[1], c - M[k].point_in_camera[2]};  // :74-76
+      const float e[3] = {pi0 - u, pi1 - v, c - d};  // :74-76
       const float error_squared = (e[0] * (omega[0] * e[0]) + e[1] * (omega[1] * e[1])) + e[2] * (omega[2] * e[2]);
       total_error_squared += error_squared;
       if (error_squared > max_kernel) {  // :83-86
@@ -625,6 +641,15 @@ __device__ bool smoother_iterate(const prs_estimator_params& P, const float* pos
         }
         b[a] += (J[0 + a] * (omega[0] * e[0]) + J[3 + a] * (omega[1] * e[1])) + J[6 + a] * (omega[2] * e[2]);
       }
+    };
+#pragma unroll
+    for (int k = 0; k < kCached; ++k) {
+      if ((uint32_t) k < n) {
+        accumulate(mu[k], mv[k], md[k], mf[k]);
+      }
+    }
+    for (uint32_t k = kCached; k < n; ++k) {
+      accumulate(M[k].point_in_image[0], M[k].point_in_image[1], M[k].point_in_camera[2], M[k].frame);
     }
     const float nb[3] = {-b[0], -b[1], -b[2]};
     float dx[3];
@@ -727,6 +752,13 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
   const int32_t* __restrict__ imap  = B.scene_index_map ? B.scene_index_map + (size_t) map * B.capacity : nullptr;
   prs_frame_pose* poses = B.poses + (size_t) map * B.max_frames;
   SmootherItem* work    = EST == PRS_EST_SMOOTHER ? static_cast<SmootherItem*>(a.work) + (size_t) map * 2 * B.corr_stride : nullptr;
+#define MG_STAMP(i)                                                          \
+  do {                                                                       \
+    if (a.stamps && tid == 0) {                                              \
+      a.stamps[(size_t) map * 16 + (i)] = (unsigned long long) clock64();    \
+    }                                                                        \
+  } while (0)
+  MG_STAMP(0);
 
   // ---- setTransforms (landmark_estimator_base.hpp:47-56) + this frame's row of the pose table ---------
   if (tid == 0) {
@@ -795,6 +827,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
     __syncthreads();
   }
 
+  MG_STAMP(1);
   // ---- correspondences: inlier reset, appearance gate, first-come bin blocking (:59-122) --------------
   for (int c = tid; c < n_corr; c += kMergeThreads) {
     const prs_corr cr = corr[c];
@@ -835,6 +868,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
     return;
   }
 
+  MG_STAMP(2);
   // ---- _updatePoint for every correspondence that owns its bin (:124-128, :192-208) -----------------------
   for (int c = tid; c < n_corr; c += kMergeThreads) {
     const prs_corr cr = corr[c];
@@ -885,6 +919,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
     }
   }
   __syncthreads();
+  MG_STAMP(3);
   if (EST == PRS_EST_SMOOTHER) {
     constexpr int kRoundIterations = 8;
     SmootherItem* cur = work;
@@ -918,6 +953,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
       __syncthreads();
     }
   }
+  MG_STAMP(4);
   const int n_merged = sh.n_merged;
   int status         = 0;
   if (n_corr > 0) {  // :137-150
@@ -954,6 +990,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
       }
       __syncthreads();
     }
+    MG_STAMP(5);
     // candidates in the reference's order, triangulated / unprojected, valid ones appended (:267-299)
     for (int i0 = 0; i0 < n_meas && !sh.error; i0 += kMergeThreads) {
       const int i = i0 + tid;
@@ -1044,6 +1081,8 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
     }
   }
   __syncthreads();
+  MG_STAMP(6);
+#undef MG_STAMP
   if (tid == 0) {
     if (sh.error) {
       B.result[map].n_merged = n_merged;
@@ -1109,7 +1148,8 @@ int merge_batch_launch(prs_context* ctx, const prs_merger_params* params, const 
   if (off > 160u * 1024u) {
     return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_merge_batch_run: bin table / scene do not fit the 160 KiB LDS");
   }
-  a.work = nullptr;
+  a.stamps = ctx_stamps(ctx, (size_t) b.batch * 16 * sizeof(unsigned long long));
+  a.work   = nullptr;
   if (e.type == PRS_EST_SMOOTHER) {
     if (!b.corr || b.corr_stride <= 0) {
       // no correspondences at all: nothing to iterate, but the pointer must be valid
@@ -1144,6 +1184,9 @@ int merge_batch_launch(prs_context* ctx, const prs_merger_params* params, const 
   }
   if (e2 != hipSuccess) {
     return ctx_fail_hip(ctx, e2, "prs_merge_batch_run launch");
+  }
+  if (a.stamps) {
+    ctx_report_stamps(ctx, b.batch, 7, "merge: setup + pose cache | correspondences (gate, bins) | update / smoother start | smoother rounds | addition bins | additions");
   }
   return PRS_OK;
 }
