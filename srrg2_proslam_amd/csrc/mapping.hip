@@ -37,6 +37,15 @@ struct MergeArgs {
   uint32_t off_owner, off_first, off_best, off_seen, off_sh, off_wave, off_pose_cache;
   void* work;          // smoother: [batch][2][corr_stride] work items (two lists, swapped every round)
   unsigned long long* stamps;  // diagnostic (PRS_STAMPS=1): [batch][16] shader-clock stamps of thread 0
+  struct MergeCarry* carry;    // smoother merger run as three kernels: [batch] state handed from one to the next
+};
+
+// pose-based smoother as front kernel | smoother kernel | back kernel (see merge_batch_launch)
+struct MergeCarry {
+  int n_merged;  // landmarks merged so far
+  int n_work;    // smoother work items the front kernel queued
+  int error;     // error raised while updating points (the frame's additions are skipped, like in the fused kernel)
+  int returned;  // the front kernel has written the frame's result already (error before any update)
 };
 
 struct MergeShared {
@@ -725,8 +734,13 @@ __device__ __forceinline__ uint32_t float_key(float v) {
 
 // EST / DIM are compile-time so that an instantiation only carries the registers of its own estimator
 // (the double-precision EKF would otherwise set the occupancy of the float estimators too)
-template <int EST, int DIM>
+// PHASE 0: the whole merger in one kernel.  The pose-based smoother runs as PHASE 1 (everything up to the queued
+// smoother work items), smoother_kernel, PHASE 2 (additions + result): its optimisation loop is a long serial
+// per-lane computation, and as part of this 256-thread kernel (bin tables in LDS, four workgroups per CU) only
+// four of them are in flight per CU -- on its own it runs sixteen.
+template <int EST, int DIM, int PHASE>
 __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a) {
+  constexpr bool kFront = PHASE != 2;  // correspondences, _updatePoint (PHASE 2: _addPoints + result only)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* owner   = reinterpret_cast<uint32_t*>(smem + a.off_owner);  // first correspondence reaching the bin
   uint32_t* first   = reinterpret_cast<uint32_t*>(smem + a.off_first);  // first addition candidate of the bin
@@ -797,16 +811,22 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
   }
   __threadfence_block();
   __syncthreads();
+  if (PHASE == 2 && a.carry[map].returned) {
+    return;  // (block-uniform) the front kernel reported this frame
+  }
   if (sh.error) {
-    if (tid == 0) {
+    if (tid == 0 && kFront) {
       B.result[map].n_merged = 0;
       B.result[map].n_added  = 0;
       B.result[map].status   = sh.error;
+      if (PHASE == 1) {
+        a.carry[map] = MergeCarry{0, 0, sh.error, 1};
+      }
     }
     return;
   }
 
-  if (EST == PRS_EST_SMOOTHER) {
+  if (EST == PRS_EST_SMOOTHER && PHASE == 0) {
     // every frame of the pose table (this frame's row was written above): world_in_sensor and camera_matrix * R
     for (int f = tid; f < B.max_frames; f += kMergeThreads) {
       const float* W  = f == frame ? sh.world_in_sensor : poses[f].world_in_sensor;
@@ -844,7 +864,9 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
       sh.error = PRS_ERR_DUPLICATE;
       continue;
     }
-    B.inlier[(size_t) map * B.capacity + s] = 0;  // :64
+    if (kFront) {
+      B.inlier[(size_t) map * B.capacity + s] = 0;  // :64
+    }
     if (cr.response > P.maximum_distance_appearance) {  // :70-73
       continue;
     }
@@ -860,17 +882,20 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
   }
   __syncthreads();
   if (sh.error) {
-    if (tid == 0) {
+    if (tid == 0 && kFront) {
       B.result[map].n_merged = 0;
       B.result[map].n_added  = 0;
       B.result[map].status   = sh.error;
+      if (PHASE == 1) {
+        a.carry[map] = MergeCarry{0, 0, sh.error, 1};
+      }
     }
     return;
   }
 
   MG_STAMP(2);
   // ---- _updatePoint for every correspondence that owns its bin (:124-128, :192-208) -----------------------
-  for (int c = tid; c < n_corr; c += kMergeThreads) {
+  for (int c = tid; kFront && c < n_corr; c += kMergeThreads) {
     const prs_corr cr = corr[c];
     if (cr.response > P.maximum_distance_appearance) {
       continue;
@@ -920,7 +945,20 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
   }
   __syncthreads();
   MG_STAMP(3);
-  if (EST == PRS_EST_SMOOTHER) {
+  if (PHASE == 1) {
+    if (tid == 0) {
+      a.carry[map] = MergeCarry{sh.n_merged, sh.n_work, sh.error, 0};  // continued by smoother_kernel and PHASE 2
+    }
+    return;
+  }
+  if (PHASE == 2) {
+    if (tid == 0) {
+      sh.n_merged = a.carry[map].n_merged;
+      sh.error    = a.carry[map].error;
+    }
+    __syncthreads();
+  }
+  if (EST == PRS_EST_SMOOTHER && PHASE == 0) {
     constexpr int kRoundIterations = 8;
     SmootherItem* cur = work;
     SmootherItem* nxt = work + B.corr_stride;
@@ -1097,6 +1135,101 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
   }
 }
 
+// The optimisation loops of one frame's queued landmarks (PHASE 1 of merge_kernel left them in `work`): ONE wave per
+// frame, 1.5 kB of LDS, so that sixteen frames are in flight per CU.  Rounds of eight iterations; landmarks whose
+// loop has not ended are compacted into the other list (same scheme as the fused kernel).
+constexpr int kSmootherThreads = 64;
+__global__ __launch_bounds__(kSmootherThreads) void smoother_kernel(const MergeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  MergeShared& sh   = *reinterpret_cast<MergeShared*>(smem);
+  float* pose_cache = reinterpret_cast<float*>(smem + ((sizeof(MergeShared) + 15) & ~(size_t) 15));  // [max_frames][21]
+  const int lane    = threadIdx.x;
+  const int map     = blockIdx.x;
+  const prs_merge_batch& B   = a.b;
+  const prs_merger_params& P = a.p;
+  MergeCarry* carry          = a.carry + map;
+  int n_work                 = carry->n_work;
+  if (carry->returned || n_work <= 0) {
+    return;  // (uniform)
+  }
+  const int frame       = B.frame[map];
+  prs_frame_pose* poses = B.poses + (size_t) map * B.max_frames;
+  const uint8_t* __restrict__ zdesc = B.measurement_desc + (size_t) map * B.measurement_stride * 32;
+  SmootherItem* cur = static_cast<SmootherItem*>(a.work) + (size_t) map * 2 * B.corr_stride;
+  SmootherItem* nxt = cur + B.corr_stride;
+  if (lane == 0) {  // setTransforms (landmark_estimator_base.hpp:47-56), as in merge_kernel
+    float Tw[16], Ts[16], Wi[16], Wl[16];
+    for (int i = 0; i < 16; ++i) {
+      Tw[i] = B.measurement_in_world[(size_t) map * 16 + i];
+      Ts[i] = B.measurement_in_scene[(size_t) map * 16 + i];
+    }
+    se3_inverse(Tw, Wi);
+    se3_mul(Ts, Wi, Wl);
+    for (int i = 0; i < 16; ++i) {
+      sh.sensor_in_world[i]      = Tw[i];
+      sh.world_in_sensor[i]      = Wi[i];
+      sh.world_in_local_map[i]   = Wl[i];
+      sh.measurement_in_scene[i] = Ts[i];
+    }
+    sh.n_next = 0;
+  }
+  __syncthreads();
+  for (int f = lane; f < B.max_frames; f += kSmootherThreads) {
+    const float* W  = f == frame ? sh.world_in_sensor : poses[f].world_in_sensor;
+    const float* Km = P.estimator.camera_matrix;
+    float* c        = pose_cache + 21 * f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      c[i] = W[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {  // landmark_estimator_pose_based_smoother_impl.cpp:89
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        c[12 + 3 * i + j] = (Km[3 * i + 0] * W[0 + j] + Km[3 * i + 1] * W[4 + j]) + Km[3 * i + 2] * W[8 + j];
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int kRoundIterations = 8;
+  int merged = 0;
+  while (n_work > 0) {  // uniform
+    for (int i = lane; i < n_work; i += kSmootherThreads) {
+      SmootherItem item = cur[i];
+      const Landmark l  = landmark_at(B, map, item.s);
+      if (smoother_iterate(P.estimator, pose_cache, l, item, kRoundIterations)) {
+        if (smoother_finish(sh, poses, l, item)) {  // merger_projective_impl.cpp:203-207
+          const uint4* src = reinterpret_cast<const uint4*>(zdesc + 32 * (size_t) item.m);
+          uint4* dst       = reinterpret_cast<uint4*>(l.desc);
+          dst[0]           = src[0];
+          dst[1]           = src[1];
+          ++merged;
+        }
+      } else {
+        nxt[atomicAdd(&sh.n_next, 1)] = item;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    n_work = sh.n_next;
+    __syncthreads();
+    if (lane == 0) {
+      sh.n_next = 0;
+    }
+    SmootherItem* t = cur;
+    cur             = nxt;
+    nxt             = t;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    merged += __shfl_xor(merged, d, 64);
+  }
+  if (lane == 0) {
+    carry->n_merged += merged;
+  }
+}
+
 static inline uint32_t mg_align16(uint32_t v) {
   return (v + 15u) & ~15u;
 }
@@ -1171,16 +1304,29 @@ int merge_batch_launch(prs_context* ctx, const prs_merger_params* params, const 
       e2 = hipGetLastError();
     }
   };
+  a.carry = nullptr;
   if (e.type == PRS_EST_WEIGHTED_MEAN) {
-    launch(merge_kernel<PRS_EST_WEIGHTED_MEAN, 4>);
+    launch(merge_kernel<PRS_EST_WEIGHTED_MEAN, 4, 0>);
+  } else if (e.type == PRS_EST_SMOOTHER && (ctx->merge_fused || a.stamps)) {
+    launch(merge_kernel<PRS_EST_SMOOTHER, 4, 0>);
   } else if (e.type == PRS_EST_SMOOTHER) {
-    launch(merge_kernel<PRS_EST_SMOOTHER, 4>);
+    a.carry = static_cast<MergeCarry*>(ctx_device_scratch_slot(ctx, 1, (size_t) b.batch * sizeof(MergeCarry)));
+    if (!a.carry) {
+      return ctx_fail(ctx, PRS_ERR_HIP, "prs_merge_batch_run: carry allocation failed");
+    }
+    launch(merge_kernel<PRS_EST_SMOOTHER, 4, 1>);
+    if (e2 == hipSuccess) {
+      const size_t lds_s = ((sizeof(MergeShared) + 15) & ~(size_t) 15) + (size_t) b.max_frames * 21 * sizeof(float);
+      hipLaunchKernelGGL(smoother_kernel, dim3(b.batch), dim3(kSmootherThreads), lds_s, ctx_stream(ctx), a);
+      e2 = hipGetLastError();
+    }
+    launch(merge_kernel<PRS_EST_SMOOTHER, 4, 2>);
   } else if (e.measurement_dim == 4) {
-    launch(merge_kernel<PRS_EST_EKF, 4>);
+    launch(merge_kernel<PRS_EST_EKF, 4, 0>);
   } else if (e.measurement_dim == 3) {
-    launch(merge_kernel<PRS_EST_EKF, 3>);
+    launch(merge_kernel<PRS_EST_EKF, 3, 0>);
   } else {
-    launch(merge_kernel<PRS_EST_EKF, 2>);
+    launch(merge_kernel<PRS_EST_EKF, 2, 0>);
   }
   if (e2 != hipSuccess) {
     return ctx_fail_hip(ctx, e2, "prs_merge_batch_run launch");

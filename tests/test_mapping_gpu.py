@@ -281,3 +281,20 @@ def test_randomised_sequences(oracle, hip_ctx):
     bad, merges = fuzz_merge.run(12, 20200305, ctx=hip_ctx, verbose=False)
     assert not bad, bad[:3]
     assert merges > 200
+
+
+def test_fused_smoother_merger_kernel(oracle, monkeypatch):
+    """the pose-based smoother merger runs as front | smoother | back kernels by default; PRS_MERGE_FUSED=1 keeps it in
+    one kernel (the form the phase stamps time).  Both must equal the oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_merge
+    monkeypatch.setenv("PRS_MERGE_FUSED", "1")
+    ctx = ops.Context(0)
+    try:
+        bad, merges = fuzz_merge.run(8, 20200307, ctx=ctx, verbose=False)
+    finally:
+        ctx.close()
+    assert not bad, bad[:3]
+    assert merges > 100
