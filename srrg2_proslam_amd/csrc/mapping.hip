@@ -568,7 +568,14 @@ __device__ int smoother_begin(const prs_estimator_params& P, const MergeShared& 
 }
 
 // up to `budget` iterations of the loop (:49-119); true when the loop has ended (converged or out of iterations)
-__device__ bool smoother_iterate(const prs_estimator_params& P, const float* pose_cache, const Landmark& l, SmootherItem& item, int budget) {
+// `ring` (optional, LDS, [kSmootherRing][5][64] floats, this lane's column `ring_lane`): the states of this call's
+// iterations, used to end a loop that has entered a short cycle.  The iteration is a deterministic map of `world`, so
+// once a state repeats (bit for bit) everything after it is known: in float arithmetic the chi2 sums of about a
+// third of the landmarks never settle within kitti.conf's delta of 1e-6 -- they alternate between 2..8 states from
+// the first ten iterations on and would run all 100.  The result is exactly the one the full loop produces.
+constexpr int kSmootherRing = 8;
+__device__ bool smoother_iterate(const prs_estimator_params& P, const float* pose_cache, const Landmark& l, SmootherItem& item, int budget,
+                                 float* ring = nullptr, int ring_lane = 0) {
   const prs_camera_measurement* M = l.meas;
   const uint32_t n           = *l.n_meas;
   const float* Km            = P.camera_matrix;
@@ -592,7 +599,14 @@ __device__ bool smoother_iterate(const prs_estimator_params& P, const float* pos
     md[k] = M[kk].point_in_camera[2];
     mf[k] = M[kk].frame;
   }
+  int slot = 0;  // iterations of this call (= states in the ring)
+  auto ring_at = [&](int state, int field) -> float& { return ring[(state * 5 + field) * 64 + ring_lane]; };
   while (!ended && budget > 0) {
+    if (ring && slot < kSmootherRing) {
+      ring_at(slot, 0) = world[0];
+      ring_at(slot, 1) = world[1];
+      ring_at(slot, 2) = world[2];
+    }
     float H[9], b[3];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -669,12 +683,55 @@ __device__ bool smoother_iterate(const prs_estimator_params& P, const float* pos
     number_of_inliers = n - number_of_outliers;
     ++it;
     --budget;
+    if (ring && slot < kSmootherRing) {
+      ring_at(slot, 3) = total_error_squared;
+      ring_at(slot, 4) = __uint_as_float(number_of_inliers);
+    }
     if (fabsf(total_error_squared - total_previous) < P.convergence_criterion_minimum_chi2_delta) {  // :113-117
       ended = true;
     } else {
       total_previous = total_error_squared;
       ended          = it >= P.maximum_number_of_iterations;
+      if (!ended && ring && slot < kSmootherRing) {
+        // the state the NEXT iteration (index `it`) starts from: has this call been there already?
+        int q = -1;
+        for (int k = slot; k >= 0; --k) {
+          if (__float_as_uint(ring_at(k, 0)) == __float_as_uint(world[0]) && __float_as_uint(ring_at(k, 1)) == __float_as_uint(world[1]) &&
+              __float_as_uint(ring_at(k, 2)) == __float_as_uint(world[2])) {
+            q = k;
+          }
+        }
+        if (q >= 0) {
+          // iterations (it - period) and it start from the same state: iteration it + m repeats iteration it - period + m.
+          // Every later convergence test compares a pair of chi2 values that has been compared before and did not end
+          // the loop -- except the one of iteration `it` itself (chi2 of state q against the chi2 just computed).
+          const int period = slot + 1 - q;
+          if (fabsf(ring_at(q, 3) - total_previous) < P.convergence_criterion_minimum_chi2_delta) {
+            // iteration `it` runs (state q -> state q + 1) and ends the loop
+            if (q + 1 <= slot) {
+              world[0] = ring_at(q + 1, 0);
+              world[1] = ring_at(q + 1, 1);
+              world[2] = ring_at(q + 1, 2);
+            }  // (period 1: a fixed point, the state after it is the current one)
+            number_of_inliers = __float_as_uint(ring_at(q, 4));
+            ++it;
+          } else {
+            // the loop runs to the iteration limit: it ends in the state (limit - first) mod period of the cycle, with the
+            // inlier count of the iteration before
+            const uint32_t first = it - (uint32_t) period;
+            const int r_world    = (int) ((P.maximum_number_of_iterations - first) % (uint32_t) period);
+            const int r_inliers  = (int) ((P.maximum_number_of_iterations - 1u - first) % (uint32_t) period);
+            world[0]             = ring_at(q + r_world, 0);
+            world[1]             = ring_at(q + r_world, 1);
+            world[2]             = ring_at(q + r_world, 2);
+            number_of_inliers    = __float_as_uint(ring_at(q + r_inliers, 4));
+            it                   = P.maximum_number_of_iterations;
+          }
+          ended = true;
+        }
+      }
     }
+    ++slot;
   }
   item.world[0]       = world[0];
   item.world[1]       = world[1];
@@ -1143,6 +1200,7 @@ __global__ __launch_bounds__(kSmootherThreads) void smoother_kernel(const MergeA
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   MergeShared& sh   = *reinterpret_cast<MergeShared*>(smem);
   float* pose_cache = reinterpret_cast<float*>(smem + ((sizeof(MergeShared) + 15) & ~(size_t) 15));  // [max_frames][21]
+  float* ring       = pose_cache + (((size_t) a.b.max_frames * 21 + 3) & ~(size_t) 3);                // [kSmootherRing][5][64]
   const int lane    = threadIdx.x;
   const int map     = blockIdx.x;
   const prs_merge_batch& B   = a.b;
@@ -1197,7 +1255,7 @@ __global__ __launch_bounds__(kSmootherThreads) void smoother_kernel(const MergeA
     for (int i = lane; i < n_work; i += kSmootherThreads) {
       SmootherItem item = cur[i];
       const Landmark l  = landmark_at(B, map, item.s);
-      if (smoother_iterate(P.estimator, pose_cache, l, item, kRoundIterations)) {
+      if (smoother_iterate(P.estimator, pose_cache, l, item, kRoundIterations, ring, lane)) {
         if (smoother_finish(sh, poses, l, item)) {  // merger_projective_impl.cpp:203-207
           const uint4* src = reinterpret_cast<const uint4*>(zdesc + 32 * (size_t) item.m);
           uint4* dst       = reinterpret_cast<uint4*>(l.desc);
@@ -1316,7 +1374,8 @@ int merge_batch_launch(prs_context* ctx, const prs_merger_params* params, const 
     }
     launch(merge_kernel<PRS_EST_SMOOTHER, 4, 1>);
     if (e2 == hipSuccess) {
-      const size_t lds_s = ((sizeof(MergeShared) + 15) & ~(size_t) 15) + (size_t) b.max_frames * 21 * sizeof(float);
+      const size_t lds_s = ((sizeof(MergeShared) + 15) & ~(size_t) 15) + (((size_t) b.max_frames * 21 + 3) & ~(size_t) 3) * sizeof(float) +
+                           (size_t) kSmootherRing * 5 * 64 * sizeof(float);
       hipLaunchKernelGGL(smoother_kernel, dim3(b.batch), dim3(kSmootherThreads), lds_s, ctx_stream(ctx), a);
       e2 = hipGetLastError();
     }
