@@ -38,8 +38,12 @@ struct MergeArgs {
   void* work;          // smoother: [batch][2][corr_stride] work items (two lists, swapped every round)
   unsigned long long* stamps;  // diagnostic (PRS_STAMPS=1): [batch][16] shader-clock stamps of thread 0
   struct MergeCarry* carry;    // smoother merger run as three kernels: [batch] state handed from one to the next
+  struct TailItem* tail;       // landmarks still iterating after the smoother kernel's rounds (all frames), [tail_capacity]
+  int* tail_count;
+  int tail_capacity;
 };
 
+struct SmootherItem;
 // pose-based smoother as front kernel | smoother kernel | back kernel (see merge_batch_launch)
 struct MergeCarry {
   int n_merged;  // landmarks merged so far
@@ -517,6 +521,15 @@ struct SmootherItem {
   uint32_t it;            // iterations done
   uint32_t n_inliers;     // of the last iteration (:110)
 };
+// a landmark that is still iterating after the per-frame smoother kernel's rounds: continued by smoother_tail_kernel,
+// where the stragglers of ALL frames share waves (a frame keeps ~4 of them, and a wave per frame would idle 60 lanes
+// for another ~75 iterations)
+struct TailItem {
+  int map;
+  SmootherItem item;
+};
+constexpr int kTailRounds   = 3;   // rounds of 8 iterations the per-frame kernel runs before handing over
+constexpr int kTailPerFrame = 64;  // hand-over only when at most this many landmarks of the frame are left (list capacity)
 
 // everything before the loop (:13-43).  Returns < 0 on error, 0 / 1 when the landmark is finished already
 // (fewer measurements than minimum_number_of_measurements_for_optimization: averaging), 2 when `item` is ready to iterate
@@ -573,7 +586,11 @@ __device__ int smoother_begin(const prs_estimator_params& P, const MergeShared& 
 // once a state repeats (bit for bit) everything after it is known: in float arithmetic the chi2 sums of about a
 // third of the landmarks never settle within kitti.conf's delta of 1e-6 -- they alternate between 2..8 states from
 // the first ten iterations on and would run all 100.  The result is exactly the one the full loop produces.
+// POSES_IN_LDS: `pose_cache` holds [frame][21] floats (world_in_sensor 3x4, camera_matrix * R 3x3) of the landmark's map
+// in LDS; otherwise it points at the map's prs_frame_pose table in global memory and the 3x3 product is formed per
+// use with the same expression (the tail kernel, whose lanes belong to different maps).
 constexpr int kSmootherRing = 8;
+template <bool POSES_IN_LDS = true>
 __device__ bool smoother_iterate(const prs_estimator_params& P, const float* pose_cache, const Landmark& l, SmootherItem& item, int budget,
                                  float* ring = nullptr, int ring_lane = 0) {
   const prs_camera_measurement* M = l.meas;
@@ -618,8 +635,25 @@ __device__ bool smoother_iterate(const prs_estimator_params& P, const float* pos
     // one measurement (image point u, v, depth d, taken at `frame`): :59-104
     auto accumulate = [&](const float u, const float v, const float d, const int frame) {
       float omega[3] = {1.0f, 1.0f, 10.0f};  // :59-60
+      float Wg[12], Jg[9];
       const float* W  = pose_cache + 21 * frame;
       const float* Jl = W + 12;
+      if (!POSES_IN_LDS) {
+        const float* src = reinterpret_cast<const prs_frame_pose*>(pose_cache)[frame].world_in_sensor;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          Wg[i] = src[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {  // landmark_estimator_pose_based_smoother_impl.cpp:89
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            Jg[3 * i + j] = (Km[3 * i + 0] * Wg[0 + j] + Km[3 * i + 1] * Wg[4 + j]) + Km[3 * i + 2] * Wg[8 + j];
+          }
+        }
+        W  = Wg;
+        Jl = Jg;
+      }
       float pc[3];
       apply_pose(W, world, pc);  // :63
       if (pc[2] <= 0.0f) {
@@ -743,7 +777,7 @@ __device__ bool smoother_iterate(const prs_estimator_params& P, const float* pos
 }
 
 // everything after the loop (:121-138)
-__device__ int smoother_finish(const MergeShared& sh, const prs_frame_pose* poses, const Landmark& l, const SmootherItem& item) {
+__device__ int smoother_finish(const float* world_in_local_map, const prs_frame_pose* poses, const Landmark& l, const SmootherItem& item) {
   float world[3] = {item.world[0], item.world[1], item.world[2]};
   if (item.n_inliers > *l.n_opt) {  // :122-127
     add_optimization_result(l, world, nullptr);
@@ -755,7 +789,7 @@ __device__ int smoother_finish(const MergeShared& sh, const prs_frame_pose* pose
     l.state[2] = world[2];
   }
   float loc[3];
-  apply_rows(sh.world_in_local_map, world, loc);  // :138
+  apply_rows(world_in_local_map, world, loc);  // :138
   l.coords[0] = loc[0];
   l.coords[1] = loc[1];
   l.coords[2] = loc[2];
@@ -1025,7 +1059,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(const MergeArgs a)
         SmootherItem item = cur[i];
         const Landmark l  = landmark_at(B, map, item.s);
         if (smoother_iterate(P.estimator, pose_cache, l, item, kRoundIterations)) {
-          if (smoother_finish(sh, poses, l, item)) {  // merger_projective_impl.cpp:203-207
+          if (smoother_finish(sh.world_in_local_map, poses, l, item)) {  // merger_projective_impl.cpp:203-207
             const uint4* src = reinterpret_cast<const uint4*>(zdesc + 32 * (size_t) item.m);
             uint4* dst       = reinterpret_cast<uint4*>(l.desc);
             dst[0]           = src[0];
@@ -1251,12 +1285,29 @@ __global__ __launch_bounds__(kSmootherThreads) void smoother_kernel(const MergeA
   __syncthreads();
   constexpr int kRoundIterations = 8;
   int merged = 0;
+  int round  = 0;
   while (n_work > 0) {  // uniform
+    if (a.tail && round >= kTailRounds && n_work <= kTailPerFrame) {
+      // the rest goes to the tail kernel (capacity: kTailPerFrame entries per frame, so the list cannot overflow)
+      int base = 0;
+      if (lane == 0) {
+        base = atomicAdd(a.tail_count, n_work);
+      }
+      base = __shfl(base, 0, 64);
+      if (lane < n_work) {
+        TailItem t;
+        t.map              = map;
+        t.item             = cur[lane];
+        a.tail[base + lane] = t;
+      }
+      break;
+    }
+    ++round;
     for (int i = lane; i < n_work; i += kSmootherThreads) {
       SmootherItem item = cur[i];
       const Landmark l  = landmark_at(B, map, item.s);
       if (smoother_iterate(P.estimator, pose_cache, l, item, kRoundIterations, ring, lane)) {
-        if (smoother_finish(sh, poses, l, item)) {  // merger_projective_impl.cpp:203-207
+        if (smoother_finish(sh.world_in_local_map, poses, l, item)) {  // merger_projective_impl.cpp:203-207
           const uint4* src = reinterpret_cast<const uint4*>(zdesc + 32 * (size_t) item.m);
           uint4* dst       = reinterpret_cast<uint4*>(l.desc);
           dst[0]           = src[0];
@@ -1285,6 +1336,43 @@ __global__ __launch_bounds__(kSmootherThreads) void smoother_kernel(const MergeA
   }
   if (lane == 0) {
     carry->n_merged += merged;
+  }
+}
+
+// The stragglers of all frames (landmarks whose loop neither converged nor entered a short cycle within the per-frame
+// kernel's rounds): 64 per wave regardless of their frame, every lane runs its landmark to the end.  Pose rows come
+// from the maps' pose tables in global memory; the result (merged count) goes to the frame's carry.
+__global__ __launch_bounds__(kSmootherThreads) void smoother_tail_kernel(const MergeArgs a) {
+  __shared__ float ring[kSmootherRing * 5 * 64];
+  const int lane = threadIdx.x;
+  const prs_merge_batch& B   = a.b;
+  const prs_merger_params& P = a.p;
+  const int count = *a.tail_count;
+  for (int idx = blockIdx.x * kSmootherThreads + lane; idx < count; idx += gridDim.x * kSmootherThreads) {
+    const TailItem t  = a.tail[idx];
+    const int map     = t.map;
+    SmootherItem item = t.item;
+    const Landmark l  = landmark_at(B, map, item.s);
+    prs_frame_pose* poses = B.poses + (size_t) map * B.max_frames;
+    while (!smoother_iterate<false>(P.estimator, reinterpret_cast<const float*>(poses), l, item, kSmootherRing, ring, lane)) {
+    }
+    // setTransforms (landmark_estimator_base.hpp:47-56): world_in_local_map = measurement_in_scene * sensor_in_world^-1
+    float Tw[16], Ts[16], Wi[16], Wl[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      Tw[i] = B.measurement_in_world[(size_t) map * 16 + i];
+      Ts[i] = B.measurement_in_scene[(size_t) map * 16 + i];
+    }
+    se3_inverse(Tw, Wi);
+    se3_mul(Ts, Wi, Wl);
+    if (smoother_finish(Wl, poses, l, item)) {  // merger_projective_impl.cpp:203-207
+      const uint8_t* zdesc = B.measurement_desc + (size_t) map * B.measurement_stride * 32;
+      const uint4* src     = reinterpret_cast<const uint4*>(zdesc + 32 * (size_t) item.m);
+      uint4* dst           = reinterpret_cast<uint4*>(l.desc);
+      dst[0]               = src[0];
+      dst[1]               = src[1];
+      atomicAdd(&a.carry[map].n_merged, 1);
+    }
   }
 }
 
@@ -1362,7 +1450,10 @@ int merge_batch_launch(prs_context* ctx, const prs_merger_params* params, const 
       e2 = hipGetLastError();
     }
   };
-  a.carry = nullptr;
+  a.carry         = nullptr;
+  a.tail          = nullptr;
+  a.tail_count    = nullptr;
+  a.tail_capacity = 0;
   if (e.type == PRS_EST_WEIGHTED_MEAN) {
     launch(merge_kernel<PRS_EST_WEIGHTED_MEAN, 4, 0>);
   } else if (e.type == PRS_EST_SMOOTHER && (ctx->merge_fused || a.stamps)) {
@@ -1372,11 +1463,22 @@ int merge_batch_launch(prs_context* ctx, const prs_merger_params* params, const 
     if (!a.carry) {
       return ctx_fail(ctx, PRS_ERR_HIP, "prs_merge_batch_run: carry allocation failed");
     }
+    // tail list: [batch * kTailPerFrame] items + the counter in front of them
+    a.tail_capacity    = b.batch * kTailPerFrame;
+    unsigned char* tmem = static_cast<unsigned char*>(ctx_device_scratch_slot(ctx, 2, 256 + (size_t) a.tail_capacity * sizeof(TailItem)));
+    if (!tmem) {
+      return ctx_fail(ctx, PRS_ERR_HIP, "prs_merge_batch_run: tail list allocation failed");
+    }
+    a.tail_count = reinterpret_cast<int*>(tmem);
+    a.tail       = reinterpret_cast<TailItem*>(tmem + 256);
+    (void) hipMemsetAsync(a.tail_count, 0, sizeof(int), ctx_stream(ctx));
     launch(merge_kernel<PRS_EST_SMOOTHER, 4, 1>);
     if (e2 == hipSuccess) {
       const size_t lds_s = ((sizeof(MergeShared) + 15) & ~(size_t) 15) + (((size_t) b.max_frames * 21 + 3) & ~(size_t) 3) * sizeof(float) +
                            (size_t) kSmootherRing * 5 * 64 * sizeof(float);
       hipLaunchKernelGGL(smoother_kernel, dim3(b.batch), dim3(kSmootherThreads), lds_s, ctx_stream(ctx), a);
+      const int tail_waves = b.batch < 2048 ? b.batch : 2048;  // grid-stride over however many stragglers there are
+      hipLaunchKernelGGL(smoother_tail_kernel, dim3(tail_waves), dim3(kSmootherThreads), 0, ctx_stream(ctx), a);
       e2 = hipGetLastError();
     }
     launch(merge_kernel<PRS_EST_SMOOTHER, 4, 2>);
