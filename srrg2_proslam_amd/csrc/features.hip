@@ -120,7 +120,7 @@ __device__ __forceinline__ int fast_response(const uint8_t* c, int t) {
 __global__ __launch_bounds__(kFastThreads) void fast_box_kernel(const FeatureArgs a) {
   constexpr int kHalo = 4;
   constexpr int kSW = kTileW + 2, kSH = kTileH + 2;  // response tile with its 1-px ring
-  __shared__ uint8_t tile[(kTileH + 2 * kHalo) * kTilePitch];
+  __shared__ __attribute__((aligned(4))) uint8_t tile[(kTileH + 2 * kHalo) * kTilePitch];
   __shared__ uint8_t resp[kSH * kSW];
   __shared__ uint16_t hsum[(kTileH + 4) * kTileW];  // horizontal 5-sums of the tile rows -2 .. kTileH+1
   __shared__ uint16_t cand[kSH * kSW];              // response-tile positions that pass the compass test
@@ -133,13 +133,26 @@ __global__ __launch_bounds__(kFastThreads) void fast_box_kernel(const FeatureArg
   const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
   const uint8_t* __restrict__ src = a.b.images + (size_t) img * rows * pitch;
   const int tid = threadIdx.x;
-  // tile + halo, clamped at the image border (clamped pixels never reach an output)
-  for (int i = tid; i < (kTileH + 2 * kHalo) * (kTileW + 2 * kHalo); i += kFastThreads) {
-    const int ty = i / (kTileW + 2 * kHalo), tx = i - ty * (kTileW + 2 * kHalo);
-    int gy = y0 + ty - kHalo, gx = x0 + tx - kHalo;
-    gy     = gy < 0 ? 0 : (gy >= rows ? rows - 1 : gy);
-    gx     = gx < 0 ? 0 : (gx >= cols ? cols - 1 : gx);
-    tile[ty * kTilePitch + tx] = src[(size_t) gy * pitch + gx];
+  // tile + halo.  A tile whose halo lies inside the image takes it in 4-byte pieces (18 per row; global loads may
+  // be unaligned, the LDS stores are not: the tile array and its pitch are multiples of four); tiles on the image
+  // border go byte by byte with clamped coordinates (clamped pixels never reach an output).
+  if (x0 >= kHalo && x0 + kTileW + kHalo <= cols && y0 >= kHalo && y0 + kTileH + kHalo <= rows) {  // (block-uniform)
+    constexpr int kWords = kTilePitch / 4;
+    for (int i = tid; i < (kTileH + 2 * kHalo) * kWords; i += kFastThreads) {
+      const int ty = i / kWords, tw = i - ty * kWords;
+      const uint8_t* g = src + (size_t) (y0 + ty - kHalo) * pitch + (x0 - kHalo) + 4 * tw;
+      uint32_t w;
+      __builtin_memcpy(&w, g, 4);
+      *reinterpret_cast<uint32_t*>(tile + ty * kTilePitch + 4 * tw) = w;
+    }
+  } else {
+    for (int i = tid; i < (kTileH + 2 * kHalo) * (kTileW + 2 * kHalo); i += kFastThreads) {
+      const int ty = i / (kTileW + 2 * kHalo), tx = i - ty * (kTileW + 2 * kHalo);
+      int gy = y0 + ty - kHalo, gx = x0 + tx - kHalo;
+      gy     = gy < 0 ? 0 : (gy >= rows ? rows - 1 : gy);
+      gx     = gx < 0 ? 0 : (gx >= cols ? cols - 1 : gx);
+      tile[ty * kTilePitch + tx] = src[(size_t) gy * pitch + gx];
+    }
   }
   __syncthreads();
   const int t = a.p.detector_threshold;
