@@ -1366,16 +1366,11 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
         if (stid >= 0 && stid < kTerms) {
           const int cnt      = nc - c0 < THREADS ? nc - c0 : THREADS;
           const float4* row4 = reinterpret_cast<const float4*>(terms + stid * kRow);
-          float4 n0 = row4[0], n1 = row4[1], n2 = row4[2], n3 = row4[3];
+          // (no software prefetch: the kernel is bound by instruction issue and eight frames per CU cover the LDS
+          // latency; a second register set costs eight copies per sixteen terms)
           for (int j = 0; j < cnt; j += 16) {
-            const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
-            if (j + 16 < cnt) {
-              const int kk = (j >> 2) + 4;
-              n0 = row4[kk];
-              n1 = row4[kk + 1];
-              n2 = row4[kk + 2];
-              n3 = row4[kk + 3];
-            }
+            const int kk    = j >> 2;
+            const float4 q0 = row4[kk], q1 = row4[kk + 1], q2 = row4[kk + 2], q3 = row4[kk + 3];
             run += q0.x; run += q0.y; run += q0.z; run += q0.w;
             run += q1.x; run += q1.y; run += q1.z; run += q1.w;
             run += q2.x; run += q2.y; run += q2.z; run += q2.w;
