@@ -1341,6 +1341,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
       sh.n_inv = pose_ok ? 0 : nc;
     }
     float run = 0.0f;
+    int wave_inl = 0, wave_out = 0, wave_inv = 0;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) {
@@ -1349,15 +1350,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
         float tv[kTerms];
         int cls;
         factor_terms(g.a, pose, zf[k], pm[k], mean_dsp, c0 + tid < nc, tv, cls);
-        {
-          // inlier / outlier / invalid counts: one LDS atomic per wave and class instead of one per lane
-          const uint64_t m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
-          if ((tid & 63) == 0) {
-            if (m0) atomicAdd(&sh.n_inl, (int) __popcll(m0));
-            if (m1) atomicAdd(&sh.n_out, (int) __popcll(m1));
-            if (m2) atomicAdd(&sh.n_inv, (int) __popcll(m2));
-          }
-        }
+        // inlier / outlier / invalid counts of the wave (scalar), added to the frame's counters once per iteration
+        wave_inl += (int) __popcll(__ballot(cls == 0));
+        wave_out += (int) __popcll(__ballot(cls == 1));
+        wave_inv += (int) __popcll(__ballot(cls == 2));
 #pragma unroll
         for (int t = 0; t < kTerms; ++t) {
           terms[t * kRow + tid] = tv[t];
@@ -1383,6 +1379,11 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
     if (stid >= 0 && stid < kTerms) {
       sh.H[sum_dst0] = run;
       sh.H[sum_dst1] = run;
+    }
+    if ((tid & 63) == 0) {
+      atomicAdd(&sh.n_inl, wave_inl);
+      atomicAdd(&sh.n_out, wave_out);
+      atomicAdd(&sh.n_inv, wave_inv);
     }
     __syncthreads();
     if (stid == 0) {
