@@ -109,15 +109,15 @@ __device__ __forceinline__ int isqrt_exact(int n) {
 }
 
 __device__ __forceinline__ int hamming_regs(const au32x4& a0, const au32x4& a1, const au32x4& b0, const au32x4& b1) {
-  int d = __popc(a0.x ^ b0.x);
-  d += __popc(a0.y ^ b0.y);
-  d += __popc(a0.z ^ b0.z);
-  d += __popc(a0.w ^ b0.w);
-  d += __popc(a1.x ^ b1.x);
-  d += __popc(a1.y ^ b1.y);
-  d += __popc(a1.z ^ b1.z);
-  d += __popc(a1.w ^ b1.w);
-  return d;
+  uint32_t d = (uint32_t) __popc(a0.x ^ b0.x);
+  d = popc_acc(a0.y ^ b0.y, d);
+  d = popc_acc(a0.z ^ b0.z, d);
+  d = popc_acc(a0.w ^ b0.w, d);
+  d = popc_acc(a1.x ^ b1.x, d);
+  d = popc_acc(a1.y ^ b1.y, d);
+  d = popc_acc(a1.z ^ b1.z, d);
+  d = popc_acc(a1.w ^ b1.w, d);
+  return (int) d;
 }
 
 // One correspondence of SE3{,Depth,RectifiedStereo}ProjectiveErrorFactor::errorAndJacobian + saturated
