@@ -1,11 +1,14 @@
 // align.hip -- projective correspondence finder + reprojection-error Gauss-Newton aligner (gfx950).
 //
-// One 256-thread workgroup owns one frame (one sequence) for the WHOLE per-frame loop the external
-// MultiAligner3DQR drives in the reference: up to max_iterations of
+// The per-frame loop the external MultiAligner3DQR drives in the reference, up to max_iterations of
 //     finder.setLocalMapInSensor(X); finder.compute(); slice.setupFactor(); linearize; GN step
-// so the ~100 dependent iterations cost no kernel launches and the frame's working set (lattice
-// database, per-correspondence operands, normal equations, pose, finder state) never leaves the CU.
-// Independent frames/sequences fill the chip: a launch covers `batch` of them.
+// for `batch` independent frames (sequences) per launch.  Two forms, bit-identical:
+//   * the split pipeline (default for PRS_MODE_ALIGN): align_kernel<512, true, pattern> performs ONE projective
+//     search for every frame that waits for it (three workgroups per CU), gn_kernel runs Gauss-Newton iterations
+//     until the finder needs the next search (two waves per frame, eight frames per CU); the host alternates
+//     them, five rounds ahead of a 4-byte readback;
+//   * the fused kernel align_kernel<256, false, -1>: one 256-thread workgroup owns a frame for the whole loop
+//     (finder-only mode, frames whose fixed cloud exceeds the split pipeline's bound, PRS_FUSED_ALIGN=1, phase stamps).
 //
 // Reference code replaced (CF/ = registration/correspondence_finders/):
 //   CorrespondenceFinderProjectiveBase::compute        CF/correspondence_finder_projective_base_impl.cpp:105-293
@@ -1181,7 +1184,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
 }
 
 // ---- split pipeline, GN half -------------------------------------------------------------------------
-// One 256-thread workgroup per frame runs aligner iterations (linearize + damped GN step, with the
+// One workgroup per frame runs aligner iterations (linearize + damped GN step, with the
 // finder's "nothing new" bookkeeping in between) until the finder needs a projective search again or
 // max_iterations is reached.  The per-correspondence operands written by the search kernel sit in
 // registers (<= 8 per thread), so a workgroup needs only the 29 x THREADS term matrix in LDS and many
