@@ -16,9 +16,14 @@
 // appended in the reference's order: bins in the order their first measurement appears, the best
 // candidate (largest disparity / smallest depth, earliest on ties) of each bin.
 //
-// Per-landmark work is tiny and independent; the kernel is bound by the scattered reads and writes
-// of the landmark rows (coordinates 16 B, state 16 B, covariance 36 B, descriptor 32 B, history
-// 28 B per measurement).
+// For the weighted mean and the EKF the per-landmark work is tiny and the kernel is bound by the scattered
+// reads and writes of the landmark rows (coordinates 16 B, state 16 B, covariance 36 B, descriptor 32 B,
+// history 28 B per measurement).  The pose-based smoother is different: up to 100 Gauss-Newton iterations per
+// landmark, a long serial per-lane computation.  It runs as four kernels (merge_batch_launch):
+//   merge_kernel<.., 1>    correspondences, updates that need no iteration, smoother work items queued
+//   smoother_kernel        one wave per frame, rounds of 8 iterations with compaction, exact cycle short-cut
+//   smoother_tail_kernel   the few landmarks per frame that are still iterating, 64 per wave across frames
+//   merge_kernel<.., 2>    additions and the frame's result
 #include "prs_device.h"
 #include "prs_host.h"
 #include "prs_se3.h"

@@ -1,4 +1,5 @@
-// stereo_match.hip -- batched stereo epipolar descriptor matcher for gfx950 (MI355X).
+// stereo_match.hip -- batched stereo epipolar descriptor matcher for gfx950 (MI355X): the general kernel and the
+// dispatch (frames of <= 2048 keypoints are served by stereo_match_v5.hip, same phases with a leaner instruction stream).
 //
 // Replaces CorrespondenceFinderDescriptorBasedEpipolar<..>::compute
 // (registration/correspondence_finders/correspondence_finder_descriptor_based_epipolar_impl.cpp:46-219)
