@@ -758,6 +758,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
               if (r0 <= r1 && cb0 <= cb1) {
                 const int cx0 = cb0 >> g.cell_sx, cx1 = cb1 >> g.cell_sx;
                 // whether the lattice entry e lies inside the search pattern of this query
+                const uint32_t query_rc = ((uint32_t) row & 0xffffu) | ((uint32_t) col << 16);
                 auto accepts = [&](const uint2 e) -> bool {
                   const int drow = (int) (int16_t) (e.x & 0xffffu);
                   const int dcol = (int) (int16_t) (e.x >> 16);
@@ -769,9 +770,12 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                   } else if (stype == PRS_SEARCH_CIRCLE && circle_exact) {
                     // rows [row - r, row + r] (circle_impl.cpp:25-26,40-47) and col - w < dcol < col + w with
                     // w = int(sqrt(r^2 - h^2) + 1) (:51-56) is |dc| <= isqrt(r^2 - h^2), i.e. the integer test
-                    // dc^2 + h^2 <= r^2 (which also implies |h| <= r): no width table, no row compare
-                    const int h = drow - row, dc = dcol - col;
-                    return dc * dc + h * h <= rad2;
+                    // dc^2 + h^2 <= r^2 (which also implies |h| <= r): no width table, no row compare.
+                    // Both differences in one packed 16-bit subtract on the entry's (row | col << 16) word, their
+                    // squares summed by one dot product (no wrap: circle_exact bounds rows, columns and radius).
+                    typedef short i16x2 __attribute__((ext_vector_type(2)));
+                    const i16x2 d = __builtin_bit_cast(i16x2, e.x) - __builtin_bit_cast(i16x2, query_rc);
+                    return __builtin_amdgcn_sdot2(d, d, 0, false) <= rad2;
                   } else if (drow < rmin || drow >= rmax) {
                     return false;  // outside the scanned rows (circle_impl.cpp:40-47)
                   } else if (stype == PRS_SEARCH_SQUARE) {
