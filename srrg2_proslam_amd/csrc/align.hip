@@ -152,6 +152,7 @@ __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const 
   // explicit fused multiply-adds (one rounding each): the factor arithmetic is defined this way on
   // both sides of the parity test
   bool valid;
+  float iz_valid;  // 1 / depth of the real point (the stand-in below reuses it: for a valid point both are the same value)
   {
     const float px = p_in.x, py = p_in.y, pz = p_in.z;
     const float pcx = fmaf(R02, pz, fmaf(R01, py, fmaf(R00, px, t0)));
@@ -161,7 +162,8 @@ __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const 
     const float hy  = fmaf(fy, pcy, cy * pcz);
     const float iz  = 1.0f / pcz;
     const float u_pred = hx * iz, v_pred = hy * iz;
-    valid = active && pcz > 0.0f && !(u_pred < 0.0f || u_pred > a.image_cols || v_pred < 0.0f || v_pred > a.image_rows);
+    valid    = active && pcz > 0.0f && !(u_pred < 0.0f || u_pred > a.image_cols || v_pred < 0.0f || v_pred > a.image_rows);
+    iz_valid = iz;
   }
   // the harmless stand-in: the point (0, 0, 1) seen with zero information and zero error
   const float px = valid ? p_in.x : 0.0f, py = valid ? p_in.y : 0.0f, pz = valid ? p_in.z : 1.0f;
@@ -171,7 +173,7 @@ __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const 
   const float hx  = fmaf(fx, pcx, cx * pcz);
   const float hy  = fmaf(fy, pcy, cy * pcz);
   const float hz  = pcz;
-  const float iz     = valid ? 1.0f / hz : 0.0f;
+  const float iz     = valid ? iz_valid : 0.0f;
   const float u_pred = hx * iz;
   const float v_pred = hy * iz;
   float e0 = u_pred - z.x, e1 = v_pred - z.y, e2 = 0.0f;
