@@ -762,14 +762,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                 // whether the lattice entry e lies inside the search pattern of this query
                 const uint32_t query_rc = ((uint32_t) row & 0xffffu) | ((uint32_t) col << 16);
                 auto accepts = [&](const uint2 e) -> bool {
-                  const int drow = (int) (int16_t) (e.x & 0xffffu);
-                  const int dcol = (int) (int16_t) (e.x >> 16);
-                  if (!lattice) {
-                    // exact radius query (kdtree_impl.cpp:39-50)
-                    const float2 c = fuv[e.y & 0xffffu];
-                    const float du = c.x - u, dv = c.y - v;
-                    return !(du * du + dv * dv > r2f);
-                  } else if (stype == PRS_SEARCH_CIRCLE && circle_exact) {
+                  if (stype == PRS_SEARCH_CIRCLE && circle_exact) {
                     // rows [row - r, row + r] (circle_impl.cpp:25-26,40-47) and col - w < dcol < col + w with
                     // w = int(sqrt(r^2 - h^2) + 1) (:51-56) is |dc| <= isqrt(r^2 - h^2), i.e. the integer test
                     // dc^2 + h^2 <= r^2 (which also implies |h| <= r): no width table, no row compare.
@@ -778,6 +771,14 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                     typedef short i16x2 __attribute__((ext_vector_type(2)));
                     const i16x2 d = __builtin_bit_cast(i16x2, e.x) - __builtin_bit_cast(i16x2, query_rc);
                     return __builtin_amdgcn_sdot2(d, d, 0, false) <= rad2;
+                  }
+                  const int drow = (int) (int16_t) (e.x & 0xffffu);
+                  const int dcol = (int) (int16_t) (e.x >> 16);
+                  if (!lattice) {
+                    // exact radius query (kdtree_impl.cpp:39-50)
+                    const float2 c = fuv[e.y & 0xffffu];
+                    const float du = c.x - u, dv = c.y - v;
+                    return !(du * du + dv * dv > r2f);
                   } else if (drow < rmin || drow >= rmax) {
                     return false;  // outside the scanned rows (circle_impl.cpp:40-47)
                   } else if (stype == PRS_SEARCH_SQUARE) {
