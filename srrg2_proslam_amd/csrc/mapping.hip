@@ -594,7 +594,7 @@ __device__ int smoother_begin(const prs_estimator_params& P, const MergeShared& 
 // POSES_IN_LDS: `pose_cache` holds [frame][21] floats (world_in_sensor 3x4, camera_matrix * R 3x3) of the landmark's map
 // in LDS; otherwise it points at the map's prs_frame_pose table in global memory and the 3x3 product is formed per
 // use with the same expression (the tail kernel, whose lanes belong to different maps).
-constexpr int kSmootherRing = 8;
+constexpr int kSmootherRing = 6;
 template <bool POSES_IN_LDS = true>
 __device__ bool smoother_iterate(const prs_estimator_params& P, const float* pose_cache, const Landmark& l, SmootherItem& item, int budget,
                                  float* ring = nullptr, int ring_lane = 0) {
