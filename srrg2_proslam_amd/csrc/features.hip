@@ -20,7 +20,7 @@
 
 namespace prs {
 
-constexpr int kTileW = 64, kTileH = 16, kFastThreads = 256;
+constexpr int kTileW = 64, kTileH = 64, kFastThreads = 256;
 constexpr int kTilePitch = kTileW + 8;  // 4-px halo on both sides
 constexpr int kNmsThreads = 1024, kSelThreads = 1024;
 constexpr int kMaxRaw = 8192;           // raw detections per image the selection sort can hold
