@@ -167,11 +167,12 @@ __global__ __launch_bounds__(kFastThreads) void fast_box_kernel(const FeatureArg
     if (gx >= 3 && gx < cols - 3 && gy >= 3 && gy < rows - 3) {  // the outermost 3 pixels are not examined
       const uint8_t* c = tile + (sy - 1 + kHalo) * kTilePitch + (sx - 1 + kHalo);
       const int v = c[0];
-      const int n = (int) c[-3 * kTilePitch] - v, e = (int) c[3] - v, so = (int) c[3 * kTilePitch] - v, w = (int) c[-3] - v;
-      const uint32_t b = (n > t ? 1u : 0u) | (e > t ? 2u : 0u) | (so > t ? 4u : 0u) | (w > t ? 8u : 0u);
-      const uint32_t d = (n < -t ? 1u : 0u) | (e < -t ? 2u : 0u) | (so < -t ? 4u : 0u) | (w < -t ? 8u : 0u);
-      // adjacent pairs (N,E) (E,S) (S,W) (W,N): m & rotate-left-by-one(m) on four bits
-      candidate = ((b & ((b << 1) | (b >> 3))) | (d & ((d << 1) | (d >> 3)))) & 0xfu;
+      const int n = c[-3 * kTilePitch], e = c[3], so = c[3 * kTilePitch], w = c[-3];
+      // adjacent pairs (N,E) (E,S) (S,W) (W,N): both brighter than v + t  <=>  the largest pair-minimum is; both
+      // darker than v - t  <=>  the smallest pair-maximum is (min / max instructions, no compare-and-select chains)
+      const int bright = max(max(min(n, e), min(e, so)), max(min(so, w), min(w, n)));
+      const int dark   = min(min(max(n, e), max(e, so)), min(max(so, w), max(w, n)));
+      candidate        = bright > v + t || dark < v - t;
     }
     resp[i] = 0;
     if (candidate) {
