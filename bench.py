@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--moving", type=int, default=2000, help="local-map points per frame")
     ap.add_argument("--max-fixed", type=int, default=896, help="LDS sizing bound on stereo matches per frame")
     ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames generated on the host and tiled")
-    ap.add_argument("--cpu-frames", type=int, default=384, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=1024, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--binned-matcher", action="store_true", help="use the second-generation (row, column-block) binned matcher kernel")
     ap.add_argument("--all-iterations", action="store_true", help="disable the exact fixed-point early exit of the GN loop")
