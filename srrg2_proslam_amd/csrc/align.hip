@@ -136,6 +136,8 @@ __device__ __forceinline__ bool pose_is_finite(const PoseRegs& X) {
   const float s = ((((X.R00 + X.R01) + (X.R02 + X.t0)) + ((X.R10 + X.R11) + (X.R12 + X.t1))) + ((X.R20 + X.R21) + (X.R22 + X.t2)));
   return (s - s) == 0.0f;
 }
+// DIM: the factor type as a compile-time constant (0 = read it from the parameters)
+template <int DIM = 0>
 __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const PoseRegs& X, const float4 z, const float4 p_in,
                                              const float mean_dsp, const bool active, float* tv, int& cls) {
   // Straight-line on purpose: with `tv` live out of nested divergent branches the compiler re-materialises
@@ -148,7 +150,7 @@ __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const 
   const float R10 = X.R10, R11 = X.R11, R12 = X.R12, t1 = X.t1;
   const float R20 = X.R20, R21 = X.R21, R22 = X.R22, t2 = X.t2;
   const float fx = a.fx, fy = a.fy, cx = a.cx, cy = a.cy;
-  const int dim = a.factor_type;
+  const int dim = DIM ? DIM : a.factor_type;
   // explicit fused multiply-adds (one rounding each): the factor arithmetic is defined this way on
   // both sides of the parity test
   bool valid;
@@ -1211,7 +1213,7 @@ struct GnShared {
 };
 
 // THREADS per frame; SLOTS = correspondences per thread the instantiation keeps in registers (ceil(max_fixed / THREADS))
-template <int THREADS, int SLOTS>
+template <int THREADS, int SLOTS, int DIM = 0>
 __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(const AlignArgs g) {
   constexpr int kRow = THREADS + 4;  // row stride of the term matrix (see kGnRow)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1359,7 +1361,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
       if (c0 < nc && pose_ok) {
         float tv[kTerms];
         int cls;
-        factor_terms(g.a, pose, zf[k], pm[k], mean_dsp, c0 + tid < nc, tv, cls);
+        factor_terms<DIM>(g.a, pose, zf[k], pm[k], mean_dsp, c0 + tid < nc, tv, cls);
         // inlier / outlier / invalid counts of the wave (scalar), added to the frame's counters once per iteration
         wave_inl += (int) __popcll(__ballot(cls == 0));
         wave_out += (int) __popcll(__ballot(cls == 1));
@@ -1704,14 +1706,24 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
         ctx_report_stamps(ctx, batch->batch, 10, "search launch (split): - | - | - | - || lattice build | projection+search | second-best pass | filter | commit");
       }
       if (gn_threads == 128) {
+        // (the rectified-stereo factor, the one kitti.conf / euroc.conf use, has its own instantiations: the factor
+        // type as a compile-time constant removes ~10 selects per linearised correspondence)
+        const bool stereo = aligner->factor_type == PRS_FACTOR_STEREO;
+        auto launch_gn    = [&](auto generic, auto for_stereo) {
+          if (stereo) {
+            hipLaunchKernelGGL(for_stereo, dim3(batch->batch), dim3(128), lds_gn, stream, g);
+          } else {
+            hipLaunchKernelGGL(generic, dim3(batch->batch), dim3(128), lds_gn, stream, g);
+          }
+        };
         if (max_fixed <= 4 * 128) {
-          hipLaunchKernelGGL((gn_kernel<128, 4>), dim3(batch->batch), dim3(128), lds_gn, stream, g);
+          launch_gn(gn_kernel<128, 4>, gn_kernel<128, 4, PRS_FACTOR_STEREO>);
         } else if (max_fixed <= 6 * 128) {
-          hipLaunchKernelGGL((gn_kernel<128, 6>), dim3(batch->batch), dim3(128), lds_gn, stream, g);
+          launch_gn(gn_kernel<128, 6>, gn_kernel<128, 6, PRS_FACTOR_STEREO>);
         } else if (max_fixed <= 7 * 128) {
-          hipLaunchKernelGGL((gn_kernel<128, 7>), dim3(batch->batch), dim3(128), lds_gn, stream, g);
+          launch_gn(gn_kernel<128, 7>, gn_kernel<128, 7, PRS_FACTOR_STEREO>);
         } else {
-          hipLaunchKernelGGL((gn_kernel<128, 8>), dim3(batch->batch), dim3(128), lds_gn, stream, g);
+          launch_gn(gn_kernel<128, 8>, gn_kernel<128, 8, PRS_FACTOR_STEREO>);
         }
       } else if (max_fixed <= 2 * kGnThreads) {
         hipLaunchKernelGGL((gn_kernel<kGnThreads, 2>), dim3(batch->batch), dim3(kGnThreads), lds_gn, stream, g);
