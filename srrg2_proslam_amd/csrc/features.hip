@@ -39,183 +39,323 @@ struct FeatureArgs {
   int target_per, regions;
 };
 
-// FAST-9: does a 16-bit circular mask contain 9 contiguous set bits?
-__device__ __forceinline__ bool has_arc9(uint32_t m) {
-  m |= m << 16;  // unroll the circle
-  uint32_t x = m & (m >> 1);
-  x &= x >> 2;   // runs of 4
-  x &= x >> 4;   // runs of 8
-  x &= m >> 8;   // runs of 9
-  return (x & 0xffffu) != 0u;
+// ---- word-parallel helpers: four pixels per 32-bit LDS word, two 16-bit lanes per VALU operation ----
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef short ss2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, (us2) (__builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {  // per lane a - b (sign bit = "a < b" for small values)
+  return __builtin_bit_cast(uint32_t, (ss2) (__builtin_bit_cast(ss2, a) - __builtin_bit_cast(ss2, b)));
+}
+__device__ __forceinline__ uint32_t pk_sign_fill(uint32_t a) {  // per lane 0xffff where negative, else 0
+  return __builtin_bit_cast(uint32_t, (ss2) (__builtin_bit_cast(ss2, a) >> (ss2) (15)));
+}
+__device__ __forceinline__ uint32_t bytes_even(uint32_t x) { return x & 0x00ff00ffu; }                          // bytes 0, 2 -> lanes
+__device__ __forceinline__ uint32_t bytes_odd(uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0c030c01u); }  // bytes 1, 3 -> lanes
+__device__ __forceinline__ int lanes_below(uint64_t m, int base) {  // base + number of set bits of m below this lane
+  return (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, (uint32_t) base));
 }
 
-// FAST-9 response of the pixel at `c` (LDS tile pointer, row pitch kTilePitch): largest threshold that still
-// detects, 0 = no corner at threshold t
-__device__ __forceinline__ int fast_response(const uint8_t* c, int t) {
-  const int v = c[0];
-  int d[16];
-  d[0]  = c[-3 * kTilePitch + 0];
-  d[1]  = c[-3 * kTilePitch + 1];
-  d[2]  = c[-2 * kTilePitch + 2];
-  d[3]  = c[-1 * kTilePitch + 3];
-  d[4]  = c[3];
-  d[5]  = c[1 * kTilePitch + 3];
-  d[6]  = c[2 * kTilePitch + 2];
-  d[7]  = c[3 * kTilePitch + 1];
-  d[8]  = c[3 * kTilePitch + 0];
-  d[9]  = c[3 * kTilePitch - 1];
-  d[10] = c[2 * kTilePitch - 2];
-  d[11] = c[1 * kTilePitch - 3];
-  d[12] = c[-3];
-  d[13] = c[-1 * kTilePitch - 3];
-  d[14] = c[-2 * kTilePitch - 2];
-  d[15] = c[-3 * kTilePitch - 1];
-  uint32_t brighter = 0, darker = 0;
+constexpr int kTileWords  = kTilePitch / 4;   // 18 words per tile row
+constexpr int kTileRows   = kTileH + 8;       // 4-px halo above and below
+constexpr int kListCap    = 1216;             // compass survivors one wave can collect (5 x 256 px is never reached: see the item map)
+constexpr int kSecondCap  = 1152;             // entries one wave can re-examine with the other polarity (18 trips x 64 lanes)
+constexpr uint32_t kBrightFlag = 0x4000u, kDarkFlag = 0x8000u, kIdMask = 0x1fffu;
+
+// FAST-9 score of one polarity at the pixel `c` (LDS tile pointer): the largest arc minimum of s * (circle - centre)
+// over the sixteen arcs of nine pixels; the pixel is a corner of that polarity at threshold t iff the value exceeds t,
+// and its response is then the value - 1 (the largest threshold that still detects).  A bright and a dark arc of nine
+// cannot both fit on sixteen pixels, so at most one polarity of a pixel ever exceeds t.
+__device__ __forceinline__ int arc_best(const uint8_t* c, bool dark) {
+  constexpr int P = kTilePitch;
+  constexpr int off[16] = {-3 * P, -3 * P + 1, -2 * P + 2, -P + 3, 3, P + 3, 2 * P + 2, 3 * P + 1, 3 * P, 3 * P - 1, 2 * P - 2, P - 3, -3, -P - 3, -2 * P - 2, -3 * P - 1};
+  const int s = dark ? -1 : 1, bias = -s * (int) c[0];
+  int e[16], m2[16], m4[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    d[i] -= v;
-    brighter |= (d[i] > t ? 1u : 0u) << i;
-    darker |= (d[i] < -t ? 1u : 0u) << i;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(e[i]) : "v"((int) c[off[i]]), "v"(s), "v"(bias));  // s * (circle - centre), one instruction
   }
-  const bool cb = has_arc9(brighter), cd = has_arc9(darker);
-  if (!cb && !cd) {
-    return 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    m2[i] = min(e[i], e[(i + 1) & 15]);
   }
-  // response = (max over arcs of the arc minimum of |difference|) - 1.  An arc can only be all brighter or
-  // all darker than the centre; when just one polarity fires the other cannot hold the maximum above t
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    m4[i] = min(m2[i], m2[(i + 2) & 15]);
+  }
   int best = -256;
 #pragma unroll
-  for (int sign = 0; sign < 2; ++sign) {
-    if (sign == 0 ? !cb : !cd) {
-      continue;
-    }
-    int e[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      e[i] = sign ? -d[i] : d[i];
-    }
-    int m2[16], m4[16], m8[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      m2[i] = min(e[i], e[(i + 1) & 15]);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      m4[i] = min(m2[i], m2[(i + 2) & 15]);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      m8[i] = min(m4[i], m4[(i + 4) & 15]);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      best = max(best, min(m8[i], e[(i + 8) & 15]));  // minimum over the arc i .. i+8
-    }
+  for (int i = 0; i < 16; ++i) {
+    best = max(best, min(min(m4[i], m4[(i + 4) & 15]), e[(i + 8) & 15]));  // minimum over the arc i .. i+8
   }
-  return best > t ? best - 1 : 0;
+  return best;
 }
 
-// image tile (+ 4-px halo) -> responses of the tile + 1-px ring -> non-maximum suppression in LDS -> the response
-// map holds a non-zero value only at surviving keypoints; 5x5 box sums of the tile on the side
-__global__ __launch_bounds__(kFastThreads) void fast_box_kernel(const FeatureArgs a) {
-  constexpr int kHalo = 4;
-  constexpr int kSW = kTileW + 2, kSH = kTileH + 2;  // response tile with its 1-px ring
-  __shared__ __attribute__((aligned(4))) uint8_t tile[(kTileH + 2 * kHalo) * kTilePitch];
-  __shared__ uint8_t resp[kSH * kSW];
-  __shared__ uint16_t hsum[(kTileH + 4) * kTileW];  // horizontal 5-sums of the tile rows -2 .. kTileH+1
-  __shared__ uint16_t cand[kSH * kSW];              // response-tile positions that pass the compass test
-  __shared__ int n_cand;
-  if (threadIdx.x == 0) {
-    n_cand = 0;
-  }
+// image tile (+ 4-px halo) in LDS -> compass test on four pixels per lane -> survivors (dense lists, one per wave) ->
+// arc minima on dense lanes -> responses of the tile and its 1-px ring -> non-maximum suppression, four pixels per
+// lane; 5x5 box sums of the tile on the side (horizontal pass: one v_qsad_pk_u16_u8 per four pixels).
+template <bool BORDER>
+__device__ __forceinline__ void fast_box_tile(const FeatureArgs& a, uint32_t* tile32, uint32_t* resp32, uint64_t* hsum64, uint16_t (*list)[kListCap],
+                                              uint16_t (*second)[kSecondCap], int* list_n) {
   const int rows = a.b.rows, cols = a.b.cols, pitch = a.b.pitch;
-  const int img  = blockIdx.z;
+  const int img = blockIdx.z;
   const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
   const uint8_t* __restrict__ src = a.b.images + (size_t) img * rows * pitch;
-  const int tid = threadIdx.x;
-  // tile + halo.  A tile whose halo lies inside the image takes it in 4-byte pieces (18 per row; global loads may
-  // be unaligned, the LDS stores are not: the tile array and its pitch are multiples of four); tiles on the image
-  // border go byte by byte with clamped coordinates (clamped pixels never reach an output).
-  if (x0 >= kHalo && x0 + kTileW + kHalo <= cols && y0 >= kHalo && y0 + kTileH + kHalo <= rows) {  // (block-uniform)
-    constexpr int kWords = kTilePitch / 4;
-    for (int i = tid; i < (kTileH + 2 * kHalo) * kWords; i += kFastThreads) {
-      const int ty = i / kWords, tw = i - ty * kWords;
-      const uint8_t* g = src + (size_t) (y0 + ty - kHalo) * pitch + (x0 - kHalo) + 4 * tw;
-      uint32_t w;
-      __builtin_memcpy(&w, g, 4);
-      *reinterpret_cast<uint32_t*>(tile + ty * kTilePitch + 4 * tw) = w;
-    }
-  } else {
-    for (int i = tid; i < (kTileH + 2 * kHalo) * (kTileW + 2 * kHalo); i += kFastThreads) {
-      const int ty = i / (kTileW + 2 * kHalo), tx = i - ty * (kTileW + 2 * kHalo);
-      int gy = y0 + ty - kHalo, gx = x0 + tx - kHalo;
-      gy     = gy < 0 ? 0 : (gy >= rows ? rows - 1 : gy);
-      gx     = gx < 0 ? 0 : (gx >= cols ? cols - 1 : gx);
-      tile[ty * kTilePitch + tx] = src[(size_t) gy * pitch + gx];
-    }
-  }
-  __syncthreads();
-  const int t = a.p.detector_threshold;
-  // Nine contiguous circle pixels always contain two ADJACENT compass points (circle indices 0, 4, 8, 12), so a
-  // pixel can only be a corner if two adjacent compass points are both brighter than v + t or both darker than
-  // v - t.  That four-read test runs for every pixel; the pixels that pass it are collected (order irrelevant) and
-  // the full segment test then runs on dense lanes.
-  for (int i = tid; i < kSH * kSW; i += kFastThreads) {
-    const int sy = i / kSW, sx = i - sy * kSW;
-    const int gx = x0 + sx - 1, gy = y0 + sy - 1;
-    bool candidate = false;
-    if (gx >= 3 && gx < cols - 3 && gy >= 3 && gy < rows - 3) {  // the outermost 3 pixels are not examined
-      const uint8_t* c = tile + (sy - 1 + kHalo) * kTilePitch + (sx - 1 + kHalo);
-      const int v = c[0];
-      const int n = c[-3 * kTilePitch], e = c[3], so = c[3 * kTilePitch], w = c[-3];
-      // adjacent pairs (N,E) (E,S) (S,W) (W,N): both brighter than v + t  <=>  the largest pair-minimum is; both
-      // darker than v - t  <=>  the smallest pair-maximum is (min / max instructions, no compare-and-select chains)
-      const int bright = max(max(min(n, e), min(e, so)), max(min(so, w), min(w, n)));
-      const int dark   = min(min(max(n, e), max(e, so)), min(max(so, w), max(w, n)));
-      candidate        = bright > v + t || dark < v - t;
-    }
-    resp[i] = 0;
-    if (candidate) {
-      cand[atomicAdd(&n_cand, 1)] = (uint16_t) i;
-    }
-  }
-  __syncthreads();
-  for (int j = tid; j < n_cand; j += kFastThreads) {
-    const int i  = cand[j];
-    const int sy = i / kSW, sx = i - sy * kSW;
-    resp[i] = (uint8_t) fast_response(tile + (sy - 1 + kHalo) * kTilePitch + (sx - 1 + kHalo), t);
-  }
-  for (int i = tid; i < (kTileH + 4) * kTileW; i += kFastThreads) {  // separable 5x5 box sum, horizontal pass
-    const int hy = i >> 6, hx = i & 63;
-    const uint8_t* c = tile + (hy - 2 + kHalo) * kTilePitch + (hx + kHalo);
-    hsum[i]          = (uint16_t) (((int) c[-2] + (int) c[-1]) + ((int) c[0] + (int) c[1]) + (int) c[2]);
-  }
-  __syncthreads();
-  const int lx = tid & 63;
-  uint8_t* __restrict__ score = a.score + (size_t) img * rows * cols;
-  uint16_t* __restrict__ box  = a.box + (size_t) img * rows * cols;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(tile32);
+  uint8_t* resp8       = reinterpret_cast<uint8_t*>(resp32);
+  constexpr int kWordsAll = kTileRows * kTileWords;  // 1296
+  // ---- tile + halo: all loads of a lane in flight before the first LDS store ----
+  {
+    uint32_t w[6];
 #pragma unroll
-  for (int k = 0; k < kTileH / 4; ++k) {
-    const int ly = (tid >> 6) + 4 * k;
-    const int gx = x0 + lx, gy = y0 + ly;
-    if (gx >= cols || gy >= rows) {
-      continue;
+    for (int u = 0; u < 6; ++u) {
+      const int i = tid + 256 * u;
+      w[u]        = 0;
+      if (i < kWordsAll) {
+        const int ty = i / kTileWords, tw = i - ty * kTileWords;
+        int gy = y0 + ty - 4;
+        const int gx = x0 - 4 + 4 * tw;
+        if (!BORDER) {
+          __builtin_memcpy(&w[u], src + (size_t) gy * pitch + gx, 4);  // global loads may be unaligned, the LDS stores are not
+        } else {
+          gy = gy < 0 ? 0 : (gy >= rows ? rows - 1 : gy);  // clamped pixels never reach an output
+          const uint8_t* row = src + (size_t) gy * pitch;
+          if (gx >= 0 && gx + 3 < cols) {
+            __builtin_memcpy(&w[u], row + gx, 4);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int x = gx + j < 0 ? 0 : (gx + j >= cols ? cols - 1 : gx + j);
+              w[u] |= (uint32_t) row[x] << (8 * j);
+            }
+          }
+        }
+      }
     }
-    int sum = 0;
-    if (gx >= 2 && gx < cols - 2 && gy >= 2 && gy < rows - 2) {
-      const uint16_t* h = hsum + (ly + 2) * kTileW + lx;  // vertical pass (integer sums: any order gives the same value)
-      sum = ((int) h[-2 * kTileW] + (int) h[-kTileW]) + ((int) h[0] + (int) h[kTileW]) + (int) h[2 * kTileW];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int i = tid + 256 * u;
+      if (i < kWordsAll) {
+        tile32[i] = w[u];
+        resp32[i] = 0;
+      }
     }
-    box[(size_t) gy * cols + gx] = (uint16_t) sum;
-    const uint8_t* q = resp + (ly + 1) * kSW + (lx + 1);
-    int s            = q[0];
-    if (s && a.p.enable_non_maximum_suppression) {
-      // strictly greater than the 8 neighbours; a non-zero response never sits on the outermost 3 pixels, so the
-      // ring values are real responses of real pixels
-      const bool keep = q[-kSW - 1] < s && q[-kSW] < s && q[-kSW + 1] < s && q[-1] < s && q[1] < s && q[kSW - 1] < s && q[kSW] < s && q[kSW + 1] < s;
-      s               = keep ? s : 0;
+  }
+  __syncthreads();
+  const int t       = a.p.detector_threshold;  // 1 .. 254 (checked by the host)
+  const uint32_t T2 = (uint32_t) t * 0x00010001u;
+  const int w1 = tid & 15, r0 = tid >> 4;
+  // ---- compass test.  Nine contiguous circle pixels always contain two ADJACENT compass points (N, E, S, W), and
+  // (N&E)|(E&S)|(S&W)|(W&N) = (N|S)&(E|W): a pixel can only be a bright corner if min(max(N,S), max(E,W)) > v + t,
+  // a dark one if max(min(N,S), min(E,W)) < v - t.  Response-tile rows 0..65 x words 1..16 (response columns 1..64);
+  // the two ring columns follow pixel by pixel.  Entry = tile byte offset | polarity flags.
+  int n_mine         = 0;  // wave-uniform
+  uint16_t* my_list  = list[wave];
+  auto push = [&](uint32_t entry, bool ok) {
+    const uint64_t m = __ballot(ok);
+    if (ok) {
+      my_list[lanes_below(m, n_mine)] = (uint16_t) entry;
     }
-    score[(size_t) gy * cols + gx] = (uint8_t) s;
+    n_mine += __popcll(m);
+  };
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int row = r0 + 16 * k;  // response-tile row; tile row = row + 3
+    bool act      = row < kTileH + 2;
+    if (BORDER) {
+      act = act && (unsigned) (y0 + row - 1 - 3) <= (unsigned) (rows - 7);  // the outermost 3 pixels are not examined
+    }
+    if (k == 4 && wave != 0) {
+      break;  // rows 64, 65 belong to the first 32 lanes
+    }
+    uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;  // no flags: not a candidate
+    if (act) {
+      const int wi = (row + 3) * kTileWords + 1 + w1;
+      const uint32_t C = tile32[wi], N = tile32[wi - 3 * kTileWords], S = tile32[wi + 3 * kTileWords];
+      const uint32_t Wst = __builtin_amdgcn_alignbyte(C, tile32[wi - 1], 1);  // the four pixels 3 to the left
+      const uint32_t Est = __builtin_amdgcn_alignbyte(tile32[wi + 1], C, 3);  // 3 to the right
+      uint32_t code[2];
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const uint32_t c = par ? bytes_odd(C) : bytes_even(C), n = par ? bytes_odd(N) : bytes_even(N), s = par ? bytes_odd(S) : bytes_even(S);
+        const uint32_t e = par ? bytes_odd(Est) : bytes_even(Est), w = par ? bytes_odd(Wst) : bytes_even(Wst);
+        const uint32_t hi = pk_min(pk_max(n, s), pk_max(e, w));
+        const uint32_t lo = pk_max(pk_min(n, s), pk_min(e, w));
+        const uint32_t fb = pk_sub(c + T2, hi);  // lane negative <=> hi > v + t
+        const uint32_t fd = pk_sub(lo + T2, c);  // lane negative <=> lo < v - t
+        code[par]         = ((fb >> 1) & 0x40004000u) | (fd & 0x80008000u);
+      }
+      const uint32_t id0 = 4u * (uint32_t) wi;
+      e0 = (code[0] & 0xc000u) | id0;
+      e1 = (code[1] & 0xc000u) | id0 | 1u;
+      e2 = (code[0] >> 16) | id0 | 2u;
+      e3 = (code[1] >> 16) | id0 | 3u;
+    }
+    bool ok0 = e0 >= kBrightFlag, ok1 = e1 >= kBrightFlag, ok2 = e2 >= kBrightFlag, ok3 = e3 >= kBrightFlag;
+    if (BORDER) {
+      const unsigned gxm3 = (unsigned) (x0 + 4 * w1 - 3), lim = (unsigned) (cols - 7);
+      ok0 = ok0 && gxm3 <= lim;
+      ok1 = ok1 && gxm3 + 1u <= lim;
+      ok2 = ok2 && gxm3 + 2u <= lim;
+      ok3 = ok3 && gxm3 + 3u <= lim;
+    }
+    push(e0, ok0);  // every lane of the wave takes part: the list position is a wave-wide count
+    push(e1, ok1);
+    push(e2, ok2);
+    push(e3, ok3);
+  }
+  if (wave < 3) {  // ring columns: response column 0 (tile x = 3) and 65 (tile x = 68), one pixel per lane
+    const int row = min(tid >> 1, kTileH + 1), tx = (tid & 1) ? kTileW + 4 : 3;
+    bool ok = tid < 2 * (kTileH + 2);
+    if (BORDER) {
+      ok = ok && (unsigned) (y0 + row - 1 - 3) <= (unsigned) (rows - 7) && (unsigned) (x0 + tx - 4 - 3) <= (unsigned) (cols - 7);
+    }
+    const int id     = (row + 3) * kTilePitch + tx;
+    const uint8_t* c = tile8 + id;
+    const int v = c[0], n = c[-3 * kTilePitch], e = c[3], so = c[3 * kTilePitch], w = c[-3];
+    const bool bright = min(max(n, so), max(e, w)) > v + t, dark = max(min(n, so), min(e, w)) < v - t;
+    push((uint32_t) id | (bright ? kBrightFlag : 0u) | (dark ? kDarkFlag : 0u), ok && (bright || dark));
+  }
+  if (lane == 0) {
+    list_n[wave] = n_mine;
+  }
+  // ---- 5x5 box sums, horizontal pass: rows -2 .. kTileH+1 of the tile, four sums per lane.  v_qsad_pk_u16_u8 with a
+  // zero reference adds the four sliding 4-byte windows of a 64-bit source to four 16-bit accumulators; the
+  // accumulators carry the fifth pixel of each window.
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int h = r0 + 16 * k;
+    if (h < kTileH + 4) {
+      const int wi     = (h + 2) * kTileWords + 1 + w1;
+      const uint32_t C = tile32[wi];
+      const uint32_t A = __builtin_amdgcn_alignbyte(C, tile32[wi - 1], 2);  // pixels x-2 .. x+1
+      const uint32_t E = __builtin_amdgcn_alignbyte(tile32[wi + 1], C, 2);  // pixels x+2 .. x+5
+      const uint64_t window = ((uint64_t) E << 32) | A;
+      const uint64_t fifth  = ((uint64_t) __builtin_amdgcn_perm(0u, E, 0x0c030c02u) << 32) | __builtin_amdgcn_perm(0u, E, 0x0c010c00u);
+      hsum64[h * 16 + w1]   = __builtin_amdgcn_qsad_pk_u16_u8(window, 0u, fifth);
+    }
+  }
+  __syncthreads();
+  // ---- arc minima on dense lanes: entry j of the concatenated lists ----
+  const int c0 = list_n[0], c1 = c0 + list_n[1], c2 = c1 + list_n[2], total = c2 + list_n[3];
+  int n_second          = 0;  // wave-uniform
+  uint16_t* my_second   = second[wave];
+  for (int base = 0; base < total; base += kFastThreads) {
+    const int j = base + tid;
+    bool again   = false;
+    int again_id = 0;
+    if (j < total) {
+      const int seg = (j >= c0) + (j >= c1) + (j >= c2);
+      const int off = j - (seg == 0 ? 0 : (seg == 1 ? c0 : (seg == 2 ? c1 : c2)));
+      const uint32_t en = list[seg][off];
+      const int id      = (int) (en & kIdMask);
+      const bool dark   = !(en & kBrightFlag);
+      const int best    = arc_best(tile8 + id, dark);
+      if (best > t) {
+        resp8[id] = (uint8_t) (best - 1);
+      }
+      again = best <= t && (en & (kBrightFlag | kDarkFlag)) == (kBrightFlag | kDarkFlag);  // bright failed, dark still open
+      again_id = id;
+    }
+    const uint64_t m = __ballot(again);  // every lane of the wave takes part
+    if (again) {
+      my_second[lanes_below(m, n_second)] = (uint16_t) again_id;
+    }
+    n_second += __popcll(m);
+  }
+  for (int base = 0; base < n_second; base += 64) {  // this wave's own list: LDS operations of a wave complete in order
+    const int j = base + lane;
+    if (j < n_second) {
+      const int id   = my_second[j];
+      const int best = arc_best(tile8 + id, true);
+      if (best > t) {
+        resp8[id] = (uint8_t) (best - 1);
+      }
+    }
+  }
+  // ---- box sums, vertical pass, straight to memory (integer sums: any order gives the same value) ----
+  uint16_t* __restrict__ box = a.box + (size_t) img * rows * cols;
+#pragma unroll
+  for (int k = 0; k < kTileH / 16; ++k) {
+    const int ly = r0 + 16 * k, gy = y0 + ly, gx = x0 + 4 * w1;
+    const uint64_t* h = hsum64 + ly * 16 + w1;
+    const uint64_t h0 = h[0], h1 = h[16], h2 = h[32], h3 = h[48], h4 = h[64];
+    const uint32_t lo = pk_add(pk_add(pk_add((uint32_t) h0, (uint32_t) h1), pk_add((uint32_t) h2, (uint32_t) h3)), (uint32_t) h4);
+    const uint32_t hi = pk_add(pk_add(pk_add((uint32_t) (h0 >> 32), (uint32_t) (h1 >> 32)), pk_add((uint32_t) (h2 >> 32), (uint32_t) (h3 >> 32))), (uint32_t) (h4 >> 32));
+    if (!BORDER) {
+      const uint64_t v = ((uint64_t) hi << 32) | lo;
+      __builtin_memcpy(box + (size_t) gy * cols + gx, &v, 8);
+    } else if (gy < rows) {
+      const bool row_in = gy >= 2 && gy < rows - 2;
+      const uint32_t s4[4] = {lo & 0xffffu, lo >> 16, hi & 0xffffu, hi >> 16};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (gx + j < cols) {
+          box[(size_t) gy * cols + gx + j] = (uint16_t) (row_in && gx + j >= 2 && gx + j < cols - 2 ? s4[j] : 0u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- non-maximum suppression (strictly greater than the 8 neighbours) and the response map, four pixels per lane.
+  // A non-zero response never sits on the outermost 3 pixels, so the ring values are real responses of real pixels.
+  uint8_t* __restrict__ score = a.score + (size_t) img * rows * cols;
+  const bool nms = a.p.enable_non_maximum_suppression != 0;
+#pragma unroll
+  for (int k = 0; k < kTileH / 16; ++k) {
+    const int ly = r0 + 16 * k, gy = y0 + ly, gx = x0 + 4 * w1;
+    const int wi = (ly + 4) * kTileWords + 1 + w1;
+    const uint32_t Cm = resp32[wi];
+    uint32_t out = Cm;
+    if (nms) {
+      const uint32_t Ct = resp32[wi - kTileWords], Cb = resp32[wi + kTileWords];
+      const uint32_t Lt = __builtin_amdgcn_alignbyte(Ct, resp32[wi - kTileWords - 1], 3), Rt = __builtin_amdgcn_alignbyte(resp32[wi - kTileWords + 1], Ct, 1);
+      const uint32_t Lm = __builtin_amdgcn_alignbyte(Cm, resp32[wi - 1], 3), Rm = __builtin_amdgcn_alignbyte(resp32[wi + 1], Cm, 1);
+      const uint32_t Lb = __builtin_amdgcn_alignbyte(Cb, resp32[wi + kTileWords - 1], 3), Rb = __builtin_amdgcn_alignbyte(resp32[wi + kTileWords + 1], Cb, 1);
+      uint32_t kept[2];
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        auto lanes = [&](uint32_t x) { return par ? bytes_odd(x) : bytes_even(x); };
+        const uint32_t around = pk_max(pk_max(pk_max(lanes(Lt), lanes(Ct)), pk_max(lanes(Rt), lanes(Lm))), pk_max(pk_max(lanes(Rm), lanes(Lb)), pk_max(lanes(Cb), lanes(Rb))));
+        const uint32_t s = lanes(Cm);
+        kept[par]        = s & pk_sign_fill(pk_sub(around, s));  // lane survives <=> largest neighbour < s
+      }
+      out = kept[0] | (kept[1] << 8);
+    }
+    if (!BORDER) {
+      __builtin_memcpy(score + (size_t) gy * cols + gx, &out, 4);
+    } else if (gy < rows) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (gx + j < cols) {
+          score[(size_t) gy * cols + gx + j] = (uint8_t) (out >> (8 * j));
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kFastThreads) void fast_box_kernel(const FeatureArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t tile32[kTileRows * kTileWords];
+  __shared__ __attribute__((aligned(16))) uint32_t resp32[kTileRows * kTileWords];  // same geometry as the tile
+  __shared__ __attribute__((aligned(16))) uint64_t hsum64[(kTileH + 4) * 16];       // horizontal 5-sums, four u16 per item
+  __shared__ uint16_t list[kFastThreads / 64][kListCap];
+  __shared__ uint16_t second[kFastThreads / 64][kSecondCap];
+  __shared__ int list_n[kFastThreads / 64];
+  const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+  // a tile whose halo lies inside the image needs no coordinate checks at all (block-uniform)
+  if (x0 >= 4 && x0 + kTileW + 4 <= a.b.cols && y0 >= 4 && y0 + kTileH + 4 <= a.b.rows) {
+    fast_box_tile<false>(a, tile32, resp32, hsum64, list, second, list_n);
+  } else {
+    fast_box_tile<true>(a, tile32, resp32, hsum64, list, second, list_n);
   }
 }
 
