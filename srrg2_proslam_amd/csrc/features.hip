@@ -9,9 +9,11 @@
 // per-region selection by response follow the in-repo code line by line.
 //
 // Three launches per batch of images:
-//   fast_box_kernel    one 64x16 pixel tile per workgroup (tile + halo in LDS): FAST response map (u8)
-//                      and 5x5 box-sum map (u16); HBM-bound apart from the segment test itself
-//   nms_compact_kernel one workgroup per image: non-maximum suppression + ordered (raster) compaction
+//   fast_box_kernel    one 64x64 pixel tile per workgroup (tile + halo in LDS), four pixels per lane: compass
+//                      test on packed 16-bit lanes, survivors in dense per-wave lists, arc minima on dense
+//                      lanes, non-maximum suppression; suppressed FAST response map (u8) and 5x5 box-sum
+//                      map (u16).  VALU-bound (the image is read once)
+//   nms_compact_kernel one workgroup per image: ordered (raster) compaction of the suppressed response map
 //   select_describe_kernel one workgroup per image: region histogram, one bitonic sort of
 //                      (region, response, order) keys in LDS, per-region selection, border filter,
 //                      256 box-sum comparisons per kept keypoint

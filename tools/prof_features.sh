@@ -1,9 +1,15 @@
+#!/bin/bash
+# rocprofv3 kernel statistics of the feature extractor (tools/bench_features.py); usage on the GPU box: bash tools/prof_features.sh
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_features
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_feat -- python3 $R/tools/bench_features.py 2048 > $R/gpurun_out/prof_feat.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/tools/bench_features.py > $OUT/run.log 2>&1
 python3 - <<PY
-import csv,glob
-for f in glob.glob("$R/gpurun_out/prof_feat/*/*_kernel_stats.csv"):
-    for r in csv.DictReader(open(f)):
-        if "prs::" in r["Name"]: print(r["Name"][:60], r["Calls"], r["AverageNs"], r["Percentage"])
+import csv, glob
+for f in glob.glob("$OUT/*/*_kernel_stats.csv"):
+    for r in list(csv.DictReader(open(f)))[:8]:
+        print("%-90s calls %5s avg %10.1f us  %5s%%" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
 PY
+tail -1 $OUT/run.log
