@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 def test_randomised_clipper_bruteforce_and_feature_cases(oracle, hip_ctx):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_rows
-    out = fuzz_rows.run(10, 20200306, ctx=hip_ctx, oracle=oracle, verbose=False)
+    out = fuzz_rows.run(24, 20200306, ctx=hip_ctx, oracle=oracle, verbose=False)
     for row, (bad, total) in out.items():
         assert bad == 0, row
     assert out["clip"][1] > 1000 and out["bruteforce"][1] > 50 and out["features"][1] > 20

@@ -78,7 +78,7 @@ def fuzz_features(cases, rng, ctx):
     bad = total = 0
     dev = torch.device("cuda", 0)
     for c in range(cases):
-        rows, cols = int(rng.choice([40, 97, 240, 376, 480])), int(rng.choice([64, 131, 640, 1241]))
+        rows, cols = int(rng.choice([7, 40, 68, 97, 132, 133, 240, 376, 480])), int(rng.choice([7, 64, 68, 131, 132, 133, 197, 640, 1241]))  # 132 = the smallest size with a tile whose halo lies inside the image
         # texture: blocks + blobs + noise of random contrast (corners of every strength), sometimes flat regions
         block = int(rng.choice([4, 8, 16]))
         base = rng.integers(0, 256, (rows // block + 1, cols // block + 1)).astype(np.float32)
@@ -87,14 +87,21 @@ def fuzz_features(cases, rng, ctx):
         if rng.random() < 0.3:
             img[: rows // 2] = 128
         img = np.clip(img, 0, 255).astype(np.uint8)
-        threshold = int(rng.choice([5, 15, 25, 60]))
+        threshold = int(rng.choice([1, 5, 15, 25, 60, 120, 254]))
+        nms = int(rng.random() < 0.8)
         target = int(rng.choice([50, 300, 1000, 10 ** 6]))
         grid = (int(rng.integers(1, 5)), int(rng.integers(1, 6)))
         stride = 8192
-        po = of.extractor_params(threshold, 1, target, grid[0], grid[1])
-        pg = ops.extractor_params(threshold, 1, target, grid[0], grid[1])
-        uv, oi, od = of.extract_features(po, img, capacity=1 << 20)
-        t = torch.from_numpy(img[None]).to(dev).contiguous()
+        po = of.extractor_params(threshold, nms, target, grid[0], grid[1])
+        pg = ops.extractor_params(threshold, nms, target, grid[0], grid[1])
+        try:
+            uv, oi, od = of.extract_features(po, img, capacity=1 << 20)
+        except RuntimeError:
+            continue  # more raw detections than the restatement's selection holds
+        pad = int(rng.choice([0, 0, 3, 64]))  # row pitch > cols
+        wide = torch.zeros((1, rows, cols + pad), dtype=torch.uint8, device=dev)
+        wide[:, :, :cols] = torch.from_numpy(img[None]).to(dev)
+        t = wide[:, :, :cols]
         kp = torch.zeros((1, stride, 2), dtype=torch.float32, device=dev)
         desc = torch.zeros((1, stride, 32), dtype=torch.uint8, device=dev)
         inten = torch.zeros((1, stride), dtype=torch.float32, device=dev)
@@ -110,7 +117,7 @@ def fuzz_features(cases, rng, ctx):
               and np.array_equal(inten[0, :ng].cpu().numpy(), oi))
         if not ok:
             bad += 1
-            print("FEATURES MISMATCH case %d %dx%d threshold %d target %d grid %s: %d vs %d" % (c, rows, cols, threshold, target, grid, len(uv), ng))
+            print("FEATURES MISMATCH case %d %dx%d pitch %d threshold %d nms %d target %d grid %s: %d vs %d" % (c, rows, cols, cols + pad, threshold, nms, target, grid, len(uv), ng))
     return bad, total
 
 
