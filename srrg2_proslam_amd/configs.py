@@ -60,7 +60,7 @@ EUROC = {
     # euroc.conf:463-470 (slice), :231-235 (robustifier), :694-698 (damping), :1-15 (aligner)
     "aligner": {"factor_type": FACTOR_STEREO, "diagonal_info": (1.0, 2.0, 1.0), "chi_threshold": 100.0,
                 "enable_inverse_depth_weighting": 1, "damping": 1.0, "max_iterations": 100,
-                "min_num_inliers": 6, "min_num_correspondences": 10},
+                "min_num_inliers": 6, "min_num_correspondences": 0},  # euroc.conf:493
     "depth": {"min": 1.0, "max": 15.0},
 }
 
@@ -82,7 +82,7 @@ ICL = {
     # icl.conf:566-570 (slice), :459-463 (robustifier), :295-299 (damping), :50-64 (aligner)
     "aligner": {"factor_type": FACTOR_DEPTH, "diagonal_info": (1.0, 1.0, 10.0), "chi_threshold": 10.0,
                 "enable_inverse_depth_weighting": 0, "damping": 0.1, "max_iterations": 100,
-                "min_num_inliers": 6, "min_num_correspondences": 10},
+                "min_num_inliers": 6, "min_num_correspondences": 0},  # icl.conf:584
     "depth": {"min": 0.5, "max": 6.0},
 }
 
@@ -104,7 +104,7 @@ TUM = {
     # tum.conf:242-246 (slice), :167-171 (robustifier), :146-150 (damping), :90-104 (aligner)
     "aligner": {"factor_type": FACTOR_DEPTH, "diagonal_info": (1.0, 1.0, 10.0), "chi_threshold": 25.0,
                 "enable_inverse_depth_weighting": 0, "damping": 0.1, "max_iterations": 100,
-                "min_num_inliers": 6, "min_num_correspondences": 10},
+                "min_num_inliers": 6, "min_num_correspondences": 0},  # tum.conf:260
     "depth": {"min": 0.5, "max": 6.0},
 }
 
