@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--from-images", action="store_true",
                     help="start every frame from a rectified 8-bit stereo image pair (feature extraction on the device); "
                          "the scene is a static layered world, the camera steps sideways (use a smaller --batch: the images stay resident)")
+    ap.add_argument("--trajectory", default="", help="write sequence 0's estimated trajectory as <prefix>_kitti.txt and <prefix>_tum.txt "
+                    "(the reference benchmark's formats, apps/app_benchmark.cpp:205-259; 10 Hz timestamps)")
     args = ap.parse_args()
     import torch
     from bench_merge import merger_params
@@ -162,6 +164,7 @@ def main():
     I4 = np.eye(4, dtype=np.float32)
     stream = torch.cuda.Stream(device=dev)
     poses_log = []
+    traj = torch.zeros((K, 16), dtype=torch.float32, device=dev) if args.trajectory else None
 
     def frame(k, ev=None):
         if ev:
@@ -197,6 +200,8 @@ def main():
         ops.merge_batch(ctx, mp, maps)
         if ev:
             ev[4].record()
+        if traj is not None:
+            traj[k].copy_(pose[0].reshape(16), non_blocking=True)  # device-to-device, 64 bytes
 
     with torch.cuda.stream(stream):
         ctx.use_torch_stream()
@@ -211,6 +216,12 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         final_pose = pose[: len(seqs)].cpu().numpy().copy()
+    if traj is not None:
+        from srrg2_proslam_amd import formats
+        # one local map per sequence: its keyframe estimate is the identity, the tracked poses are local to it
+        unrolled = formats.unroll_trajectory([(np.eye(4), [(0.1 * k, T) for k, T in enumerate(traj.cpu().numpy().reshape(K, 4, 4))])])
+        formats.write_trajectory_kitti(args.trajectory + "_kitti.txt", unrolled)
+        formats.write_trajectory_tum(args.trajectory + "_tum.txt", unrolled)
     status = maps.result[:, 2].cpu().numpy()
     if (status < 0).any():
         raise SystemExit("merge reported error %d" % int(status.min()))
