@@ -28,6 +28,7 @@ constexpr int kNmsThreads = 1024, kSelThreads = 1024;
 constexpr int kMaxRaw = 8192;           // raw detections per image the selection sort can hold
 constexpr int kFeatureBorder = 17;      // keypoints closer to the border get no descriptor
 constexpr int kMaxRegions = 256;
+constexpr int kMaxCells = 512;          // 256 pairs name at most 512 distinct cells; 8 x 64 lanes
 
 struct FeatureArgs {
   prs_extractor_params p;
@@ -36,7 +37,11 @@ struct FeatureArgs {
   uint16_t* box;      // [batch][rows][cols] 5x5 sums
   uint32_t* raw;      // [batch][kMaxRaw] response << 24 | pixel index, raster order
   int32_t* n_raw;     // [batch]
-  int8_t pattern[1024];
+  // the descriptor's pair table as the distinct box-sum cells it reads (row-major) and, per comparison, the positions
+  // of its two cells in that list (fill_window_cells)
+  int8_t cell_dy[kMaxCells], cell_dx[kMaxCells];
+  uint16_t pair_first[256], pair_second[256];
+  int n_cells;
   float rows_per, cols_per;
   int target_per, regions;
 };
@@ -466,9 +471,8 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const Feat
   __shared__ uint32_t keys[kMaxRaw];
   __shared__ uint32_t count[kMaxRegions + 1];
   __shared__ uint32_t start[kMaxRegions + 1];
-  __shared__ int8_t pattern[1024];
   __shared__ int wave_tot[kSelThreads / 64];
-  __shared__ uint16_t patch[(kSelThreads / 64) * 27 * 27];  // per wave: box sums around the keypoint being described
+  __shared__ uint16_t patch[(kSelThreads / 64) * kMaxCells];  // per wave: the box sums the pair table reads around the keypoint being described
   const int rows = a.b.rows, cols = a.b.cols;
   const int img  = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -482,9 +486,6 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const Feat
       a.b.status[img]     = PRS_ERR_CAPACITY;
     }
     return;
-  }
-  for (int i = tid; i < 1024; i += kSelThreads) {
-    pattern[i] = a.pattern[i];
   }
   for (int i = tid; i <= a.regions; i += kSelThreads) {
     count[i] = 0;
@@ -596,32 +597,36 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const Feat
   //      texture addresser), then every lane evaluates four comparisons and a ballot IS eight bytes of the
   //      descriptor: bit t lands in byte t / 8, bit t % 8
   {
-    constexpr int kWin = 27;  // offsets -13 .. 13
+    // Only the cells the pair table names are fetched (258 of the 27 x 27 window for the built-in table): the phase
+    // scales with the bytes it pulls through the vector memory path.  Cell e = lane + 64 u.
+    constexpr int kCellLoads = kMaxCells / 64;
     int o1[4], o2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int8_t* pp = pattern + 4 * (64 * j + lane);
-      o1[j]            = ((int) pp[1] + 13) * kWin + ((int) pp[0] + 13);
-      o2[j]            = ((int) pp[3] + 13) * kWin + ((int) pp[2] + 13);
+      o1[j] = a.pair_first[64 * j + lane];
+      o2[j] = a.pair_second[64 * j + lane];
     }
-    uint16_t* win = patch + wave * (kWin * kWin);
+    int cell_off[kCellLoads];
+#pragma unroll
+    for (int u = 0; u < kCellLoads; ++u) {
+      const int e = min(lane + 64 * u, a.n_cells - 1);
+      cell_off[u] = (int) a.cell_dy[e] * cols + (int) a.cell_dx[e];
+    }
+    const int n_loads = (a.n_cells + 63) >> 6;  // (uniform) 5 for the built-in table
+    uint16_t* win = patch + wave * kMaxCells;
     for (int slot = wave; slot < n_kept; slot += kSelThreads / 64) {
       const uint32_t pix = keys[slot];
       const int r = (int) (pix / (uint32_t) cols), c = (int) (pix - (uint32_t) r * (uint32_t) cols);
-      const uint16_t* __restrict__ corner = box + (size_t) (r - 13) * cols + (c - 13);
-      uint16_t v[12];  // 12 x 64 >= 729: all loads are issued before the first one is consumed
+      const uint16_t* __restrict__ centre = box + (size_t) r * cols + c;
+      uint16_t v[kCellLoads];  // all loads are issued before the first one is consumed
 #pragma unroll
-      for (int u = 0; u < 12; ++u) {
-        const int e  = lane + 64 * u;
-        const int ec = e < kWin * kWin ? e : kWin * kWin - 1;
-        const int wr = ec / kWin, wc = ec - wr * kWin;
-        v[u]         = corner[(size_t) wr * cols + wc];
+      for (int u = 0; u < kCellLoads; ++u) {
+        v[u] = u < n_loads ? centre[cell_off[u]] : (uint16_t) 0;
       }
 #pragma unroll
-      for (int u = 0; u < 12; ++u) {
-        const int e = lane + 64 * u;
-        if (e < kWin * kWin) {
-          win[e] = v[u];
+      for (int u = 0; u < kCellLoads; ++u) {
+        if (u < n_loads) {
+          win[lane + 64 * u] = v[u];
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -678,6 +683,32 @@ void fill_brief_pattern(int8_t* pattern) {
   }
 }
 
+// the distinct cells of the pair table in row-major order + every comparison's two positions in that list
+static void fill_window_cells(const int8_t* pattern, FeatureArgs* a) {
+  int16_t index[27 * 27];
+  for (int i = 0; i < 27 * 27; ++i) {
+    index[i] = -1;
+  }
+  for (int t = 0; t < 256; ++t) {
+    for (int k = 0; k < 2; ++k) {
+      index[((int) pattern[4 * t + 2 * k + 1] + 13) * 27 + ((int) pattern[4 * t + 2 * k] + 13)] = 0;
+    }
+  }
+  int n = 0;
+  for (int i = 0; i < 27 * 27; ++i) {
+    if (index[i] == 0) {
+      a->cell_dy[n] = (int8_t) (i / 27 - 13);
+      a->cell_dx[n] = (int8_t) (i % 27 - 13);
+      index[i]      = (int16_t) n++;
+    }
+  }
+  a->n_cells = n;
+  for (int t = 0; t < 256; ++t) {
+    a->pair_first[t]  = (uint16_t) index[((int) pattern[4 * t + 1] + 13) * 27 + ((int) pattern[4 * t] + 13)];
+    a->pair_second[t] = (uint16_t) index[((int) pattern[4 * t + 3] + 13) * 27 + ((int) pattern[4 * t + 2] + 13)];
+  }
+}
+
 int extract_features_launch(prs_context* ctx, const prs_extractor_params* params, const prs_extract_batch* batch) {
   if (!params || !batch || !batch->images) {
     return ctx_fail(ctx, PRS_ERR_NULL, "prs_extract_features_batch: image not set");
@@ -710,7 +741,9 @@ int extract_features_launch(prs_context* ctx, const prs_extractor_params* params
   }
   a.raw   = rawbuf;
   a.n_raw = reinterpret_cast<int32_t*>(rawbuf + (size_t) batch->batch * kMaxRaw);
-  fill_brief_pattern(a.pattern);
+  int8_t pattern[1024];
+  fill_brief_pattern(pattern);
+  fill_window_cells(pattern, &a);
   a.rows_per   = (float) batch->rows / (float) params->number_of_detectors_vertical;   // binned.cpp:52-55
   a.cols_per   = (float) batch->cols / (float) params->number_of_detectors_horizontal;
   a.regions    = regions;
