@@ -369,46 +369,52 @@ __global__ __launch_bounds__(kFastThreads) void fast_box_kernel(const FeatureArg
 // raster-order compaction of the (already suppressed) response map.
 // Every wave owns a contiguous range of the image; it counts its survivors, the 16 counts are scanned once,
 // then the wave rescans its range (response map still in L2) and writes at its offset: two barriers per image.
-__device__ __forceinline__ uint32_t nms_mask4(const FeatureArgs&, const uint8_t* __restrict__, int, int, uint32_t word) {
-  // the response map is already suppressed: survivors are its non-zero bytes
-  return ((word & 0xffu) ? 1u : 0u) | ((word & 0xff00u) ? 2u : 0u) | ((word & 0xff0000u) ? 4u : 0u) | ((word & 0xff000000u) ? 8u : 0u);
+// A lane takes 16 pixels per load, four loads in flight; survivors are the non-zero bytes.
+typedef uint32_t px16 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t w) {  // bit j <=> byte j of the word is non-zero
+  return ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u) | ((w & 0xff0000u) ? 4u : 0u) | ((w & 0xff000000u) ? 8u : 0u);
 }
 
 __global__ __launch_bounds__(kNmsThreads) void nms_compact_kernel(const FeatureArgs a) {
   __shared__ int wave_tot[kNmsThreads / 64];
+  constexpr int kPerLane = 16, kChunk = 64 * kPerLane, kInFlight = 4;
   const int rows = a.b.rows, cols = a.b.cols;
   const int img  = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint8_t* __restrict__ score = a.score + (size_t) img * rows * cols;
   uint32_t* __restrict__ raw        = a.raw + (size_t) img * kMaxRaw;
   const int n_pix = rows * cols;
-  // ranges in units of 256 pixels (64 lanes x 4), so that every lane reads one aligned 32-bit word per step
-  const int n_chunks = (n_pix + 255) / 256;
+  const int n_chunks = (n_pix + kChunk - 1) / kChunk;
   const int per_wave = (n_chunks + kNmsThreads / 64 - 1) / (kNmsThreads / 64);
   const int c_begin = wave * per_wave, c_end = min(c_begin + per_wave, n_chunks);
-  const bool aligned = (((size_t) score) & 3) == 0;
-  auto load4 = [&](int i) -> uint32_t {
-    if (aligned && i + 3 < n_pix) {
-      return *reinterpret_cast<const uint32_t*>(score + i);
+  auto load16 = [&](int ch) -> px16 {
+    px16 r     = {0u, 0u, 0u, 0u};
+    const int i = ch * kChunk + kPerLane * lane;
+    if (ch < c_end && i < n_pix) {
+      if (i + kPerLane <= n_pix) {
+        __builtin_memcpy(&r, score + i, kPerLane);  // any alignment
+      } else {  // the last pixels of the image
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        for (int j = 0; i + j < n_pix; ++j) {
+          w[j >> 2] |= (uint32_t) score[i + j] << (8 * (j & 3));
+        }
+        r = px16{w[0], w[1], w[2], w[3]};
+      }
     }
-    uint32_t w = 0;
-    for (int j = 0; j < 4; ++j) {
-      w |= (i + j < n_pix ? (uint32_t) score[i + j] : 0u) << (8 * j);
-    }
-    return w;
+    return r;
   };
   int mine = 0;
-  for (int ch = c_begin; ch < c_end; ch += 8) {  // eight independent loads in flight per lane
-    uint32_t word[8];
+  for (int ch = c_begin; ch < c_end; ch += kInFlight) {
+    px16 px[kInFlight];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = (ch + u) * 256 + 4 * lane;
-      word[u]     = (ch + u < c_end && i < n_pix) ? load4(i) : 0u;
+    for (int u = 0; u < kInFlight; ++u) {
+      px[u] = load16(ch + u);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (word[u]) {
-        mine += __popc(nms_mask4(a, score, cols, (ch + u) * 256 + 4 * lane, word[u]));
+    for (int u = 0; u < kInFlight; ++u) {
+      if (px[u].x | px[u].y | px[u].z | px[u].w) {
+        mine += __popc(nonzero_bytes(px[u].x) | (nonzero_bytes(px[u].y) << 4) | (nonzero_bytes(px[u].z) << 8) | (nonzero_bytes(px[u].w) << 12));
       }
     }
   }
@@ -427,21 +433,21 @@ __global__ __launch_bounds__(kNmsThreads) void nms_compact_kernel(const FeatureA
     total += wave_tot[w];
   }
   if (total <= kMaxRaw) {
-    for (int ch0 = c_begin; ch0 < c_end; ch0 += 8) {
-      uint32_t words[8];
+    for (int ch0 = c_begin; ch0 < c_end; ch0 += kInFlight) {
+      px16 px[kInFlight];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = (ch0 + u) * 256 + 4 * lane;
-        words[u]    = (ch0 + u < c_end && i < n_pix) ? load4(i) : 0u;
+      for (int u = 0; u < kInFlight; ++u) {
+        px[u] = load16(ch0 + u);
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i         = (ch0 + u) * 256 + 4 * lane;
-        const uint32_t word = words[u];
-        const uint32_t keep = word ? nms_mask4(a, score, cols, i, word) : 0u;
-        if (__ballot(keep != 0u) == 0ull) {
-          continue;  // nothing in these 256 pixels (wave-uniform)
+      for (int u = 0; u < kInFlight; ++u) {
+        const int i          = (ch0 + u) * kChunk + kPerLane * lane;
+        const uint32_t wd[4] = {px[u].x, px[u].y, px[u].z, px[u].w};
+        const bool any       = (wd[0] | wd[1] | wd[2] | wd[3]) != 0u;
+        if (__ballot(any) == 0ull) {
+          continue;  // nothing in these 1024 pixels (wave-uniform)
         }
+        const uint32_t keep = any ? nonzero_bytes(wd[0]) | (nonzero_bytes(wd[1]) << 4) | (nonzero_bytes(wd[2]) << 8) | (nonzero_bytes(wd[3]) << 12) : 0u;
         const int cnt = __popc(keep);
         int incl      = cnt;
 #pragma unroll
@@ -452,10 +458,18 @@ __global__ __launch_bounds__(kNmsThreads) void nms_compact_kernel(const FeatureA
           }
         }
         int slot = offset + incl - cnt;
+        if (any) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if ((keep >> j) & 1u) {
-            raw[slot++] = (((word >> (8 * j)) & 0xffu) << 24) | (uint32_t) (i + j);
+          for (int q = 0; q < 4; ++q) {  // raster order within the lane's 16 pixels
+            if (wd[q]) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const uint32_t s = (wd[q] >> (8 * j)) & 0xffu;
+                if (s) {
+                  raw[slot++] = (s << 24) | (uint32_t) (i + 4 * q + j);
+                }
+              }
+            }
           }
         }
         offset += __shfl(incl, 63, 64);
