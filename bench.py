@@ -150,6 +150,18 @@ def cpu_all_cores(args, n_workers, frames_each):
     return total, ok, time.perf_counter() - t0
 
 
+def valu_busy_fractions():
+    """VALU-busy fraction of the aligner kernels from the committed PMC passes (profiles/rNN/align_pmc.json:
+    SQ_ACTIVE_INST_VALU / (8 x SQ_BUSY_CYCLES)); None when the file is absent.  Evidence, not a live measurement."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "align_pmc.json")
+    try:
+        with open(path) as f:
+            frac = json.load(f)["valu_busy_fraction"]
+        return {k.split("prs::")[-1]: round(v, 3) for k, v in frac.items() if isinstance(v, float) and ("align_kernel" in k or "gn_kernel<128, 7, 4>" in k)}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def pmc_traffic_bytes(kernel_substrings, frames_per_launch, keypoints):
     """HBM bytes per bench step of the named kernels (= per launch for the matcher) from the committed rocprofv3 PMC passes of this same
     command (profiles/rNN/rocprof_summary.json, written by tools/profile_round.sh: FETCH_SIZE and
@@ -340,7 +352,8 @@ def main():
         },
         "roofline_align": {
             "kernel": "align_kernel<512> (projective search) + gn_kernel, all rounds of one step "
-                      "(time-dominant: serial GN chain, latency/issue bound, not HBM bound)",
+                      "(time-dominant; VALU-bound, not HBM-bound: see valu_busy_frac)",
+            "valu_busy_frac": valu_busy_fractions(),
             "bound": "hbm",
             "achieved": gbps_align,
             "peak": HBM_PEAK_GBPS,
