@@ -124,13 +124,8 @@ class AlignResult(C.Structure):
 
 def build(force=False):
     """compile the oracle with its committed Makefile (gcc, seconds)"""
-    src = os.path.join(_HERE, "proslam_oracle.c")
-    hdr = os.path.join(_HERE, "proslam_oracle.h")
-    stale = (
-        force
-        or not os.path.exists(_LIB_PATH)
-        or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))
-    )
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc")) or f == "Makefile"]
+    stale = force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs)
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libproslam_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH

@@ -1,0 +1,248 @@
+"""Restatement of the reference's OWN tests on its OWN test images, shared by the oracle (CPU) and the HIP (GPU) suites.
+
+Every expected value below is a number the reference's gtest files assert on the images under
+/root/reference/test_data (loaded by srrg2_proslam/tests/fixtures.hpp); the images travel as the data fixtures
+tests/golden/ref_*.npz (tools/make_ref_fixtures.py).  A backend `B` is either tests/test_ref_pins.py::OracleBackend or
+tests/test_ref_pins_gpu.py::HipBackend; both expose the same calls, so the scenarios read like the reference's tests.
+"""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+KDTREE, SQUARE, CIRCLE, RHOMBUS = 0, 1, 2, 3
+
+# fixtures.hpp:810-811 / :577
+KITTI_K = dict(fx=718.856, fy=718.856, cx=607.193, cy=185.216, cols=1241, rows=376)
+KITTI_BX = 386.1448
+ICL_K = dict(fx=481.2, fy=-481.0, cx=319.5, cy=239.5, cols=640, rows=480)
+
+_cache = {}
+
+
+def load(name):
+    if name not in _cache:
+        _cache[name] = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return _cache[name]
+
+
+def kitti_image(side, i):
+    return load("ref_kitti")["city_" + side][i]
+
+
+def kitti_pose(i):
+    """camera_i_in_world of sequence 00 (fixtures.hpp:883-904 copies these rows of 00_gt.txt)"""
+    T = np.eye(4)
+    T[:3, :4] = load("ref_kitti_gt")["city_head_f64"][i].reshape(3, 4)
+    return T
+
+
+def kitti_relative(i, j=0):
+    """camera_i_in_j"""
+    return np.linalg.inv(kitti_pose(j)) @ kitti_pose(i)
+
+
+def icl_gray(k):
+    return load("ref_icl")["gray"][{0: 0, 1: 1, 50: 2}[k]]
+
+
+def icl_depth_m(k):
+    """fixtures.hpp:737-740: 16-bit PGM converted with 1e-3"""
+    return load("ref_icl")["depth_mm"][{0: 0, 1: 1, 50: 2}[k]].astype(np.float32) * np.float32(1e-3)
+
+
+def _quat_pose(t, q):
+    w, x, y, z = np.asarray(q, np.float64) / np.linalg.norm(q)
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, t
+    return T
+
+
+# fixtures.hpp:597-608
+ICL_POSE = {0: _quat_pose([0, 0, -2.25], [1, 0, 0, 0]),
+            1: _quat_pose([0.000466347, 0.00895357, -2.24935], [0.999999, -0.00101358, 0.00052453, -0.000231475]),
+            50: _quat_pose([0.129723, 0.00959134, -2.25525], [0.995539, -0.00521396, 0.0821083, 0.0461804])}
+
+
+def icl_relative(i, j=0):
+    return np.linalg.inv(ICL_POSE[j]) @ ICL_POSE[i]
+
+
+def assemble(uv_left, uv_right, corr):
+    """RawDataPreprocessorStereoProjective::compute (raw_data_preprocessor_stereo_projective.cpp:107-132):
+    (uL, vL, uR, vR) per match, matches with a negative horizontal or vertical disparity are dropped"""
+    f, m = corr["fixed_idx"], corr["moving_idx"]
+    pts = np.concatenate([uv_left[f], uv_right[m]], axis=1).astype(np.float32)
+    keep = (pts[:, 0] - pts[:, 2] >= 0) & (pts[:, 1] - pts[:, 3] >= 0)
+    return pts[keep], f[keep]
+
+
+def stereo_adaptor(B, left, right, thr, matcher, max_dist, ratio):
+    """the stereo adaptor with binned extractors (target 500, 3x3) -> (4-D points, their descriptors, left features)"""
+    uvl, dl, _ = B.extract(left, thr, 500, 3, 3)
+    uvr, dr, _ = B.extract(right, thr, 500, 3, 3)
+    if matcher == "epipolar":
+        corr = B.stereo_match(uvl, dl, uvr, dr, max_dist, ratio, 100, 0, rows=left.shape[0])
+    else:
+        corr = B.bruteforce(dl, dr, max_dist, ratio)
+    pts, src = assemble(uvl, uvr, corr)
+    return pts, dl[src], (uvl, dl)
+
+
+def kitti_fixture(B):
+    """KITTI::SetUp (fixtures.hpp:800-1050): adaptor = epipolar matcher (distance 50, Lowe 0.8), FAST threshold 15,
+    500 keypoints; measurements of pair 0 triangulated with minimum disparity 0"""
+    key = ("kitti_fixture", B.name)
+    if key not in _cache:
+        meas, desc = {}, {}
+        for i in (0, 1):
+            meas[i], desc[i], _ = stereo_adaptor(B, kitti_image("left", i), kitti_image("right", i), 15, "epipolar", 50.0, 0.8)
+        xyz, valid = B.triangulate(meas[0], KITTI_K, KITTI_BX, 0.0)
+        assert valid.all()  # fixtures.hpp:953 indicesInvalidated().size() == 0
+        xyz1, valid1 = B.triangulate(meas[1], KITTI_K, KITTI_BX, 0.0)
+        assert valid1.all()
+        _cache[key] = dict(meas=meas, desc=desc, points_in_camera_00=xyz, points_in_camera_01=xyz1)
+    return _cache[key]
+
+
+def icl_measurements(B, k):
+    """ICL::SetUp (fixtures.hpp:565-650): RawDataPreprocessorMonocularDepth with FAST 5 / 500 keypoints, depth scale 1
+    on the metre image (raw_data_preprocessor_monocular_depth.cpp:156-180), unprojected with K"""
+    key = ("icl", B.name, k)
+    if key not in _cache:
+        uv, desc, inten = B.extract(icl_gray(k), 5, 500, 3, 3)
+        depth = icl_depth_m(k)
+        z = depth[np.rint(uv[:, 1]).astype(int), np.rint(uv[:, 0]).astype(int)]
+        keep = z > 0
+        uv, desc, inten, z = uv[keep], desc[keep], inten[keep], z[keep]
+        K = ICL_K
+        xyz = np.stack([(uv[:, 0] - K["cx"]) / K["fx"] * z, (uv[:, 1] - K["cy"]) / K["fy"] * z, z], axis=1).astype(np.float32)
+        _cache[key] = dict(uv=uv, desc=desc, intensity=inten, depth=z, xyz=xyz)
+    return _cache[key]
+
+
+def finder_params(K, search_type, range_min, range_max, max_dist=50.0, min_dist=50.0, ratio=0.9, min_ratio=0.25,
+                  max_radius=100, min_radius=10):
+    """defaults of correspondence_finder_projective_base.h:30-74 / ..bruteforce.h:22-36 unless a test overrides them"""
+    return dict(maximum_descriptor_distance=max_dist, maximum_distance_ratio_to_second_best=ratio, minimum_matching_ratio=min_ratio,
+                minimum_descriptor_distance=min_dist, descriptor_distance_step_size_pixels=5.0,
+                maximum_search_radius_pixels=max_radius, minimum_search_radius_pixels=min_radius, search_radius_step_size_pixels=5,
+                minimum_number_of_iterations=10, maximum_estimate_change_norm_for_convergence=1e-5,
+                number_of_solver_iterations_per_projection=25, search_type=search_type,
+                K=K, range_min=range_min, range_max=range_max)
+
+
+def scene_flow_inliers(points4):
+    """SceneFlow::evaluateStereoMatches (fixtures.hpp:515-535) against gt_stereo_matching_threshold-100.txt
+    (fixtures.hpp:465 loads the file named by detector_threshold = 100)"""
+    gt = {}
+    for r, c, _, _, d in load("ref_scene_flow")["gt_threshold_100"]:
+        gt.setdefault((int(r), int(c)), float(d))  # unordered_map::insert keeps the first entry
+    n = 0
+    for uL, vL, uR, _ in points4:
+        d = gt.get((int(vL), int(uL)))
+        if d is None:
+            continue
+        cl, cr = int(uL), int(uR)
+        est = float(cl - cr) if cl >= cr else float(2 ** 64 - (cr - cl))  # size_t arithmetic of the reference
+        n += abs(d - est) < 1.0
+    return n
+
+
+def t2tnq(T):
+    """geometry3d::t2tnq: translation + imaginary part of the normalised quaternion"""
+    T = np.asarray(T, np.float64)
+    R = T[:3, :3]
+    w = np.sqrt(max(0.0, 1.0 + R[0, 0] + R[1, 1] + R[2, 2])) / 2.0
+    q = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / (4.0 * w)
+    return np.concatenate([T[:3, 3], q])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# scenarios: each returns the observed values next to what the reference asserts
+# ---------------------------------------------------------------------------------------------------------------------
+def feature_counts(B):
+    """test_feature_extractors.cpp:7-22,98-166; test_correspondence_finders.cpp:25,62,116,166,204,458,599"""
+    n = lambda img, thr, target, nv, nh: len(B.extract(img, thr, target, nv, nh)[0])  # noqa: E731
+    got, want = {}, {}
+    got["kitti_fastorb_1x1_t1000"], want["kitti_fastorb_1x1_t1000"] = n(kitti_image("left", 0), 5, 1000, 1, 1), 887
+    for tag, side, i, w in (("00_left", "left", 0, 272), ("01_left", "left", 1, 280), ("00_right", "right", 0, 270), ("01_right", "right", 1, 271)):
+        got["kitti_density_3x3_" + tag], want["kitti_density_3x3_" + tag] = n(kitti_image(side, i), 5, 300, 3, 3), w
+    got["kitti_left0_t500"], want["kitti_left0_t500"] = n(kitti_image("left", 0), 5, 500, 3, 3), 446
+    got["kitti_right0_t500"], want["kitti_right0_t500"] = n(kitti_image("right", 0), 5, 500, 3, 3), 444
+    got["kitti_left1_thr15"], want["kitti_left1_thr15"] = n(kitti_image("left", 1), 15, 500, 3, 3), 458
+    got["kitti_left2_thr15"], want["kitti_left2_thr15"] = n(kitti_image("left", 2), 15, 500, 3, 3), 444
+    for k, w1, w3 in ((0, 259, 220), (1, 254, 228)):
+        got["icl_%02d_1x1_t300" % k], want["icl_%02d_1x1_t300" % k] = n(icl_gray(k), 5, 300, 1, 1), w1
+        got["icl_%02d_3x3_t300" % k], want["icl_%02d_3x3_t300" % k] = n(icl_gray(k), 5, 300, 3, 3), w3
+    for k, w in ((0, 321), (1, 338), (50, 261)):
+        got["icl_%02d_t500" % k], want["icl_%02d_t500" % k] = n(icl_gray(k), 5, 500, 3, 3), w
+    return got, want
+
+
+def kitti_epipolar(B):
+    """test_correspondence_finders.cpp:152-181 (self match) and :240-295 (left to right, thickness 0 and 1)"""
+    uvl, dl, _ = B.extract(kitti_image("left", 0), 5, 500, 3, 3)
+    uvr, dr, _ = B.extract(kitti_image("right", 0), 5, 500, 3, 3)
+    self_match = B.stereo_match(uvl, dl, uvl, dl, 50.0, 0.9, 100, 0, rows=376)
+    t0 = B.stereo_match(uvl, dl, uvr, dr, 50.0, 0.9, 100, 0, rows=376)
+    t1 = B.stereo_match(uvl, dl, uvr, dr, 50.0, 0.9, 100, 1, rows=376)
+    return dict(n_left=len(uvl), self_match=self_match, t0=t0, t1=t1)
+
+
+def kitti_bruteforce(B):
+    """test_correspondence_finders.cpp:183-238"""
+    _, dl, _ = B.extract(kitti_image("left", 0), 5, 500, 3, 3)
+    _, dr, _ = B.extract(kitti_image("right", 0), 5, 500, 3, 3)
+    return B.bruteforce(dl, dr, 50.0, 0.9), B.bruteforce(dr, dl, 50.0, 0.9)
+
+
+def icl_bruteforce(B, a, b):
+    """test_correspondence_finders.cpp:13-150"""
+    da, db = icl_measurements(B, a)["desc"], icl_measurements(B, b)["desc"]
+    return B.bruteforce(da, db, 50.0, 0.9), B.bruteforce(db, da, 50.0, 0.9)
+
+
+def adaptor_counts(B):
+    """test_measurement_adaptors.cpp:7-57 (SceneFlow), :59-89 (ICL), :91-131 (KITTI)"""
+    sf = load("ref_scene_flow")
+    got, want = {}, {}
+    pts, _, _ = stereo_adaptor(B, sf["left"], sf["right"], 5, "bruteforce", 100.0, 0.8)
+    got["scene_flow_bruteforce"], want["scene_flow_bruteforce"] = (len(pts), scene_flow_inliers(pts)), (83, 43)
+    pts, _, _ = stereo_adaptor(B, sf["left"], sf["right"], 5, "epipolar", 100.0, 0.8)
+    got["scene_flow_epipolar"], want["scene_flow_epipolar"] = (len(pts), scene_flow_inliers(pts)), (115, 59)
+    pts, _, _ = stereo_adaptor(B, kitti_image("left", 0), kitti_image("right", 0), 5, "bruteforce", 100.0, 0.8)
+    got["kitti_bruteforce"], want["kitti_bruteforce"] = len(pts), 213
+    pts, _, _ = stereo_adaptor(B, kitti_image("left", 0), kitti_image("right", 0), 5, "epipolar", 100.0, 0.8)
+    got["kitti_epipolar"], want["kitti_epipolar"] = len(pts), 177
+    got["icl_monocular_depth"], want["icl_monocular_depth"] = len(icl_measurements(B, 0)["uv"]), 321
+    return got, want
+
+
+def icl_projective(B, search_type, fixed_frame, T_moving_from_fixed, max_radius=100):
+    """test_correspondence_finders.cpp:297-431: fixed = features of `fixed_frame`, moving = points_in_camera_00"""
+    fx = icl_measurements(B, fixed_frame)
+    mv = icl_measurements(B, 0)
+    f = B.finder(finder_params(ICL_K, search_type, 0.1, 10.0, max_radius=max_radius))
+    f.set_fixed(fx["uv"], fx["desc"])
+    f.set_moving(mv["xyz"], mv["desc"])
+    f.set_local_map_in_sensor(T_moving_from_fixed)
+    corr, _ = f.compute()
+    return f, corr
+
+
+def kitti_projective(B, search_type, frame, radius, T_local_map_in_sensor, thr=15):
+    """test_correspondence_finders.cpp:433-613: fixed = binned features of left image `frame` (FAST 15, the fixture's
+    extractor), moving = points_in_camera_00"""
+    fix = kitti_fixture(B)
+    uv, desc, _ = B.extract(kitti_image("left", frame), thr, 500, 3, 3)
+    f = B.finder(finder_params(KITTI_K, search_type, 0.1, 1000.0, max_radius=radius, min_radius=radius))
+    f.set_fixed(uv, desc)
+    f.set_moving(fix["points_in_camera_00"], fix["desc"][0])
+    f.set_local_map_in_sensor(T_local_map_in_sensor)
+    corr, _ = f.compute()
+    return len(uv), corr

@@ -1,10 +1,16 @@
-"""Oracle pins for SURVEY.md 8f row 3 (feature extraction).  The reference's gates
-(tests/test_feature_extractors.cpp:7-262) count OpenCV detections on dataset images that are not in the
-repository; what can be pinned is the behaviour: FAST finds rectangle corners and nothing on edges or flat areas,
+"""Behaviour pins for SURVEY.md 8f row 3 (feature extraction); the reference's own count gates
+(tests/test_feature_extractors.cpp:7-262) on its own images are in tests/test_ref_pins.py.  Here: FAST finds rectangle
+corners and nothing on edges or flat areas,
 responses grow with contrast, the in-repo region binning (intensity_feature_extractor_binned.cpp:47-196), translation
 covariance of the descriptors, and that a synthetic stereo pair extracts into clouds the epipolar matcher associates
 at the painted disparities."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
 import numpy as np
+import pytest
 
 from oracle import binding as ob
 from oracle import binding_features as of
@@ -80,8 +86,8 @@ def test_F4_descriptors_follow_a_translation():
             assert np.array_equal(d0[i], d1[j])
             hits += 1
     assert hits > 200
-    pat = of.brief_pattern()
-    assert pat.min() >= -13 and pat.max() <= 13 and len({tuple(r) for r in pat}) > 250
+    pat = of.orb_pattern()
+    assert pat.min() >= -13 and pat.max() <= 13 and len({tuple(r) for r in pat}) == 256
 
 
 def test_F5_stereo_pair_extracts_into_matchable_clouds():
@@ -97,4 +103,67 @@ def test_F5_stereo_pair_extracts_into_matchable_clouds():
     disp = uvl[corr["fixed_idx"], 0] - uvr[corr["moving_idx"], 0]
     painted = {2} | {r[4] for r in rects}
     good = np.isin(disp.astype(int), list(painted))
-    assert good.mean() > 0.9 and np.median(corr["response"]) <= 5
+    assert good.mean() > 0.9 and np.median(corr["response"]) <= 16  # random pairs sit at 128 +- 8
+
+
+def test_F6_gaussian_blur_fixed_point():
+    """cv::GaussianBlur(7x7, sigma 2) on 8-bit data: kernel round(256 g) = 18 34 49 55 49 34 18 (sum 257), reflect-101
+    borders, (sum + 2^15) >> 16 -- against a direct numpy evaluation"""
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    k = np.array([18, 34, 49, 55, 49, 34, 18], np.int64)
+    pad = np.pad(img.astype(np.int64), 3, mode="reflect")
+    h = sum(k[i] * pad[:, i:i + 53] for i in range(7))
+    v = sum(k[i] * h[i:i + 37, :] for i in range(7))
+    want = np.minimum((v + (1 << 15)) >> 16, 255).astype(np.uint8)
+    assert np.array_equal(of.gaussian_blur7(img), want)
+    assert of.gaussian_blur7(np.full((20, 20), 255, np.uint8)).min() == 255  # the 257/256 gain saturates
+    assert np.array_equal(of.gaussian_blur7(np.full((9, 9), 100, np.uint8)), np.full((9, 9), 101, np.uint8))
+
+
+_STD_SORT_REF = r"""
+#include <algorithm>
+#include <vector>
+struct KP { float x, y, size, angle, response; int octave, class_id; int order; };  // cv::KeyPoint-sized element
+extern "C" void sort_desc(int n, const int* resp, int* order_out) {
+  std::vector<KP> v(n);
+  for (int i = 0; i < n; ++i) { v[i].response = (float) resp[i]; v[i].order = i; }
+  std::sort(v.begin(), v.end(), [](const KP& a, const KP& b) { return a.response > b.response; });
+  for (int i = 0; i < n; ++i) order_out[i] = v[i].order;
+}
+"""
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++ (GNU libstdc++) to compile the std::sort reference")
+def test_F7_std_sort_restatement_equals_libstdcxx(tmp_path):
+    """orc_std_sort_desc must leave exactly the permutation GNU std::sort leaves (the comparator of
+    intensity_feature_extractor_binned.cpp:182-186 only looks at the response): ties, sorted / reversed runs and
+    inputs that exhaust the depth limit (heapsort fallback)"""
+    src = tmp_path / "std_sort_ref.cpp"
+    src.write_text(_STD_SORT_REF)
+    so = tmp_path / "libstd_sort_ref.so"
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", str(so), str(src)])
+    L = C.CDLL(str(so))
+
+    def ref(x):
+        r = np.ascontiguousarray(x, np.int32)
+        o = np.zeros(len(r), np.int32)
+        L.sort_desc(len(r), r.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p))
+        return o
+
+    rng = np.random.default_rng(5)
+    cases = []
+    for n in list(range(0, 40)) + [100, 257, 1000, 1650, 6000]:
+        for vals in (2, 5, 30, 250, 10 ** 6):
+            cases.append(rng.integers(0, vals, n))
+        cases += [np.arange(n), np.arange(n)[::-1].copy(), np.zeros(n, int)]
+    for n in (200, 1000, 5000):  # structured inputs, many of which reach the heapsort fallback
+        cases.append(np.concatenate([np.arange(0, n, 2), np.arange(1, n, 2)]))
+        for m in (3, 17, 101):
+            cases.append((np.arange(n) * 7919) % m)
+        cases.append(np.abs(np.arange(n) - n // 2) + rng.integers(0, 2, n))
+        cases.append(-np.abs(np.arange(n) - n // 2) + rng.integers(0, 2, n))
+    for x in cases:
+        got = of.std_sort_desc(x)
+        assert np.array_equal(got, ref(x))
+        assert np.all(np.diff(np.asarray(x)[got]) <= 0)
