@@ -556,22 +556,35 @@ PRS_API int prs_pose_compose_batch(prs_context* ctx, int32_t batch, const float*
  * keypoints with non-maximum suppression, the detection-region grid with "keep all below the
  * per-region target, else the best by response" (:47-196, in-repo, restated exactly), then one
  * 256-bit binary descriptor per keypoint.
- * The two OpenCV calls of the reference (cv::FastFeatureDetector, cv::ORB / BRIEF) are NOT part of the
- * reference tree: the detector here is the published FAST-9 segment test on the 16-pixel circle of
- * radius 3 with the arc-minimum response and strict 8-neighbour non-maximum suppression (outermost
- * 3 pixels not examined, raster order); the descriptor is BUILD-DEFINED -- 256 comparisons of 5x5 box
- * sums at point pairs inside a 31x31 patch (fixed table), keypoints closer than 17 px to the border get
- * none and are dropped.  It is not bit-compatible with cv::ORB; a map must be built and tracked with the
- * same extractor.  Outputs have the layout of prs_stereo_batch's inputs.
- * Status per image: PRS_WARN_NO_MATCHES (no keypoints, :126-131), PRS_ERR_CAPACITY (more than 8192
+ * The two OpenCV calls of the reference (cv::FastFeatureDetector::detect, cv::ORB::compute) are NOT part of the
+ * reference tree; they are restated from OpenCV's published algorithms:
+ *  - FAST-9 segment test on the 16-pixel circle of radius 3, response = largest threshold that still detects
+ *    (cornerScore), strict 8-neighbour non-maximum suppression, outermost 3 pixels not examined, raster order;
+ *  - cv::ORB::compute on provided keypoints: keypoints closer than 31 px (edgeThreshold) to the border are removed, no
+ *    orientation (FAST keypoints carry angle -1: the pattern is used unrotated), the image is smoothed with the
+ *    8-bit fixed-point GaussianBlur(7x7, sigma 2) and bit i compares the smoothed pixels of pair i of ORB's learned
+ *    pattern (bit_pattern_31_).
+ * With selection_order = PRS_SELECT_LIBSTDCXX this reproduces every feature / match count the reference's own tests
+ * assert on its own KITTI / ICL / SceneFlow images (tests/test_ref_pins_gpu.py).  Outputs have the layout of
+ * prs_stereo_batch's inputs.
+ * Status per image: PRS_WARN_NO_MATCHES (no keypoints, :126-131), PRS_ERR_CAPACITY (more than max_raw_detections
  * raw detections or more features than `stride`).
  * ============================================================================================== */
+/* which of several EQUAL responses survive the per-region cut (intensity_feature_extractor_binned.cpp:179-195 uses
+ * std::sort with a response-only comparator, so the answer is implementation defined):
+ *   PRS_SELECT_CANONICAL  ties in detection (raster) order; parallel sort, the fast path
+ *   PRS_SELECT_LIBSTDCXX  the permutation GNU libstdc++'s std::sort produces; one lane per region runs the same
+ *                         introsort sequentially (slower), results identical to a reference built with GCC */
+enum { PRS_SELECT_CANONICAL = 0, PRS_SELECT_LIBSTDCXX = 1 };
+
 typedef struct {
   int32_t detector_threshold;             /* intensity_feature_extractor_base.h:36-40; in [1, 254] */
   int32_t enable_non_maximum_suppression; /* :48-52 */
   int32_t target_number_of_keypoints;     /* :54-58 */
   int32_t number_of_detectors_vertical;   /* intensity_feature_extractor_binned.h:17-22 */
   int32_t number_of_detectors_horizontal; /* :23-28 */
+  int32_t selection_order;                /* PRS_SELECT_* */
+  int32_t max_raw_detections;             /* FAST detections per image the selection can hold: 0 = 8192, at most 32768 */
 } prs_extractor_params;
 
 typedef struct {

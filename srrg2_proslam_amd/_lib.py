@@ -237,7 +237,8 @@ class ExtractorParams(C.Structure):
     """prs_extractor_params"""
     _fields_ = [("detector_threshold", C.c_int32), ("enable_non_maximum_suppression", C.c_int32),
                 ("target_number_of_keypoints", C.c_int32), ("number_of_detectors_vertical", C.c_int32),
-                ("number_of_detectors_horizontal", C.c_int32)]
+                ("number_of_detectors_horizontal", C.c_int32), ("selection_order", C.c_int32),
+                ("max_raw_detections", C.c_int32)]
 
 
 class ExtractBatch(C.Structure):

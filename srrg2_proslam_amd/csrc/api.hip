@@ -601,17 +601,36 @@ int prs_bruteforce_match(prs_context* ctx,
   b.matches            = reinterpret_cast<prs_corr*>(d + b_f + b_m + b_s);
   b.n_matches          = reinterpret_cast<int32_t*>(d + b_f + b_m + 8);
   b.status             = reinterpret_cast<int32_t*>(d + b_f + b_m + 12);
-  b.candidate_capacity = 0;
-  const int rc = bruteforce_batch_launch(ctx, params, &b);
-  if (rc != PRS_OK) {
-    return rc;
-  }
-  e = hipMemcpyAsync(h + b_f + b_m, d + b_f + b_m, b_s + b_out, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) {
-    e = hipStreamSynchronize(s);
-  }
-  if (e != hipSuccess) {
-    return ctx_fail_hip(ctx, e, "prs_bruteforce_match download");
+  // the candidate list defaults to 16 entries per descriptor; a loose threshold on correlated descriptors can need more
+  // (at most every pair): grow and repeat, like the reference's std::vector would
+  const long long all_pairs = (long long) n_fixed * (long long) n_moving;
+  long long cand_cap        = 16ll * (long long) (n_fixed > n_moving ? n_fixed : n_moving);
+  for (;;) {
+    if (cand_cap > all_pairs) {
+      cand_cap = all_pairs;
+    }
+    b.candidate_capacity = (int32_t) (cand_cap > 0x7fffffffll ? 0x7fffffffll : cand_cap);
+    const int rc         = bruteforce_batch_launch(ctx, params, &b);
+    if (rc != PRS_OK) {
+      return rc;
+    }
+    e = hipMemcpyAsync(h + b_f + b_m, d + b_f + b_m, b_s + b_out, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) {
+      e = hipStreamSynchronize(s);
+    }
+    if (e != hipSuccess) {
+      return ctx_fail_hip(ctx, e, "prs_bruteforce_match download");
+    }
+    if (hs[3] != PRS_ERR_CAPACITY || cand_cap >= all_pairs) {
+      break;
+    }
+    cand_cap *= 8;
+    hs[2] = 0;
+    hs[3] = 0;
+    e     = hipMemcpyAsync(d + b_f + b_m, h + b_f + b_m, b_s, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+      return ctx_fail_hip(ctx, e, "prs_bruteforce_match upload");
+    }
   }
   if (hs[3] < 0) {
     return ctx_fail(ctx, hs[3], "prs_bruteforce_match: more candidates below the threshold than the kernel's candidate capacity");

@@ -2,21 +2,21 @@
 // IntensityFeatureExtractorBinned_::computeKeypoints + compute
 // (sensor_processing/feature_extractors/intensity_feature_extractor_binned.cpp:7-208,
 //  intensity_feature_extractor_base.cpp:56-95) around the two OpenCV calls the reference makes:
-// FAST detection with non-maximum suppression (:121-123) and a 256-bit binary descriptor (:139-170).
-// OpenCV is not part of the reference tree: the detector is the published FAST-9 segment test with the
-// arc-minimum response, the descriptor is BUILD-DEFINED (BRIEF-style comparisons of 5x5 box sums, pair
-// table from a fixed linear congruential sequence) -- see include/proslam_hip.h.  The region grid and the
-// per-region selection by response follow the in-repo code line by line.
+// cv::FastFeatureDetector::detect with non-maximum suppression (:121-123) and cv::ORB::compute (:139-170).
+// OpenCV is not part of the reference tree; both are restated from their published algorithms (see
+// include/proslam_hip.h) and the restatement is pinned by the counts the reference's own tests assert on its own
+// test images (tests/test_ref_pins_gpu.py).  The region grid and the per-region selection by response follow the
+// in-repo code line by line; PRS_SELECT_LIBSTDCXX reproduces the tie order of GNU std::sort there.
 //
 // Three launches per batch of images:
-//   fast_box_kernel    one 64x64 pixel tile per workgroup (tile + halo in LDS), four pixels per lane: compass
+//   fast_blur_kernel   one 64x64 pixel tile per workgroup (tile + halo in LDS), four pixels per lane: compass
 //                      test on packed 16-bit lanes, survivors in dense per-wave lists, arc minima on dense
-//                      lanes, non-maximum suppression; suppressed FAST response map (u8) and 5x5 box-sum
-//                      map (u16).  VALU-bound (the image is read once)
+//                      lanes, non-maximum suppression; suppressed FAST response map (u8) and the 7x7 Gaussian
+//                      (fixed point, what ORB samples) of the tile (u8).  VALU-bound (the image is read once)
 //   nms_compact_kernel one workgroup per image: ordered (raster) compaction of the suppressed response map
 //   select_describe_kernel one workgroup per image: region histogram, one bitonic sort of
 //                      (region, response, order) keys in LDS, per-region selection, border filter,
-//                      256 box-sum comparisons per kept keypoint
+//                      256 comparisons of smoothed pixels per kept keypoint
 #include "prs_device.h"
 #include "prs_host.h"
 
@@ -25,19 +25,23 @@ namespace prs {
 constexpr int kTileW = 64, kTileH = 64, kFastThreads = 256;
 constexpr int kTilePitch = kTileW + 8;  // 4-px halo on both sides
 constexpr int kNmsThreads = 1024, kSelThreads = 1024;
-constexpr int kMaxRaw = 8192;           // raw detections per image the selection sort can hold
-constexpr int kFeatureBorder = 17;      // keypoints closer to the border get no descriptor
+constexpr int kDefaultRaw = 8192;       // raw detections per image the selection sort holds by default
+constexpr int kMaxRawLimit = 32768;     // ... at most (prs_extractor_params.max_raw_detections; 128 KB of LDS keys)
+constexpr int kFeatureBorder = 31;      // cv::ORB edgeThreshold: keypoints closer to the border are removed (runByImageBorder)
 constexpr int kMaxRegions = 256;
 constexpr int kMaxCells = 512;          // 256 pairs name at most 512 distinct cells; 8 x 64 lanes
+// cv::GaussianBlur(7x7, sigma 2) on 8-bit data: round(256 * exp(-x^2 / 8) / sum), sum of the taps = 257
+constexpr uint32_t kG0 = 18, kG1 = 34, kG2 = 49, kG3 = 55;
 
 struct FeatureArgs {
   prs_extractor_params p;
   prs_extract_batch b;
   uint8_t* score;     // [batch][rows][cols]
-  uint16_t* box;      // [batch][rows][cols] 5x5 sums
-  uint32_t* raw;      // [batch][kMaxRaw] response << 24 | pixel index, raster order
+  uint8_t* blur;      // [batch][rows][cols] smoothed image (defined 3 px inside the border; ORB reads >= 18 px inside)
+  uint32_t* raw;      // [batch][max_raw] response << 24 | pixel index, raster order
   int32_t* n_raw;     // [batch]
-  // the descriptor's pair table as the distinct box-sum cells it reads (row-major) and, per comparison, the positions
+  int max_raw;        // capacity of `raw` and of the selection sort (power of two)
+  // the descriptor's pair table as the distinct smoothed pixels it reads (row-major) and, per comparison, the positions
   // of its two cells in that list (fill_window_cells)
   int8_t cell_dy[kMaxCells], cell_dx[kMaxCells];
   uint16_t pair_first[256], pair_second[256];
@@ -107,9 +111,9 @@ __device__ __forceinline__ int arc_best(const uint8_t* c, bool dark) {
 
 // image tile (+ 4-px halo) in LDS -> compass test on four pixels per lane -> survivors (dense lists, one per wave) ->
 // arc minima on dense lanes -> responses of the tile and its 1-px ring -> non-maximum suppression, four pixels per
-// lane; 5x5 box sums of the tile on the side (horizontal pass: one v_qsad_pk_u16_u8 per four pixels).
+// lane; the separable 7x7 Gaussian of the tile on the side (packed 16-bit horizontal pass, 32-bit vertical pass).
 template <bool BORDER>
-__device__ __forceinline__ void fast_box_tile(const FeatureArgs& a, uint32_t* tile32, uint32_t* resp32, uint64_t* hsum64, uint16_t (*list)[kListCap],
+__device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* tile32, uint32_t* resp32, uint64_t* hsum64, uint16_t (*list)[kListCap],
                                               uint16_t (*second)[kSecondCap], int* list_n) {
   const int rows = a.b.rows, cols = a.b.cols, pitch = a.b.pitch;
   const int img = blockIdx.z;
@@ -234,20 +238,26 @@ __device__ __forceinline__ void fast_box_tile(const FeatureArgs& a, uint32_t* ti
   if (lane == 0) {
     list_n[wave] = n_mine;
   }
-  // ---- 5x5 box sums, horizontal pass: rows -2 .. kTileH+1 of the tile, four sums per lane.  v_qsad_pk_u16_u8 with a
-  // zero reference adds the four sliding 4-byte windows of a 64-bit source to four 16-bit accumulators; the
-  // accumulators carry the fifth pixel of each window.
+  // ---- 7x7 Gaussian, horizontal pass: tile rows -3 .. kTileH+2, four sums per lane on packed 16-bit lanes.  The taps are
+  // symmetric: 55 c + 49 (l1 + r1) + 34 (l2 + r2) + 18 (l3 + r3) <= 257 * 255 = 65535 fits the lane exactly.
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     const int h = r0 + 16 * k;
-    if (h < kTileH + 4) {
-      const int wi     = (h + 2) * kTileWords + 1 + w1;
-      const uint32_t C = tile32[wi];
-      const uint32_t A = __builtin_amdgcn_alignbyte(C, tile32[wi - 1], 2);  // pixels x-2 .. x+1
-      const uint32_t E = __builtin_amdgcn_alignbyte(tile32[wi + 1], C, 2);  // pixels x+2 .. x+5
-      const uint64_t window = ((uint64_t) E << 32) | A;
-      const uint64_t fifth  = ((uint64_t) __builtin_amdgcn_perm(0u, E, 0x0c030c02u) << 32) | __builtin_amdgcn_perm(0u, E, 0x0c010c00u);
-      hsum64[h * 16 + w1]   = __builtin_amdgcn_qsad_pk_u16_u8(window, 0u, fifth);
+    if (h < kTileH + 6) {
+      const int wi      = (h + 1) * kTileWords + 1 + w1;
+      const uint32_t C = tile32[wi], L = tile32[wi - 1], R = tile32[wi + 1];
+      const uint32_t l3 = __builtin_amdgcn_alignbyte(C, L, 1), l2 = __builtin_amdgcn_alignbyte(C, L, 2), l1 = __builtin_amdgcn_alignbyte(C, L, 3);
+      const uint32_t r1 = __builtin_amdgcn_alignbyte(R, C, 1), r2 = __builtin_amdgcn_alignbyte(R, C, 2), r3 = __builtin_amdgcn_alignbyte(R, C, 3);
+      uint32_t sum[2];
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        auto lanes = [&](uint32_t x) { return par ? bytes_odd(x) : bytes_even(x); };
+        const us2 s1 = __builtin_bit_cast(us2, pk_add(lanes(l1), lanes(r1))), s2 = __builtin_bit_cast(us2, pk_add(lanes(l2), lanes(r2)));
+        const us2 s3 = __builtin_bit_cast(us2, pk_add(lanes(l3), lanes(r3))), c = __builtin_bit_cast(us2, lanes(C));
+        const us2 acc = c * (us2) ((unsigned short) kG3) + s1 * (us2) ((unsigned short) kG2) + s2 * (us2) ((unsigned short) kG1) + s3 * (us2) ((unsigned short) kG0);
+        sum[par]      = __builtin_bit_cast(uint32_t, acc);
+      }
+      hsum64[h * 16 + w1] = ((uint64_t) sum[1] << 32) | sum[0];  // lanes: pixel 0 | pixel 2 , pixel 1 | pixel 3
     }
   }
   __syncthreads();
@@ -288,25 +298,31 @@ __device__ __forceinline__ void fast_box_tile(const FeatureArgs& a, uint32_t* ti
       }
     }
   }
-  // ---- box sums, vertical pass, straight to memory (integer sums: any order gives the same value) ----
-  uint16_t* __restrict__ box = a.box + (size_t) img * rows * cols;
+  // ---- Gaussian, vertical pass, straight to memory: (sum + 2^15) >> 16, saturated (the taps sum to 257 / 256) ----
+  uint8_t* __restrict__ blur = a.blur + (size_t) img * rows * cols;
 #pragma unroll
   for (int k = 0; k < kTileH / 16; ++k) {
     const int ly = r0 + 16 * k, gy = y0 + ly, gx = x0 + 4 * w1;
-    const uint64_t* h = hsum64 + ly * 16 + w1;
-    const uint64_t h0 = h[0], h1 = h[16], h2 = h[32], h3 = h[48], h4 = h[64];
-    const uint32_t lo = pk_add(pk_add(pk_add((uint32_t) h0, (uint32_t) h1), pk_add((uint32_t) h2, (uint32_t) h3)), (uint32_t) h4);
-    const uint32_t hi = pk_add(pk_add(pk_add((uint32_t) (h0 >> 32), (uint32_t) (h1 >> 32)), pk_add((uint32_t) (h2 >> 32), (uint32_t) (h3 >> 32))), (uint32_t) (h4 >> 32));
+    const uint64_t* h = hsum64 + ly * 16 + w1;  // row ly of the tile is horizontal row ly + 3: rows ly .. ly + 6
+    uint32_t acc[4] = {1u << 15, 1u << 15, 1u << 15, 1u << 15};
+    constexpr uint32_t taps[7] = {kG0, kG1, kG2, kG3, kG2, kG1, kG0};
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const uint64_t hv = h[16 * i];
+      const uint32_t ev = (uint32_t) hv, od = (uint32_t) (hv >> 32);
+      acc[0] += taps[i] * (ev & 0xffffu);
+      acc[1] += taps[i] * (od & 0xffffu);
+      acc[2] += taps[i] * (ev >> 16);
+      acc[3] += taps[i] * (od >> 16);
+    }
+    const uint32_t out = min(acc[0] >> 16, 255u) | (min(acc[1] >> 16, 255u) << 8) | (min(acc[2] >> 16, 255u) << 16) | (min(acc[3] >> 16, 255u) << 24);
     if (!BORDER) {
-      const uint64_t v = ((uint64_t) hi << 32) | lo;
-      __builtin_memcpy(box + (size_t) gy * cols + gx, &v, 8);
+      __builtin_memcpy(blur + (size_t) gy * cols + gx, &out, 4);
     } else if (gy < rows) {
-      const bool row_in = gy >= 2 && gy < rows - 2;
-      const uint32_t s4[4] = {lo & 0xffffu, lo >> 16, hi & 0xffffu, hi >> 16};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (gx + j < cols) {
-          box[(size_t) gy * cols + gx + j] = (uint16_t) (row_in && gx + j >= 2 && gx + j < cols - 2 ? s4[j] : 0u);
+          blur[(size_t) gy * cols + gx + j] = (uint8_t) (out >> (8 * j));
         }
       }
     }
@@ -350,19 +366,19 @@ __device__ __forceinline__ void fast_box_tile(const FeatureArgs& a, uint32_t* ti
   }
 }
 
-__global__ __launch_bounds__(kFastThreads) void fast_box_kernel(const FeatureArgs a) {
+__global__ __launch_bounds__(kFastThreads) void fast_blur_kernel(const FeatureArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t tile32[kTileRows * kTileWords];
   __shared__ __attribute__((aligned(16))) uint32_t resp32[kTileRows * kTileWords];  // same geometry as the tile
-  __shared__ __attribute__((aligned(16))) uint64_t hsum64[(kTileH + 4) * 16];       // horizontal 5-sums, four u16 per item
+  __shared__ __attribute__((aligned(16))) uint64_t hsum64[(kTileH + 6) * 16];       // horizontal 7-tap sums, four u16 per item
   __shared__ uint16_t list[kFastThreads / 64][kListCap];
   __shared__ uint16_t second[kFastThreads / 64][kSecondCap];
   __shared__ int list_n[kFastThreads / 64];
   const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
   // a tile whose halo lies inside the image needs no coordinate checks at all (block-uniform)
   if (x0 >= 4 && x0 + kTileW + 4 <= a.b.cols && y0 >= 4 && y0 + kTileH + 4 <= a.b.rows) {
-    fast_box_tile<false>(a, tile32, resp32, hsum64, list, second, list_n);
+    fast_blur_tile<false>(a, tile32, resp32, hsum64, list, second, list_n);
   } else {
-    fast_box_tile<true>(a, tile32, resp32, hsum64, list, second, list_n);
+    fast_blur_tile<true>(a, tile32, resp32, hsum64, list, second, list_n);
   }
 }
 
@@ -383,7 +399,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_compact_kernel(const FeatureA
   const int img  = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint8_t* __restrict__ score = a.score + (size_t) img * rows * cols;
-  uint32_t* __restrict__ raw        = a.raw + (size_t) img * kMaxRaw;
+  uint32_t* __restrict__ raw        = a.raw + (size_t) img * a.max_raw;
   const int n_pix = rows * cols;
   const int n_chunks = (n_pix + kChunk - 1) / kChunk;
   const int per_wave = (n_chunks + kNmsThreads / 64 - 1) / (kNmsThreads / 64);
@@ -432,7 +448,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_compact_kernel(const FeatureA
     offset += w < wave ? wave_tot[w] : 0;
     total += wave_tot[w];
   }
-  if (total <= kMaxRaw) {
+  if (total <= a.max_raw) {
     for (int ch0 = c_begin; ch0 < c_end; ch0 += kInFlight) {
       px16 px[kInFlight];
 #pragma unroll
@@ -477,22 +493,169 @@ __global__ __launch_bounds__(kNmsThreads) void nms_compact_kernel(const FeatureA
     }
   }
   if (tid == 0) {
-    a.n_raw[img] = total > kMaxRaw ? -1 : total;
+    a.n_raw[img] = total > a.max_raw ? -1 : total;
+  }
+}
+
+// ---- GNU libstdc++ std::sort (bits/stl_algo.h, bits/stl_heap.h) on packed items, comparator a.response > b.response
+// (intensity_feature_extractor_binned.cpp:182-186): the response is the low byte of an item, the rest rides along.
+// One lane runs it for one region (tests compare the permutation with what g++ itself produces).
+__device__ __forceinline__ bool scomp(uint32_t a, uint32_t b) {
+  return (a & 0xffu) > (b & 0xffu);
+}
+
+__device__ void std_adjust_heap(uint32_t* first, int hole, int len, uint32_t value) {
+  const int top = hole;
+  int child     = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (scomp(first[child], first[child - 1])) {
+      --child;
+    }
+    first[hole] = first[child];
+    hole        = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child       = 2 * (child + 1);
+    first[hole] = first[child - 1];
+    hole        = child - 1;
+  }
+  int parent = (hole - 1) / 2;  // __push_heap
+  while (hole > top && scomp(first[parent], value)) {
+    first[hole] = first[parent];
+    hole        = parent;
+    parent      = (hole - 1) / 2;
+  }
+  first[hole] = value;
+}
+
+__device__ void std_heapsort(uint32_t* first, int len) {  // __partial_sort(first, last, last)
+  if (len >= 2) {
+    for (int parent = (len - 2) / 2;; --parent) {
+      std_adjust_heap(first, parent, len, first[parent]);
+      if (parent == 0) {
+        break;
+      }
+    }
+  }
+  for (int last = len - 1; last >= 1; --last) {  // __sort_heap: __pop_heap(first, last, last)
+    const uint32_t value = first[last];
+    first[last]          = first[0];
+    std_adjust_heap(first, 0, last, value);
+  }
+}
+
+__device__ __forceinline__ void std_unguarded_linear_insert(uint32_t* v, int last) {
+  const uint32_t val = v[last];
+  int next           = last - 1;
+  while (scomp(val, v[next])) {
+    v[last] = v[next];
+    last    = next;
+    --next;
+  }
+  v[last] = val;
+}
+
+__device__ void std_insertion_sort(uint32_t* v, int first, int last) {
+  for (int i = first + 1; i < last; ++i) {
+    if (scomp(v[i], v[first])) {
+      const uint32_t val = v[i];
+      for (int j = i; j > first; --j) {
+        v[j] = v[j - 1];
+      }
+      v[first] = val;
+    } else {
+      std_unguarded_linear_insert(v, i);
+    }
+  }
+}
+
+__device__ void std_sort_desc(uint32_t* v, int n) {
+  if (n <= 0) {
+    return;
+  }
+  int lg = 0;
+  for (int m = n; m > 1; m >>= 1) {
+    ++lg;
+  }
+  // __introsort_loop with an explicit stack: the recursion takes the right part, the loop continues on the left; the
+  // parts are disjoint, so the order in which they are finished does not change the result
+  int st_first[64], st_last[64], st_depth[64];
+  int sp       = 0;
+  st_first[0]  = 0;
+  st_last[0]   = n;
+  st_depth[0]  = 2 * lg;
+  sp           = 1;
+  while (sp > 0) {
+    --sp;
+    const int first = st_first[sp];
+    int last = st_last[sp], depth = st_depth[sp];
+    while (last - first > 16) {
+      if (depth == 0) {
+        std_heapsort(v + first, last - first);
+        break;
+      }
+      --depth;
+      {  // __move_median_to_first(first, first + 1, mid, last - 1)
+        const int a = first + 1, b = first + (last - first) / 2, c = last - 1;
+        int pick;
+        if (scomp(v[a], v[b])) {
+          pick = scomp(v[b], v[c]) ? b : (scomp(v[a], v[c]) ? c : a);
+        } else {
+          pick = scomp(v[a], v[c]) ? a : (scomp(v[b], v[c]) ? c : b);
+        }
+        const uint32_t t = v[first];
+        v[first]         = v[pick];
+        v[pick]          = t;
+      }
+      int lo = first + 1, hi = last;  // __unguarded_partition(first + 1, last, first)
+      const uint32_t pivot = v[first];
+      for (;;) {
+        while (scomp(v[lo], pivot)) {
+          ++lo;
+        }
+        --hi;
+        while (scomp(pivot, v[hi])) {
+          --hi;
+        }
+        if (!(lo < hi)) {
+          break;
+        }
+        const uint32_t t = v[lo];
+        v[lo]            = v[hi];
+        v[hi]            = t;
+        ++lo;
+      }
+      st_first[sp] = lo;
+      st_last[sp]  = last;
+      st_depth[sp] = depth;
+      ++sp;
+      last = lo;
+    }
+  }
+  if (n > 16) {  // __final_insertion_sort
+    std_insertion_sort(v, 0, 16);
+    for (int i = 16; i < n; ++i) {
+      std_unguarded_linear_insert(v, i);
+    }
+  } else {
+    std_insertion_sort(v, 0, n);
   }
 }
 
 __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const FeatureArgs a) {
-  __shared__ uint32_t keys[kMaxRaw];
+  extern __shared__ __attribute__((aligned(16))) uint32_t keys[];  // [max_raw]
   __shared__ uint32_t count[kMaxRegions + 1];
   __shared__ uint32_t start[kMaxRegions + 1];
   __shared__ int wave_tot[kSelThreads / 64];
-  __shared__ uint16_t patch[(kSelThreads / 64) * kMaxCells];  // per wave: the box sums the pair table reads around the keypoint being described
+  __shared__ uint16_t patch[(kSelThreads / 64) * kMaxCells];  // per wave: the smoothed pixels the pair table reads around the keypoint being described
   const int rows = a.b.rows, cols = a.b.cols;
   const int img  = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t* __restrict__ raw = a.raw + (size_t) img * kMaxRaw;
-  const uint16_t* __restrict__ box = a.box + (size_t) img * rows * cols;
+  const uint32_t* __restrict__ raw = a.raw + (size_t) img * a.max_raw;
+  const uint8_t* __restrict__ blur = a.blur + (size_t) img * rows * cols;
   const uint8_t* __restrict__ src  = a.b.images + (size_t) img * rows * a.b.pitch;
+  const bool std_order = a.p.selection_order == PRS_SELECT_LIBSTDCXX;
   const int n = a.n_raw[img];
   if (n < 0) {  // more raw detections than the selection can hold: loud per-image error
     if (tid == 0) {
@@ -504,20 +667,22 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const Feat
   for (int i = tid; i <= a.regions; i += kSelThreads) {
     count[i] = 0;
   }
+  int n_sort = 1024;
+  while (n_sort < n) {
+    n_sort <<= 1;
+  }
   __syncthreads();
   // ---- region of every keypoint (intensity_feature_extractor_binned.cpp:85-92) + region sizes ------------
-  uint32_t my_region[kMaxRaw / kSelThreads];
-#pragma unroll
-  for (int k = 0; k < kMaxRaw / kSelThreads; ++k) {
-    const int i  = k * kSelThreads + tid;
-    my_region[k] = 0;
+  for (int i = tid; i < n_sort; i += kSelThreads) {
+    uint32_t region = 0xffffffffu;
     if (i < n) {
       const uint32_t pix = raw[i] & 0xffffffu;
       const int r = (int) (pix / (uint32_t) cols), c = (int) (pix - (uint32_t) r * (uint32_t) cols);
-      const int region = (int) floorf((float) r / a.rows_per) * a.p.number_of_detectors_horizontal + (int) ((float) c / a.cols_per);
-      my_region[k]     = (uint32_t) (region < a.regions ? region : a.regions - 1);
-      atomicAdd(&count[my_region[k]], 1u);
+      const int g = (int) floorf((float) r / a.rows_per) * a.p.number_of_detectors_horizontal + (int) ((float) c / a.cols_per);
+      region      = (uint32_t) (g < a.regions ? g : a.regions - 1);
+      atomicAdd(&count[region], 1u);
     }
+    keys[i] = region;
   }
   __syncthreads();
   if (tid == 0) {
@@ -528,25 +693,21 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const Feat
     }
     start[a.regions] = run;
   }
-  // ---- keys: (region, sort field, detection order); a region below its target keeps detection order (:174-178),
-  //      the others are ordered by decreasing response (:179-195), ties by detection order
-#pragma unroll
-  for (int k = 0; k < kMaxRaw / kSelThreads; ++k) {
-    const int i = k * kSelThreads + tid;
-    uint32_t key = 0xffffffffu;
-    if (i < n) {
-      const uint32_t s     = raw[i] >> 24;
-      const uint32_t field = count[my_region[k]] < (uint32_t) a.target_per ? 0u : 255u - s;
-      key                  = (my_region[k] << 21) | (field << 13) | (uint32_t) i;
+  // ---- keys.  Canonical order: (region, sort field, detection order); a region below its target keeps detection order
+  //      (:174-178), the others are ordered by decreasing response (:179-195), ties by detection order.
+  //      libstdc++ order: (region, detection order | response) = the region's std::vector before its std::sort
+  for (int i = tid; i < n; i += kSelThreads) {
+    const uint32_t region = keys[i];
+    const uint32_t s      = raw[i] >> 24;
+    if (std_order) {
+      keys[i] = (region << 23) | ((uint32_t) i << 8) | s;
+    } else {
+      const uint32_t field = count[region] < (uint32_t) a.target_per ? 0u : 255u - s;
+      keys[i]              = (region << 23) | (field << 15) | (uint32_t) i;
     }
-    keys[i] = key;
   }
   __syncthreads();
-  // ---- bitonic sort of the 8192 keys in LDS -------------------------------------------------------------------
-  int n_sort = 1024;
-  while (n_sort < n) {
-    n_sort <<= 1;
-  }
+  // ---- bitonic sort of the keys in LDS -------------------------------------------------------------------
   for (int size = 2; size <= n_sort; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       for (int t = tid; t < (n_sort >> 1); t += kSelThreads) {
@@ -562,6 +723,14 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const Feat
       __syncthreads();
     }
   }
+  if (std_order) {  // one lane per region runs the reference's std::sort on the region's keypoints (wave-uniform branch)
+    for (int g = wave; g < a.regions; g += kSelThreads / 64) {
+      if (lane == 0 && count[g] >= (uint32_t) a.target_per) {
+        std_sort_desc(keys + start[g], (int) count[g]);
+      }
+    }
+    __syncthreads();
+  }
   // ---- selection + border filter + ordered output slots, 1024 sorted positions at a time ------------------------
   prs_kp2* __restrict__ out_kp   = a.b.keypoints + (size_t) img * a.b.stride;
   float* __restrict__ out_int    = a.b.intensity ? a.b.intensity + (size_t) img * a.b.stride : nullptr;
@@ -574,9 +743,9 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const Feat
     uint32_t pix = 0;
     if (p < n) {
       const uint32_t key    = keys[p];
-      const uint32_t region = key >> 21;
+      const uint32_t region = key >> 23;
       const uint32_t rank   = (uint32_t) p - start[region];
-      pix                   = raw[key & 0x1fffu] & 0xffffffu;
+      pix                   = raw[std_order ? (key >> 8) & 0x7fffu : key & 0x7fffu] & 0xffffffu;
       const int r           = (int) (pix / (uint32_t) cols);
       const int c           = (int) (pix - (uint32_t) r * (uint32_t) cols);
       keep = (count[region] < (uint32_t) a.target_per || rank < (uint32_t) a.target_per) && r >= kFeatureBorder &&
@@ -606,13 +775,12 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const Feat
     __syncthreads();
   }
   const int n_kept = running < a.b.stride ? running : a.b.stride;
-  // ---- descriptors: one wave per keypoint.  The 27x27 window of box sums the pair table can reach is staged in
-  //      LDS with row-contiguous reads (scattered 2-byte reads from global memory would serialise in the
-  //      texture addresser), then every lane evaluates four comparisons and a ballot IS eight bytes of the
-  //      descriptor: bit t lands in byte t / 8, bit t % 8
+  // ---- descriptors (cv::ORB on provided keypoints: no orientation, unrotated pattern): one wave per keypoint.  The
+  //      smoothed pixels the pair table names are staged in LDS, then every lane evaluates four comparisons and a
+  //      ballot IS eight bytes of the descriptor: bit t lands in byte t / 8, bit t % 8
   {
-    // Only the cells the pair table names are fetched (258 of the 27 x 27 window for the built-in table): the phase
-    // scales with the bytes it pulls through the vector memory path.  Cell e = lane + 64 u.
+    // Only the distinct cells of the pair table are fetched: the phase scales with the bytes it pulls through the
+    // vector memory path.  Cell e = lane + 64 u.
     constexpr int kCellLoads = kMaxCells / 64;
     int o1[4], o2[4];
 #pragma unroll
@@ -626,12 +794,12 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const Feat
       const int e = min(lane + 64 * u, a.n_cells - 1);
       cell_off[u] = (int) a.cell_dy[e] * cols + (int) a.cell_dx[e];
     }
-    const int n_loads = (a.n_cells + 63) >> 6;  // (uniform) 5 for the built-in table
+    const int n_loads = (a.n_cells + 63) >> 6;  // (uniform)
     uint16_t* win = patch + wave * kMaxCells;
     for (int slot = wave; slot < n_kept; slot += kSelThreads / 64) {
       const uint32_t pix = keys[slot];
       const int r = (int) (pix / (uint32_t) cols), c = (int) (pix - (uint32_t) r * (uint32_t) cols);
-      const uint16_t* __restrict__ centre = box + (size_t) r * cols + c;
+      const uint8_t* __restrict__ centre = blur + (size_t) r * cols + c;
       uint16_t v[kCellLoads];  // all loads are issued before the first one is consumed
 #pragma unroll
       for (int u = 0; u < kCellLoads; ++u) {
@@ -677,25 +845,9 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const Feat
   }
 }
 
-// 256 point pairs (x1, y1, x2, y2) in [-13, 13]: fixed linear congruential sequence, roughly bell shaped
-void fill_brief_pattern(int8_t* pattern) {
-  uint32_t x = 0x12345678u;
-  int n      = 0;
-  while (n < 256) {
-    int v[4];
-    for (int k = 0; k < 4; ++k) {
-      x    = x * 1664525u + 1013904223u;
-      v[k] = (int) ((x >> 8) % 9u) - 4 + (int) ((x >> 16) % 9u) - 4 + (int) ((x >> 24) % 11u) - 5;
-    }
-    if (v[0] == v[2] && v[1] == v[3]) {
-      continue;
-    }
-    for (int k = 0; k < 4; ++k) {
-      pattern[4 * n + k] = (int8_t) v[k];
-    }
-    ++n;
-  }
-}
+static const int8_t kOrbPattern[1024] = {
+#include "orb_pattern.inc"
+};
 
 // the distinct cells of the pair table in row-major order + every comparison's two positions in that list
 static void fill_window_cells(const int8_t* pattern, FeatureArgs* a) {
@@ -743,31 +895,46 @@ int extract_features_launch(prs_context* ctx, const prs_extractor_params* params
     return ctx_fail(ctx, PRS_ERR_UNSUPPORTED,
                     "prs_extract_features_batch: image below 7x7 or above 2^24 pixels, more than 256 regions, or threshold outside [1,254]");
   }
+  int max_raw = params->max_raw_detections > 0 ? params->max_raw_detections : kDefaultRaw;
+  if (max_raw > kMaxRawLimit || (params->selection_order != PRS_SELECT_CANONICAL && params->selection_order != PRS_SELECT_LIBSTDCXX)) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_extract_features_batch: max_raw_detections above 32768 or unknown selection_order");
+  }
+  {
+    int pow2 = 1024;
+    while (pow2 < max_raw) {
+      pow2 <<= 1;
+    }
+    max_raw = pow2;
+  }
   FeatureArgs a;
   a.p = *params;
   a.b = *batch;
   const size_t npix = (size_t) batch->rows * batch->cols;
   a.score = static_cast<uint8_t*>(ctx_device_scratch_slot(ctx, 0, (size_t) batch->batch * npix));
-  a.box   = static_cast<uint16_t*>(ctx_device_scratch_slot(ctx, 1, (size_t) batch->batch * npix * 2));
-  uint32_t* rawbuf = static_cast<uint32_t*>(ctx_device_scratch_slot(ctx, 2, (size_t) batch->batch * (kMaxRaw + 1) * 4));
-  if (!a.score || !a.box || !rawbuf) {
+  a.blur  = static_cast<uint8_t*>(ctx_device_scratch_slot(ctx, 1, (size_t) batch->batch * npix));
+  uint32_t* rawbuf = static_cast<uint32_t*>(ctx_device_scratch_slot(ctx, 2, (size_t) batch->batch * ((size_t) max_raw + 1) * 4));
+  if (!a.score || !a.blur || !rawbuf) {
     return ctx_fail(ctx, PRS_ERR_HIP, "prs_extract_features_batch: scratch allocation failed");
   }
   a.raw   = rawbuf;
-  a.n_raw = reinterpret_cast<int32_t*>(rawbuf + (size_t) batch->batch * kMaxRaw);
-  int8_t pattern[1024];
-  fill_brief_pattern(pattern);
-  fill_window_cells(pattern, &a);
+  a.n_raw   = reinterpret_cast<int32_t*>(rawbuf + (size_t) batch->batch * max_raw);
+  a.max_raw = max_raw;
+  fill_window_cells(kOrbPattern, &a);
   a.rows_per   = (float) batch->rows / (float) params->number_of_detectors_vertical;   // binned.cpp:52-55
   a.cols_per   = (float) batch->cols / (float) params->number_of_detectors_horizontal;
   a.regions    = regions;
   a.target_per = (int) ((float) params->target_number_of_keypoints / (float) regions);  // :72-76
   hipStream_t stream = ctx_stream(ctx);
   const dim3 tiles((batch->cols + kTileW - 1) / kTileW, (batch->rows + kTileH - 1) / kTileH, batch->batch);
-  hipLaunchKernelGGL(fast_box_kernel, tiles, dim3(kFastThreads), 0, stream, a);
+  hipLaunchKernelGGL(fast_blur_kernel, tiles, dim3(kFastThreads), 0, stream, a);
   hipLaunchKernelGGL(nms_compact_kernel, dim3(batch->batch), dim3(kNmsThreads), 0, stream, a);
-  hipLaunchKernelGGL(select_describe_kernel, dim3(batch->batch), dim3(kSelThreads), 0, stream, a);
-  const hipError_t e = hipGetLastError();
+  const size_t lds_keys = (size_t) max_raw * sizeof(uint32_t);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_describe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_keys);
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_extract_features_batch: LDS for the selection sort");
+  }
+  hipLaunchKernelGGL(select_describe_kernel, dim3(batch->batch), dim3(kSelThreads), lds_keys, stream, a);
+  e = hipGetLastError();
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_extract_features_batch launch");
   }

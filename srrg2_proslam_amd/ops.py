@@ -659,9 +659,14 @@ def pose_compose_batch(ctx, prediction, X, pose_out):
 
 
 # ---- intensity feature extraction (sensor_processing/feature_extractors) ----
-def extractor_params(threshold=15, nms=1, target=1000, vertical=3, horizontal=3):
-    """defaults of configurations/kitti.conf:229-255"""
-    return _lib.ExtractorParams(threshold, nms, target, vertical, horizontal)
+SELECT_CANONICAL, SELECT_LIBSTDCXX = 0, 1
+
+
+def extractor_params(threshold=15, nms=1, target=1000, vertical=3, horizontal=3, selection_order=SELECT_CANONICAL, max_raw_detections=0):
+    """defaults of configurations/kitti.conf:229-255.  selection_order: tie handling of the per-region cut
+    (SELECT_LIBSTDCXX = GNU std::sort's permutation, what a GCC build of the reference does; slower);
+    max_raw_detections: FAST detections per image the selection holds (0 = 8192, at most 32768)"""
+    return _lib.ExtractorParams(threshold, nms, target, vertical, horizontal, selection_order, max_raw_detections)
 
 
 def extract_features_batch(ctx, params, images, keypoints, descriptors, n_features, status, intensity=None):

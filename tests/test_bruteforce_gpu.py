@@ -126,7 +126,11 @@ def test_error_and_warning_contract(hip_ctx):
     assert b"correspondences not set" in L.prs_last_error(hip_ctx._h)
     # empty clouds: warnings, empty result (:217-226, :237-242)
     assert L.prs_bruteforce_match(hip_ctx._h, C.byref(p), vp(d), 0, vp(d), 4, vp(out), 4, C.byref(n)) == 3 and n.value == 0
-    # all-equal descriptors: n^2 candidates at distance 0 exceed the default candidate capacity -> loud error
+    # all-equal descriptors: n^2 candidates at distance 0 exceed the default candidate capacity; the host-pointer entry
+    # grows the list and answers like the reference (every candidate is ambiguous: no match, warning)
     big = np.zeros((300, 32), np.uint8)
     o2 = np.zeros(300, dtype=ops.CORR_DTYPE)
-    assert L.prs_bruteforce_match(hip_ctx._h, C.byref(p), vp(big), 300, vp(big), 300, vp(o2), 300, C.byref(n)) == -2
+    from oracle import binding as ob
+    ref, ref_flags = ob.bruteforce_match(big, big, p.maximum_descriptor_distance, p.maximum_distance_ratio_to_second_best)
+    assert L.prs_bruteforce_match(hip_ctx._h, C.byref(p), vp(big), 300, vp(big), 300, vp(o2), 300, C.byref(n)) == ref_flags
+    assert n.value == len(ref)
