@@ -96,6 +96,13 @@ class AlignerParams(C.Structure):
         ("max_iterations", C.c_int32),
         ("min_num_inliers", C.c_int32),
         ("min_num_correspondences", C.c_int32),
+        ("enable_inlier_only_runs", C.c_int32),
+        ("keep_only_inlier_correspondences", C.c_int32),
+        ("inlier_only_iterations", C.c_int32),
+        ("with_sensor", C.c_int32),
+        ("sensor_in_robot", C.c_float * 16),
+        ("enable_motion_prior", C.c_int32),
+        ("motion_prior_info", C.c_float * 6),
     ]
 
 
@@ -206,6 +213,14 @@ def lib():
         L.orc_gn_step.argtypes = [C.POINTER(LinearSystem), C.c_float, vp]
         L.orc_align_frame.restype = None
         L.orc_align_frame.argtypes = [vp, C.POINTER(AlignerParams), vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, i32p, C.POINTER(AlignResult)]
+        L.orc_align_frame_ex.restype = None
+        L.orc_align_frame_ex.argtypes = [vp, C.POINTER(AlignerParams), vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, i32p, C.POINTER(AlignResult)]
+        L.orc_linearize_ex.restype = None
+        L.orc_linearize_ex.argtypes = [C.POINTER(AlignerParams), vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.POINTER(LinearSystem)]
+        L.orc_add_motion_prior.restype = None
+        L.orc_add_motion_prior.argtypes = [C.POINTER(AlignerParams), vp, vp, C.POINTER(LinearSystem)]
+        L.orc_motion_predict.restype = None
+        L.orc_motion_predict.argtypes = [vp, vp, vp]
         L.orc_bruteforce_match.restype = C.c_int
         L.orc_bruteforce_match.argtypes = [vp, C.c_int, vp, C.c_int, C.c_float, C.c_float, vp, C.c_int, i32p]
         _lib = L
@@ -403,13 +418,40 @@ def linearize(params, X, corr, fixed, moving_xyz, info_scale):
     return sys
 
 
+def linearize_ex(params, X, corr, fixed, moving_xyz, info_scale, inlier_only=False):
+    """-> (LinearSystem, classes [n_corr] u8: 0 inlier, 1 kernelised, 2 invalid)"""
+    X = _f32(X, (4, 4))
+    corr = np.ascontiguousarray(corr, dtype=CORR_DTYPE)
+    fixed = _f32(fixed)
+    moving_xyz = _f32(moving_xyz, (-1, 3))
+    info_scale = None if info_scale is None else _f32(info_scale)
+    sys = LinearSystem()
+    cls = np.zeros(max(len(corr), 1), np.uint8)
+    lib().orc_linearize_ex(C.byref(params), _ptr(X), _ptr(corr), len(corr), _ptr(fixed), _ptr(moving_xyz), _ptr(info_scale), int(inlier_only), _ptr(cls), C.byref(sys))
+    return sys, cls[: len(corr)]
+
+
+def add_motion_prior(params, X, prior_mean, sys):
+    X = _f32(X, (4, 4))
+    Z = None if prior_mean is None else _f32(prior_mean, (4, 4))
+    lib().orc_add_motion_prior(C.byref(params), _ptr(X), _ptr(Z), C.byref(sys))
+    return sys
+
+
+def motion_predict(pose_prev2, pose_prev1):
+    a, b = _f32(pose_prev2, (4, 4)), _f32(pose_prev1, (4, 4))
+    out = np.zeros((4, 4), np.float32)
+    lib().orc_motion_predict(_ptr(a), _ptr(b), _ptr(out))
+    return out
+
+
 def gn_step(sys, damping, X):
     X = _f32(X, (4, 4)).copy()
     rc = lib().orc_gn_step(C.byref(sys), float(damping), _ptr(X))
     return X, rc
 
 
-def align_frame(finder, params, fixed, moving_xyz, info_scale, X_init, prior=None):
+def align_frame(finder, params, fixed, moving_xyz, info_scale, X_init, prior=None, prior_mean=None):
     fixed = _f32(fixed)
     n_fixed = fixed.shape[0]
     moving_xyz = _f32(moving_xyz, (-1, 3))
@@ -421,7 +463,8 @@ def align_frame(finder, params, fixed, moving_xyz, info_scale, X_init, prior=Non
     pH = pb = None
     if prior is not None:
         pH, pb = _f32(prior[0], (36,)), _f32(prior[1], (6,))
-    lib().orc_align_frame(finder._h, C.byref(params), _ptr(fixed), n_fixed, _ptr(moving_xyz), _ptr(info_scale), moving_xyz.shape[0], _ptr(X_init), _ptr(pH), _ptr(pb), _ptr(corr), C.byref(n), C.byref(res))
+    Z = None if prior_mean is None else _f32(prior_mean, (4, 4))
+    lib().orc_align_frame_ex(finder._h, C.byref(params), _ptr(fixed), n_fixed, _ptr(moving_xyz), _ptr(info_scale), moving_xyz.shape[0], _ptr(X_init), _ptr(pH), _ptr(pb), _ptr(Z), _ptr(corr), C.byref(n), C.byref(res))
     return res, corr[: n.value].copy()
 
 

@@ -1054,7 +1054,33 @@ void orc_linearize(const orc_aligner_params* P,
                    const float* moving_xyz,
                    const float* info_scale,
                    orc_linear_system* out) {
+  orc_linearize_ex(P, X, corr, n_corr, fixed, moving_xyz, info_scale, 0, NULL, out);
+}
+
+/* points -> camera: X, or sensor_in_robot^-1 * X for the ...WithSensor factors */
+static void pose_to_camera(const orc_aligner_params* P, const float* X, float* A) {
+  if (P->with_sensor) {
+    float Si[16];
+    orc_se3_inverse(P->sensor_in_robot, Si);
+    orc_se3_mul(Si, X, A);
+  } else {
+    memcpy(A, X, 16 * sizeof(float));
+  }
+}
+
+void orc_linearize_ex(const orc_aligner_params* P,
+                      const float* X_robot,
+                      const orc_corr* corr,
+                      int n_corr,
+                      const float* fixed,
+                      const float* moving_xyz,
+                      const float* info_scale,
+                      int inlier_only,
+                      uint8_t* cls_out,
+                      orc_linear_system* out) {
   memset(out, 0, sizeof(*out));
+  float X[16];
+  pose_to_camera(P, X_robot, X);
   const int dim  = P->factor_type;
   const int edim = dim == ORC_FACTOR_MONO ? 2 : 3;
   const float R00 = X[0], R01 = X[1], R02 = X[2], t0 = X[3];
@@ -1081,6 +1107,9 @@ void orc_linearize(const orc_aligner_params* P,
     const float hx  = fmaf(fx, pcx, cx * pcz);
     const float hy  = fmaf(fy, pcy, cy * pcz);
     const float hz  = pcz;
+    if (cls_out) {
+      cls_out[ic] = 2;
+    }
     if (!(hz > 0.0f)) {
       ++out->num_invalid;
       continue;
@@ -1159,15 +1188,22 @@ void orc_linearize(const orc_aligner_params* P,
     /* chi2 + saturated kernel (landmark_estimator_pose_based_smoother_impl.cpp:77-84) */
     float chi = fmaf(o[2] * e[2], e[2], fmaf(o[1] * e[1], e[1], (o[0] * e[0]) * e[0]));
     if (chi > P->chi_threshold) {
-      const float scale = P->chi_threshold / chi;
+      /* inlier-only run: a kernelised factor contributes nothing (weights * 0 keeps the +-0 terms in the sums) */
+      const float scale = inlier_only ? 0.0f : P->chi_threshold / chi;
       o[0] *= scale;
       o[1] *= scale;
       o[2] *= scale;
       chi = P->chi_threshold;
       ++out->num_outliers;
+      if (cls_out) {
+        cls_out[ic] = 1;
+      }
     } else {
       ++out->num_inliers;
       out->chi_inliers += chi;
+      if (cls_out) {
+        cls_out[ic] = 0;
+      }
     }
     out->chi_total += chi;
 
@@ -1236,9 +1272,36 @@ int orc_gn_step(const orc_linear_system* sys, float damping, float* X) {
   return 0;
 }
 
+void orc_add_motion_prior(const orc_aligner_params* P, const float* X, const float* prior_mean, orc_linear_system* sys) {
+  if (!P->enable_motion_prior) {
+    return;
+  }
+  float e[6];
+  if (prior_mean) {
+    float Zi[16], D[16];
+    orc_se3_inverse(prior_mean, Zi);
+    orc_se3_mul(Zi, X, D);
+    orc_t2tnq(D, e);
+  } else {
+    orc_t2tnq(X, e);
+  }
+  for (int i = 0; i < 6; ++i) {
+    sys->H[7 * i] += P->motion_prior_info[i];
+    sys->b[i] += P->motion_prior_info[i] * e[i];
+  }
+}
+
+void orc_motion_predict(const float* pose_prev2, const float* pose_prev1, float* pose_pred) {
+  float inv2[16], motion[16];
+  orc_se3_inverse(pose_prev2, inv2);
+  orc_se3_mul(inv2, pose_prev1, motion);
+  orc_se3_mul(pose_prev1, motion, pose_pred);
+}
+
 /* MultiAligner3DQR::compute (srrg2_slam_interfaces, external) restated minimally per SURVEY.md
  * section 8 row a14: fixed number of iterations (termination_criteria unset,
- * configurations/kitti.conf:1006-1009), status by inlier count (tests/test_aligners.cpp:117-121). */
+ * configurations/kitti.conf:1006-1009), status by inlier count (tests/test_aligners.cpp:117-121),
+ * the two inlier flags of the RGB-D configurations as defined in proslam_oracle.h. */
 void orc_align_frame(orc_pcf* finder,
                      const orc_aligner_params* P,
                      const float* fixed,
@@ -1252,6 +1315,23 @@ void orc_align_frame(orc_pcf* finder,
                      orc_corr* corr_out,
                      int* n_corr_out,
                      orc_align_result* result) {
+  orc_align_frame_ex(finder, P, fixed, n_fixed, moving_xyz, info_scale, n_moving, X_init, prior_H, prior_b, NULL, corr_out, n_corr_out, result);
+}
+
+void orc_align_frame_ex(orc_pcf* finder,
+                        const orc_aligner_params* P,
+                        const float* fixed,
+                        int n_fixed,
+                        const float* moving_xyz,
+                        const float* info_scale,
+                        int n_moving,
+                        const float* X_init,
+                        const float* prior_H,
+                        const float* prior_b,
+                        const float* prior_mean,
+                        orc_corr* corr_out,
+                        int* n_corr_out,
+                        orc_align_result* result) {
   (void) n_moving;
   float X[16];
   memcpy(X, X_init, sizeof(X));
@@ -1259,20 +1339,35 @@ void orc_align_frame(orc_pcf* finder,
   int n_corr   = 0;
   orc_linear_system sys;
   memset(&sys, 0, sizeof(sys));
-  int it = 0;
-  for (; it < P->max_iterations; ++it) {
-    orc_pcf_set_local_map_in_sensor(finder, X);
-    const int flags = orc_pcf_compute(finder, corr_out, n_fixed, &n_corr);
-    if (flags < 0) {
-      warnings = flags;
-      break;
+  uint8_t* cls  = (uint8_t*) malloc((size_t) (n_fixed > 0 ? n_fixed : 1));
+  int have_cls  = 0;
+  int it        = 0;
+  int failed    = 0;
+  const int extra = P->enable_inlier_only_runs ? (P->inlier_only_iterations > 0 ? P->inlier_only_iterations : P->max_iterations) : 0;
+  for (; it < P->max_iterations + extra; ++it) {
+    const int inlier_run = it >= P->max_iterations;
+    if (it == P->max_iterations && sys.num_inliers < P->min_num_inliers) {
+      break; /* not enough inliers for an inlier-only run */
     }
-    warnings |= flags;
+    if (!inlier_run) {
+      float A[16];
+      pose_to_camera(P, X, A);
+      orc_pcf_set_local_map_in_sensor(finder, A);
+      const int flags = orc_pcf_compute(finder, corr_out, n_fixed, &n_corr);
+      if (flags < 0) {
+        warnings = flags;
+        failed   = 1;
+        break;
+      }
+      warnings |= flags;
+    }
     if (n_corr < P->min_num_correspondences) {
       memset(&sys, 0, sizeof(sys));
+      have_cls = 0;
       continue; /* slice has too few correspondences: no update this iteration */
     }
-    orc_linearize(P, X, corr_out, n_corr, fixed, moving_xyz, info_scale, &sys);
+    orc_linearize_ex(P, X, corr_out, n_corr, fixed, moving_xyz, info_scale, inlier_run, cls, &sys);
+    have_cls = 1;
     orc_linear_system total = sys;
     if (prior_H && prior_b) {
       for (int i = 0; i < 36; ++i) {
@@ -1282,8 +1377,19 @@ void orc_align_frame(orc_pcf* finder,
         total.b[i] += prior_b[i];
       }
     }
+    orc_add_motion_prior(P, X, prior_mean, &total);
     orc_gn_step(&total, P->damping, X);
   }
+  if (!failed && P->keep_only_inlier_correspondences && have_cls) {
+    int k = 0;
+    for (int i = 0; i < n_corr; ++i) {
+      if (cls[i] == 0) {
+        corr_out[k++] = corr_out[i];
+      }
+    }
+    n_corr = k;
+  }
+  free(cls);
   memcpy(result->X, X, sizeof(X));
   result->iterations          = it;
   result->num_inliers         = sys.num_inliers;

@@ -192,6 +192,27 @@ typedef struct {
   int32_t max_iterations;       /* MultiAligner3DQR max_iterations (kitti.conf:990-991) */
   int32_t min_num_inliers;      /* kitti.conf:993-994 */
   int32_t min_num_correspondences; /* slice min_num_correspondences (kitti.conf:286-287) */
+  /* MultiAligner3DQR flags of the RGB-D configurations (icl.conf:50-64, tum.conf:90-104; 0 in kitti.conf:980-1010).
+   * The class is external and its loop unpinned: BUILD-DEFINED as
+   *   enable_inlier_only_runs: after the max_iterations loop, if the last linearisation had >= min_num_inliers
+   *     inliers, `inlier_only_iterations` (<= 0: max_iterations) further GN iterations on the frozen correspondence
+   *     vector (the finder is not called) in which kernelised factors (chi2 > threshold) are suppressed entirely;
+   *   keep_only_inlier_correspondences: the returned vector keeps only the correspondences whose factor was an
+   *     inlier in the last linearisation (order preserved). */
+  int32_t enable_inlier_only_runs;
+  int32_t keep_only_inlier_correspondences;
+  int32_t inlier_only_iterations;
+  /* ...WithSensor factor variants (aligner_slice_processor_projective.h:80-83,88-91, tests/test_aligners.cpp:142-279):
+   * the estimate X is the ROBOT pose (moving in fixed robot frame); points reach the camera through
+   * A = sensor_in_robot^-1 * X, which is what the finder and the factor see; the perturbation stays on X. */
+  int32_t with_sensor;
+  float sensor_in_robot[16];
+  /* AlignerSliceMotionModel3D + MotionModelConstantVelocity3D stand-in (kitti.conf:257-260,747-772; external, weights
+   * unpinned: the .conf gives the slice no information matrix, so the default identity is assumed): a prior factor
+   * e = t2tnq(Z^-1 X) with J = I, H += diag(info), b += info * e, re-evaluated every iteration.  Z = prior mean
+   * (the constant-velocity prediction of movingInFixed; identity when the local map was clipped at the prediction). */
+  int32_t enable_motion_prior;
+  float motion_prior_info[6];
 } orc_aligner_params;
 
 /* info scale per moving point: (n_opt > 2 ? 1 + log(n_opt) : 1), aligner_slice_processor_projective.cpp:46-52 */
@@ -219,6 +240,22 @@ void orc_linearize(const orc_aligner_params* p,
                    const float* moving_xyz,
                    const float* info_scale,
                    orc_linear_system* out);
+/* the same with the sensor transform applied (p->with_sensor), optionally suppressing kernelised factors
+ * (inlier-only run) and reporting the class of every correspondence: 0 inlier, 1 kernelised, 2 invalid */
+void orc_linearize_ex(const orc_aligner_params* p,
+                      const float* X,
+                      const orc_corr* corr,
+                      int n_corr,
+                      const float* fixed,
+                      const float* moving_xyz,
+                      const float* info_scale,
+                      int inlier_only,
+                      uint8_t* cls_out,
+                      orc_linear_system* out);
+/* adds the motion prior (p->enable_motion_prior) at X to sys; prior_mean NULL = identity */
+void orc_add_motion_prior(const orc_aligner_params* p, const float* X, const float* prior_mean, orc_linear_system* sys);
+/* constant-velocity prediction: pose_pred = pose_prev1 * (pose_prev2^-1 * pose_prev1) (MotionModelConstantVelocity3D) */
+void orc_motion_predict(const float* pose_prev2, const float* pose_prev1, float* pose_pred);
 
 /* (H + damping I) dx = -b; X <- X * exp(dx). returns 0 ok, 1 if the system was not SPD (X unchanged) */
 int orc_gn_step(const orc_linear_system* sys, float damping, float* X);
@@ -249,6 +286,21 @@ void orc_align_frame(orc_pcf* finder,
                      orc_corr* corr_out,
                      int* n_corr_out,
                      orc_align_result* result);
+/* the same with a motion-prior mean (NULL = identity) */
+void orc_align_frame_ex(orc_pcf* finder,
+                        const orc_aligner_params* p,
+                        const float* fixed,
+                        int n_fixed,
+                        const float* moving_xyz,
+                        const float* info_scale,
+                        int n_moving,
+                        const float* X_init,
+                        const float* prior_H,
+                        const float* prior_b,
+                        const float* prior_mean,
+                        orc_corr* corr_out,
+                        int* n_corr_out,
+                        orc_align_result* result);
 
 /* ---- section 8f next #4: bijective brute-force matcher (bruteforce_impl.cpp:8-293) ---- */
 int orc_bruteforce_match(const uint8_t* desc_fixed,

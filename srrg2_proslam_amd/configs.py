@@ -82,7 +82,8 @@ ICL = {
     # icl.conf:566-570 (slice), :459-463 (robustifier), :295-299 (damping), :50-64 (aligner)
     "aligner": {"factor_type": FACTOR_DEPTH, "diagonal_info": (1.0, 1.0, 10.0), "chi_threshold": 10.0,
                 "enable_inverse_depth_weighting": 0, "damping": 0.1, "max_iterations": 100,
-                "min_num_inliers": 6, "min_num_correspondences": 0},  # icl.conf:584
+                "min_num_inliers": 6, "min_num_correspondences": 0,  # icl.conf:584
+                "enable_inlier_only_runs": 1, "keep_only_inlier_correspondences": 1},  # icl.conf:50-53, :57-59
     "depth": {"min": 0.5, "max": 6.0},
 }
 
@@ -104,7 +105,8 @@ TUM = {
     # tum.conf:242-246 (slice), :167-171 (robustifier), :146-150 (damping), :90-104 (aligner)
     "aligner": {"factor_type": FACTOR_DEPTH, "diagonal_info": (1.0, 1.0, 10.0), "chi_threshold": 25.0,
                 "enable_inverse_depth_weighting": 0, "damping": 0.1, "max_iterations": 100,
-                "min_num_inliers": 6, "min_num_correspondences": 0},  # tum.conf:260
+                "min_num_inliers": 6, "min_num_correspondences": 0,  # tum.conf:260
+                "enable_inlier_only_runs": 1, "keep_only_inlier_correspondences": 1},  # tum.conf:90-93, :97-99
     "depth": {"min": 0.5, "max": 6.0},
 }
 

@@ -98,6 +98,9 @@ def aligner_params(ob, cfg, mean_disparity=0.0, **kw):
     p.max_iterations = al["max_iterations"]
     p.min_num_inliers = al["min_num_inliers"]
     p.min_num_correspondences = al["min_num_correspondences"]
+    p.enable_inlier_only_runs = int(al.get("enable_inlier_only_runs", 0))
+    p.keep_only_inlier_correspondences = int(al.get("keep_only_inlier_correspondences", 0))
+    p.inlier_only_iterations = int(al.get("inlier_only_iterations", 0))
     return p
 
 

@@ -246,3 +246,95 @@ def kitti_projective(B, search_type, frame, radius, T_local_map_in_sensor, thr=1
     f.set_local_map_in_sensor(T_local_map_in_sensor)
     corr, _ = f.compute()
     return len(uv), corr
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# float64 evaluation of SURVEY.md Appendix A (factor, saturated kernel, normal equations, GN step): the independent
+# check of the oracle's float32 / fmaf-defined arithmetic
+# ---------------------------------------------------------------------------------------------------------------------
+def linearize_f64(P, X, corr, fixed, moving_xyz, info_scale=None):
+    """P: dict(factor_type 2|3|4, fx, fy, cx, cy, cols, rows, b_lr_x, info(3), chi_threshold, weighting, mean_disparity)
+    -> H (6x6), b (6), chi_total, inliers"""
+    X = np.asarray(X, np.float64)
+    R, t = X[:3, :3], X[:3, 3]
+    K = np.array([[P["fx"], 0, P["cx"]], [0, P["fy"], P["cy"]], [0, 0, 1.0]])
+    dim = P["factor_type"]
+    H, b, chi_total, inliers = np.zeros((6, 6)), np.zeros(6), 0.0, 0
+    for f, m in zip(corr["fixed_idx"], corr["moving_idx"]):
+        z = np.asarray(fixed[f], np.float64)
+        p = np.asarray(moving_xyz[m], np.float64)
+        h = K @ (R @ p + t)
+        if not h[2] > 0:
+            continue
+        u, v = h[0] / h[2], h[1] / h[2]
+        if u < 0 or u > P["cols"] or v < 0 or v > P["rows"]:
+            continue
+        wt = 1.0
+        if dim == 4 and P.get("weighting", 0):
+            wt = min(max((z[0] - z[2]) / P["mean_disparity"], 0.01), 1.0)
+        px = np.array([[0, -p[2], p[1]], [p[2], 0, -p[0]], [-p[1], p[0], 0]])
+        Jp = R @ np.hstack([wt * np.eye(3), -2.0 * px])  # d(X exp(d) p) / d d
+        A = K @ Jp
+        Jdiv = np.array([[1 / h[2], 0, -h[0] / h[2] ** 2], [0, 1 / h[2], -h[1] / h[2] ** 2]])
+        if dim == 2:
+            e, J = np.array([u, v]) - z[:2], Jdiv @ A
+        elif dim == 3:
+            e, J = np.array([u, v, h[2]]) - z[:3], np.vstack([Jdiv @ A, A[2]])
+        else:
+            hr = h[0] + P["b_lr_x"]
+            e = np.array([u, v, hr / h[2]]) - z[:3]
+            J = np.vstack([Jdiv @ A, np.array([1 / h[2], 0, -hr / h[2] ** 2]) @ A])
+        s = 1.0 if info_scale is None else float(info_scale[m])
+        om = np.array(P["info"][: len(e)], np.float64) * s
+        chi = float(e @ (om * e))
+        if chi > P["chi_threshold"]:
+            om = om * (P["chi_threshold"] / chi)
+            chi = P["chi_threshold"]
+        else:
+            inliers += 1
+        chi_total += chi
+        H += J.T @ (om[:, None] * J)
+        b += J.T @ (om * e)
+    return H, b, chi_total, inliers
+
+
+def gn_step_f64(H, b, damping, X):
+    """(H + damping I) dx = -b; X <- X * [R(q), dt] with q = (sqrt(1 - |dq|^2), dq)"""
+    dx = np.linalg.solve(H + damping * np.eye(6), -b)
+    n2 = float(dx[3:] @ dx[3:])
+    w = np.sqrt(1.0 - n2) if n2 < 1.0 else 0.0
+    x, y, z = dx[3:] if n2 < 1.0 else dx[3:] / np.sqrt(n2)
+    D = np.eye(4)
+    D[:3, :3] = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                          [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                          [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    D[:3, 3] = dx[:3]
+    return np.asarray(X, np.float64) @ D
+
+
+def kitti_aligner_circle(B):
+    """tests/test_aligners.cpp:1182-1261 (KITTI 00To01_Aligner_ProjectiveCircle): kitti.conf aligner + stereo slice,
+    robustifier chi 1000, circle finder with distance 50..100, Lowe 0.8, radius 50..10, reprojection every 5 iterations,
+    from an identity guess; error = t2tnq(movingInFixed * camera_01_in_00)"""
+    from srrg2_proslam_amd import configs
+    cfg = configs.get("kitti")
+    fix = kitti_fixture(B)
+    f = dict(cfg["projective_finder"])
+    f.update(minimum_descriptor_distance=50.0, maximum_descriptor_distance=100.0, maximum_distance_ratio_to_second_best=0.8,
+             minimum_search_radius_pixels=10, maximum_search_radius_pixels=50, number_of_solver_iterations_per_projection=5)
+    al = dict(cfg["aligner"])
+    al["chi_threshold"] = 1000.0
+    X, corr, status, inliers = B.align(cfg, f, al, fix["meas"][1], fix["desc"][1], fix["points_in_camera_00"], fix["desc"][0], np.eye(4, dtype=np.float32))
+    return dict(status=status, inliers=inliers, n_corr=len(corr), X=X, error=t2tnq(np.asarray(X, np.float64) @ kitti_relative(1, 0)))
+
+
+def icl_aligner_depth(B):
+    """tests/test_aligners.cpp:1035-1104 (ICL 00To50_AlignerProjectiveDepth_ProjectiveBF): icl.conf aligner (both inlier
+    flags on) + depth slice + circle finder, guess = camera_50_in_00; error = t2tnq(movingInFixed * camera_50_in_00)"""
+    from srrg2_proslam_amd import configs
+    cfg = configs.get("icl")
+    mv, fx = icl_measurements(B, 0), icl_measurements(B, 50)
+    fixed3 = np.concatenate([fx["uv"], fx["depth"][:, None]], axis=1).astype(np.float32)
+    X, corr, status, inliers = B.align(cfg, dict(cfg["projective_finder"]), dict(cfg["aligner"]), fixed3, fx["desc"], mv["xyz"], mv["desc"],
+                                       icl_relative(50, 0).astype(np.float32))
+    return dict(status=status, inliers=inliers, n_corr=len(corr), X=X, error=t2tnq(np.asarray(X, np.float64) @ icl_relative(50, 0)))

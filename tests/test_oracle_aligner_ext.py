@@ -1,0 +1,246 @@
+"""Oracle tests of the aligner rows finished in round 2: the ...WithSensor factor variants (a13), the two inlier flags
+of MultiAligner3DQR that icl.conf / tum.conf switch on (a14), the motion-model prior slice, the float64 cross-check of
+the float32 / fmaf-defined factor arithmetic, and the reference's aligner tests on its own KITTI / ICL images."""
+import numpy as np
+import pytest
+
+import ref_pins as rp
+from helpers import aligner_params, pcf_params, pcf_params_from_cfg, project_points, synthetic_world
+from srrg2_proslam_amd import configs, synthetic as syn
+from test_ref_pins import OracleBackend
+
+
+def _set_sensor(ap, S):
+    ap.with_sensor = 1
+    for i, v in enumerate(np.asarray(S, np.float32).reshape(16)):
+        ap.sensor_in_robot[i] = float(v)
+
+
+def _cfg_for(K, mode, baseline_px):
+    return {"camera": {"fx": K["fx"], "fy": K["fy"], "cx": K["cx"], "cy": K["cy"], "cols": K["cols"], "rows": K["rows"],
+                       "baseline_m": baseline_px / K["fx"]},
+            "aligner": {"factor_type": mode, "diagonal_info": (1.0, 1.0, 1.0), "chi_threshold": 100.0 * 100.0,
+                        "enable_inverse_depth_weighting": 0, "damping": 0.0, "max_iterations": 10, "min_num_inliers": 6,
+                        "min_num_correspondences": 0}}
+
+
+def with_sensor_scene(mode, seed=0):
+    """tests/test_aligners.cpp:142-279 (mono), :281-426 (depth), :428-584 (stereo) WithSensor: sensor_in_robot =
+    ((0.2, 0.3, 0.4), a2r(0, 0.05 pi, 0)); robot 1 sits at (0, 0, -1); fixed = what sensor 1 measures, moving = world"""
+    pts, desc, K = synthetic_world(seed)
+    S = syn.make_transform([0.2, 0.3, 0.4], [0.0, np.pi * 0.05, 0.0])
+    pose = syn.make_transform([0, 0, -1], [0, 0, 0])           # robot 1 in world
+    W2C = np.linalg.inv(pose @ S)                              # world -> sensor 1
+    pc = pts @ W2C[:3, :3].T + W2C[:3, 3]
+    uvz, idx = project_points(K, pc, 0.1, 1000.0)
+    baseline_px = 50.0
+    if mode == 2:
+        fixed = uvz[:, :2].copy()
+    elif mode == 3:
+        fixed = uvz.copy()
+    else:
+        fixed = np.stack([uvz[:, 0], uvz[:, 1], uvz[:, 0] - baseline_px / uvz[:, 2], uvz[:, 1]], axis=1).astype(np.float32)
+    return pts, desc, K, S, pose, fixed, idx, baseline_px
+
+
+@pytest.mark.parametrize("mode", [2, 3, 4])
+def test_with_sensor_aligner_recovers_the_robot_motion(oracle, mode):
+    pts, desc, K, S, pose, fixed, idx, baseline_px = with_sensor_scene(mode)
+    f = oracle.ProjectiveFinder(pcf_params(oracle, K, 0, maximum_descriptor_distance=75.0, minimum_descriptor_distance=25.0,
+                                           maximum_distance_ratio_to_second_best=0.5, maximum_search_radius_pixels=50))
+    f.set_fixed(fixed, desc[idx])
+    f.set_moving(pts, desc)
+    ap = aligner_params(oracle, _cfg_for(K, mode, baseline_px))
+    _set_sensor(ap, S)
+    res, corr = oracle.align_frame(f, ap, fixed, pts, None, np.eye(4, dtype=np.float32))
+    assert res.status == 1
+    X = np.array(res.X, np.float32).reshape(4, 4)
+    err = oracle.t2tnq(oracle.se3_mul(X, pose.astype(np.float32)))  # movingInFixed * pose ~ identity (:271-278)
+    assert np.all(np.abs(err[:3]) < 0.15) and np.all(np.abs(err[3:]) < 0.005), err
+    assert len(corr) > 40
+    # without the sensor transform the same data converges to the SENSOR motion, not the robot's
+    ap2 = aligner_params(oracle, _cfg_for(K, mode, baseline_px))
+    f.set_fixed(fixed, desc[idx])
+    res2, _ = oracle.align_frame(f, ap2, fixed, pts, None, np.eye(4, dtype=np.float32))
+    err2 = oracle.t2tnq(oracle.se3_mul(np.array(res2.X, np.float32).reshape(4, 4), pose.astype(np.float32)))
+    assert np.abs(err2).max() > 0.05
+
+
+def test_with_sensor_linearisation_is_the_plain_one_at_the_composed_pose(oracle):
+    pts, desc, K, S, pose, fixed, idx, baseline_px = with_sensor_scene(4)
+    corr = np.zeros(len(idx), dtype=oracle.CORR_DTYPE)
+    corr["fixed_idx"], corr["moving_idx"] = np.arange(len(idx)), idx
+    X = syn.perturb(np.random.default_rng(1), np.linalg.inv(pose), 0.05, 0.003)
+    ap = aligner_params(oracle, _cfg_for(K, 4, baseline_px))
+    _set_sensor(ap, S)
+    s1, _ = oracle.linearize_ex(ap, X, corr, fixed, pts, None)
+    A = oracle.se3_mul(oracle.se3_inverse(S.astype(np.float32)), X.astype(np.float32))
+    s2 = oracle.linearize(aligner_params(oracle, _cfg_for(K, 4, baseline_px)), A, corr, fixed, pts, None)
+    assert np.array_equal(np.array(s1.H), np.array(s2.H)) and np.array_equal(np.array(s1.b), np.array(s2.b))
+
+
+def _icl_case(seed=3):
+    cfg = configs.get("icl")
+    rng = np.random.default_rng(seed)
+    fr = syn.rgbd_frame(rng, cfg, 500)
+    T = syn.default_motion(rng, cfg)
+    mp = syn.local_map(rng, cfg, fr, T, n_moving=500)
+    # a handful of gross outliers among the measurements: wrong depth on true pixels
+    fixed = fr["fixed"].copy()
+    bad = rng.choice(len(fixed), 25, replace=False)
+    fixed[bad, 2] += 3.0  # chi2 = 10 * 3^2 >> 10
+    return cfg, fixed, fr["desc_fixed"], mp, T, syn.perturb(rng, T, 0.03, 0.002), bad
+
+
+def test_inlier_flags_of_the_rgbd_configurations(oracle):
+    """icl.conf:50-64: enable_inlier_only_runs 1, keep_only_inlier_correspondences 1"""
+    cfg, fixed, dfix, mp, T, X0, bad = _icl_case()
+
+    def run(**kw):
+        f = oracle.ProjectiveFinder(pcf_params_from_cfg(oracle, cfg))
+        f.set_fixed(fixed, dfix)
+        f.set_moving(mp["xyz"], mp["desc"])
+        ap = aligner_params(oracle, cfg, enable_inlier_only_runs=0, keep_only_inlier_correspondences=0)
+        for k, v in kw.items():
+            setattr(ap, k, v)
+        res, corr = oracle.align_frame(f, ap, fixed, mp["xyz"], None, X0)
+        return res, corr, np.array(res.X, np.float32).reshape(4, 4)
+
+    r0, c0, X_plain = run()
+    r1, c1, X_inl = run(enable_inlier_only_runs=1)
+    r2, c2, X_keep = run(keep_only_inlier_correspondences=1)
+    r3, c3, X_both = run(enable_inlier_only_runs=1, keep_only_inlier_correspondences=1, inlier_only_iterations=7)
+    assert r0.iterations == 100 and r1.iterations == 200 and r3.iterations == 107
+    assert np.array_equal(X_keep, X_plain) and np.array_equal(c1, c0)  # keep-only filters the output, nothing else
+    # the kept correspondences are a subsequence of the full vector, and exactly the inliers of the last linearisation
+    assert len(c2) == r2.num_inliers < len(c0)
+    assert set(map(tuple, c2[["fixed_idx", "moving_idx"]].tolist())) <= set(map(tuple, c0[["fixed_idx", "moving_idx"]].tolist()))
+    assert np.all(np.diff(c2["fixed_idx"]) > 0)
+    assert not set(c2["fixed_idx"].tolist()) & set(bad.tolist())  # the corrupted measurements are gone
+    assert len(c3) == r3.num_inliers
+    # suppressing the kernelised factors moves the estimate (slightly) and keeps it within the reference's tolerance
+    assert not np.array_equal(X_inl, X_plain)
+    for X in (X_plain, X_inl, X_both):
+        err = oracle.t2tnq(oracle.se3_mul(X, np.linalg.inv(T).astype(np.float32)))
+        assert np.all(np.abs(err) < 0.01), err
+    e_plain = np.abs(oracle.t2tnq(oracle.se3_mul(X_plain, np.linalg.inv(T).astype(np.float32)))).max()
+    e_inl = np.abs(oracle.t2tnq(oracle.se3_mul(X_inl, np.linalg.inv(T).astype(np.float32)))).max()
+    assert e_inl <= e_plain * 1.05
+
+
+def test_inlier_only_run_needs_enough_inliers(oracle):
+    cfg, fixed, dfix, mp, T, X0, _ = _icl_case(4)
+    f = oracle.ProjectiveFinder(pcf_params_from_cfg(oracle, cfg))
+    f.set_fixed(fixed, dfix)
+    f.set_moving(mp["xyz"], mp["desc"])
+    ap = aligner_params(oracle, cfg, min_num_inliers=10 ** 6, keep_only_inlier_correspondences=0)
+    ap.enable_inlier_only_runs = 1
+    res, _ = oracle.align_frame(f, ap, fixed, mp["xyz"], None, X0)
+    assert res.iterations == 100 and res.status == 0
+
+
+def test_motion_prior_slice(oracle):
+    """AlignerSliceMotionModel3D stand-in: information 0 = no prior; with few correspondences the prior keeps the estimate
+    at its mean; the constant-velocity prediction composes the last inter-frame motion"""
+    cfg, fixed, dfix, mp, T, X0, _ = _icl_case(5)
+
+    def run(info, n_keep=None, mean=None):
+        f = oracle.ProjectiveFinder(pcf_params_from_cfg(oracle, cfg))
+        fx, dx = (fixed, dfix) if n_keep is None else (fixed[:n_keep], dfix[:n_keep])
+        f.set_fixed(fx, dx)
+        f.set_moving(mp["xyz"], mp["desc"])
+        ap = aligner_params(oracle, cfg, enable_inlier_only_runs=0, keep_only_inlier_correspondences=0)
+        ap.enable_motion_prior = 1
+        for i in range(6):
+            ap.motion_prior_info[i] = info
+        res, corr = oracle.align_frame(f, ap, fx, mp["xyz"], None, X0, prior_mean=mean)
+        return np.array(res.X, np.float32).reshape(4, 4)
+
+    f0 = oracle.ProjectiveFinder(pcf_params_from_cfg(oracle, cfg))
+    f0.set_fixed(fixed, dfix)
+    f0.set_moving(mp["xyz"], mp["desc"])
+    res, _ = oracle.align_frame(f0, aligner_params(oracle, cfg, enable_inlier_only_runs=0, keep_only_inlier_correspondences=0), fixed, mp["xyz"], None, X0)
+    assert np.array_equal(run(0.0), np.array(res.X, np.float32).reshape(4, 4))
+    # unit information against ~400 reprojection factors: the estimate barely moves
+    assert rp.t2tnq(np.linalg.inv(run(1.0, mean=X0).astype(np.float64)) @ np.array(res.X, np.float64).reshape(4, 4))[:3].max() < 0.01
+    # a huge information pins the estimate to the prior mean
+    Z = syn.perturb(np.random.default_rng(9), T, 0.2, 0.02)
+    Xp = run(1e9, mean=Z)
+    assert np.abs(rp.t2tnq(np.linalg.inv(Z.astype(np.float64)) @ Xp.astype(np.float64))).max() < 1e-3
+    # constant velocity: pred = p1 * (p2^-1 * p1)
+    p2 = syn.make_transform([0.1, 0.0, 1.0], [0.0, 0.01, 0.0]).astype(np.float32)
+    p1 = (p2.astype(np.float64) @ syn.make_transform([0.0, 0.0, 0.9], [0.0, 0.02, 0.0])).astype(np.float32)
+    pred = oracle.motion_predict(p2, p1)
+    want = p1.astype(np.float64) @ (np.linalg.inv(p2.astype(np.float64)) @ p1.astype(np.float64))
+    assert np.abs(pred - want).max() < 1e-5
+
+
+# ---- float64 cross-check of the float32 / fmaf-defined arithmetic --------------------------------
+@pytest.mark.parametrize("mode", [2, 3, 4])
+def test_oracle_linearisation_and_gn_agree_with_float64(oracle, mode):
+    pts, desc, K, S, pose, fixed, idx, baseline_px = with_sensor_scene(mode, seed=2)
+    corr = np.zeros(len(idx), dtype=oracle.CORR_DTYPE)
+    corr["fixed_idx"], corr["moving_idx"] = np.arange(len(idx)), idx
+    cfg = _cfg_for(K, mode, baseline_px)
+    cfg["aligner"]["chi_threshold"] = 200.0
+    ap = aligner_params(oracle, cfg, mean_disparity=20.0, enable_inverse_depth_weighting=1 if mode == 4 else 0)
+    P = dict(factor_type=mode, fx=K["fx"], fy=K["fy"], cx=K["cx"], cy=K["cy"], cols=K["cols"], rows=K["rows"], b_lr_x=-baseline_px,
+             info=(1.0, 1.0, 1.0), chi_threshold=200.0, weighting=1 if mode == 4 else 0, mean_disparity=20.0)
+    fx64 = fixed[:, [0, 1, 2]] if mode == 4 else fixed
+    X32 = syn.perturb(np.random.default_rng(3), np.linalg.inv(pose @ S), 0.05, 0.003)
+    X64 = X32.astype(np.float64)
+    for it in range(100):
+        s = oracle.linearize(ap, X32, corr, fixed, pts, None)
+        H, b, chi, inl = rp.linearize_f64(P, X64, corr, fx64, pts)
+        if it == 0:
+            H32, b32 = np.array(s.H, np.float64).reshape(6, 6), np.array(s.b, np.float64)
+            assert np.linalg.norm(H32 - H) / np.linalg.norm(H) < 1e-5
+            assert np.linalg.norm(b32 - b) / np.linalg.norm(b) < 1e-4
+            assert s.num_inliers == inl and abs(s.chi_total - chi) / chi < 1e-4
+        X32, rc = oracle.gn_step(s, 0.1, X32)
+        X64 = rp.gn_step_f64(H, b, 0.1, X64)
+    assert np.linalg.norm(X32 - X64) / np.linalg.norm(X64) < 1e-4  # north star: 1e-4 relative Frobenius
+
+
+@pytest.mark.parametrize("weighting", [0, 1])
+def test_kitti_factor_level_gn_on_the_reference_images(oracle, weighting):
+    """tests/test_aligners.cpp:640-759 (00To01_SE3StereoPositErrorFactorInfoDiagonal_CFProjectiveBF): correspondences of
+    the circle finder at the perfect estimate (radius 5, distance 100, Lowe 0.5, 100 compute() calls), then 100 solver
+    iterations from identity, chi 1000, Omega (1,2,1), with and without disparity weighting; float64 alongside"""
+    B = OracleBackend()
+    fix = rp.kitti_fixture(B)
+    m1, d1, p0 = fix["meas"][1], fix["desc"][1], fix["points_in_camera_00"]
+    f = B.finder(rp.finder_params(rp.KITTI_K, rp.CIRCLE, 0.1, 1000.0, max_dist=100.0, min_dist=100.0, ratio=0.5, min_ratio=0.1, max_radius=5, min_radius=5))
+    f.set_fixed(m1, d1)
+    f.set_moving(p0, fix["desc"][0])
+    f.set_local_map_in_sensor(np.linalg.inv(rp.kitti_relative(1, 0)))
+    for _ in range(100):
+        corr, _ = f.compute()
+    assert len(corr) > 30
+    md = float(np.mean(m1[corr["fixed_idx"], 0] - m1[corr["fixed_idx"], 2]))  # :693-704
+    cfg = configs.get("kitti")
+    ap = aligner_params(oracle, cfg, mean_disparity=md, chi_threshold=1000.0, enable_inverse_depth_weighting=weighting, damping=0.0)
+    P = dict(factor_type=4, fx=718.856, fy=718.856, cx=607.193, cy=185.216, cols=1241, rows=376, b_lr_x=-rp.KITTI_BX, info=(1, 2, 1),
+             chi_threshold=1000.0, weighting=weighting, mean_disparity=md)
+    X32, X64 = np.eye(4, dtype=np.float32), np.eye(4)
+    for _ in range(100):
+        s = oracle.linearize(ap, X32, corr, m1, p0, None)
+        X32, rc = oracle.gn_step(s, 0.0, X32)
+        H, b, _, _ = rp.linearize_f64(P, X64, corr, m1[:, :3], p0)
+        X64 = rp.gn_step_f64(H, b, 0.0, X64)
+    err = rp.t2tnq(X32.astype(np.float64) @ rp.kitti_relative(1, 0))
+    assert np.all(np.abs(err[:3]) < 0.1) and np.all(np.abs(err[3:]) < 0.005), err  # :722-727, :751-756
+    assert np.linalg.norm(X32 - X64) / np.linalg.norm(X64) < 1e-4
+
+
+def test_kitti_aligner_projective_circle_on_the_reference_images(oracle):
+    got = rp.kitti_aligner_circle(OracleBackend())
+    assert got["status"] == 1  # tests/test_aligners.cpp:1246
+    err = got["error"]
+    assert abs(err[0]) < 0.05 and abs(err[1]) < 0.05 and abs(err[2]) < 0.20 and np.all(np.abs(err[3:]) < 0.01), err  # :1255-1260
+
+
+def test_icl_aligner_projective_depth_on_the_reference_images(oracle):
+    got = rp.icl_aligner_depth(OracleBackend())
+    assert got["status"] == 1  # tests/test_aligners.cpp:1089
+    assert np.all(np.abs(got["error"]) < 0.01), got["error"]  # :1098-1103

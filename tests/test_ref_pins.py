@@ -39,6 +39,19 @@ class OracleBackend:
         f.make_params = self.pcf
         return f
 
+    def align(self, cfg, finder, aligner, fixed, dfix, moving, dmov, X0):
+        """MultiAligner3DQR::compute stand-in with the parameter groups of a configs.* dictionary"""
+        import helpers as hp
+        c = dict(cfg)
+        c["projective_finder"], c["aligner"] = finder, aligner
+        f = ob.ProjectiveFinder(hp.pcf_params_from_cfg(ob, c))
+        f.set_fixed(fixed, dfix)
+        f.set_moving(moving, dmov)
+        md = ob.mean_disparity(fixed) if aligner["factor_type"] == 4 else 0.0
+        ap = hp.aligner_params(ob, c, mean_disparity=md)
+        res, corr = ob.align_frame(f, ap, fixed, moving, None, X0)
+        return np.array(res.X, np.float32).reshape(4, 4), corr, res.status, res.num_inliers
+
 
 @pytest.fixture(scope="module")
 def B():
