@@ -236,6 +236,30 @@ typedef struct {
   int32_t stop_at_fixed_point;            /* 1: leave the loop once the finder has converged and a GN
                                              step reproduces the estimate bit-for-bit (every remaining
                                              iteration would repeat it exactly); 0: always run all */
+  /* MultiAligner3DQR flags of the RGB-D configurations (configurations/icl.conf:50-64, tum.conf:90-104; both 0 in
+   * kitti.conf:980-1010 / euroc.conf).  The class is external and its loop is not pinned by anything in the reference
+   * tree, so the semantics are BUILD-DEFINED:
+   *   enable_inlier_only_runs ("toggles additional inlier only runs if sufficient inliers are available"): after the
+   *     max_iterations loop, if the last linearisation had >= min_num_inliers inliers, inlier_only_iterations
+   *     (<= 0: max_iterations) further Gauss-Newton iterations on the frozen correspondence vector (the finder is not
+   *     called) in which kernelised factors (chi2 > threshold) are suppressed instead of saturated;
+   *   keep_only_inlier_correspondences ("toggles removal of correspondences which factors are not inliers in the last
+   *     iteration"): the returned vector keeps the inliers of the last linearisation, order preserved. */
+  int32_t enable_inlier_only_runs;
+  int32_t keep_only_inlier_correspondences;
+  int32_t inlier_only_iterations;
+  /* AlignerSliceProcessorProjective{,Depth,Stereo}WithSensor (aligner_slice_processor_projective.h:80-83,88-91,
+   * tests/test_aligners.cpp:142-584): the estimate X is the ROBOT's movingInFixed; points reach the camera through
+   * A = sensor_in_robot^-1 * X, which is what the finder projects with and the factor linearises at; the
+   * perturbation stays on X.  sensor_in_robot: row-major 4x4 (Platform::getTransform(frame_id, base_frame_id)). */
+  int32_t with_sensor;
+  float sensor_in_robot[16];
+  /* AlignerSliceMotionModel3D + MotionModelConstantVelocity3D (configurations/kitti.conf:257-260,747-772; external,
+   * the .conf gives the slice no information matrix: identity assumed, BUILD-DEFINED): prior factor
+   * e = t2tnq(Z^-1 X), J = I, H += diag(motion_prior_info), b += motion_prior_info * e, re-evaluated every iteration.
+   * Z = prs_align_batch.prior_mean (NULL = identity: the local map was clipped at the motion-model prediction). */
+  int32_t enable_motion_prior;
+  float motion_prior_info[6];
 } prs_aligner_params;
 
 typedef struct {
@@ -280,7 +304,8 @@ typedef struct {
   prs_corr* corr;                /* [batch][fixed_stride] in/out: the caller-owned CorrespondenceVector */
   int32_t* n_corr;               /* [batch] in/out */
   prs_align_result* result;      /* [batch] */
-  const float* prior;            /* optional [batch][42]: additive H0 (36) and b0 (6) (motion-model slice) */
+  const float* prior;            /* optional [batch][42]: additive H0 (36) and b0 (6) (an externally linearised slice) */
+  const float* prior_mean;       /* optional [batch][16]: mean Z of the motion prior (NULL = identity) */
   int32_t max_fixed;             /* 0 = fixed_stride; else an upper bound on n_fixed[] the kernel sizes its LDS
                                     for (fewer bytes per frame = more frames per CU); a frame exceeding it
                                     gets PRS_ERR_CAPACITY in result[].warnings */
@@ -307,6 +332,9 @@ PRS_API int prs_pcf_set_local_map_in_sensor(prs_pcf* h, const float* T16);
 PRS_API int prs_pcf_set_search_radius(prs_pcf* h, uint64_t radius_pixels);      /* CF/..projective_base.h:82-85 */
 PRS_API int prs_pcf_set_descriptor_distance(prs_pcf* h, float distance);        /* CF/..projective_base.h:94-97 */
 PRS_API int prs_pcf_get_state(prs_pcf* h, prs_pcf_state* out);
+/* mean Z (row-major 4x4) of the motion prior prs_pcf_align applies when prs_aligner_params.enable_motion_prior is set;
+ * NULL = identity */
+PRS_API int prs_pcf_set_motion_prior_mean(prs_pcf* h, const float* Z16);
 /* out capacity >= n_fixed; untouched calls ("nothing new", converged) return the previous vector */
 PRS_API int prs_pcf_compute(prs_pcf* h, prs_corr* out, int32_t capacity, int32_t* n_out);
 /* the full per-frame loop on the handle's fixed/moving clouds (MultiAligner3DQR::compute stand-in) */
@@ -548,6 +576,11 @@ PRS_API int prs_merge_batch_run(prs_context* ctx, const prs_merger_params* param
  * motion relative to the prediction; the tracker's new sensor pose in the map is prediction * X^-1.
  * All pointers are device arrays of [batch][16] row-major float; pose_out may alias prediction. */
 PRS_API int prs_pose_compose_batch(prs_context* ctx, int32_t batch, const float* prediction, const float* X, float* pose_out);
+
+/* MotionModelConstantVelocity3D (external; configurations/kitti.conf:257-260): the tracker's guess for the next pose
+ * repeats the last inter-frame motion, pose_pred[b] = pose_prev1[b] * (pose_prev2[b]^-1 * pose_prev1[b]).
+ * Device arrays of [batch][16] row-major float; pose_pred may alias pose_prev2. */
+PRS_API int prs_motion_predict_batch(prs_context* ctx, int32_t batch, const float* pose_prev2, const float* pose_prev1, float* pose_pred);
 
 /* ================================================================================================
  * Intensity feature extraction

@@ -129,6 +129,13 @@ class AlignerParams(C.Structure):
         ("min_num_inliers", C.c_int32),
         ("min_num_correspondences", C.c_int32),
         ("stop_at_fixed_point", C.c_int32),
+        ("enable_inlier_only_runs", C.c_int32),
+        ("keep_only_inlier_correspondences", C.c_int32),
+        ("inlier_only_iterations", C.c_int32),
+        ("with_sensor", C.c_int32),
+        ("sensor_in_robot", C.c_float * 16),
+        ("enable_motion_prior", C.c_int32),
+        ("motion_prior_info", C.c_float * 6),
     ]
 
 
@@ -159,7 +166,7 @@ class AlignBatch(C.Structure):
         ("moving", C.c_void_p), ("moving_desc", C.c_void_p), ("n_moving", C.c_void_p),
         ("inputs_changed", C.c_void_p), ("state", C.c_void_p), ("X", C.c_void_p),
         ("corr", C.c_void_p), ("n_corr", C.c_void_p), ("result", C.c_void_p), ("prior", C.c_void_p),
-        ("max_fixed", C.c_int32),
+        ("prior_mean", C.c_void_p), ("max_fixed", C.c_int32),
     ]
 
 
@@ -274,6 +281,7 @@ SYMBOLS = {
     "prs_pcf_set_search_radius": (C.c_int, [_vp, C.c_uint64]),
     "prs_pcf_set_descriptor_distance": (C.c_int, [_vp, C.c_float]),
     "prs_pcf_get_state": (C.c_int, [_vp, C.POINTER(PcfState)]),
+    "prs_pcf_set_motion_prior_mean": (C.c_int, [_vp, _vp]),
     "prs_pcf_compute": (C.c_int, [_vp, _vp, C.c_int32, _i32p]),
     "prs_pcf_align": (C.c_int, [_vp, C.POINTER(AlignerParams), _vp, _vp, _vp, _vp, C.c_int32, _i32p, C.POINTER(AlignResult)]),
     "prs_pcf_linearize": (C.c_int, [_vp, C.POINTER(AlignerParams), _vp, _vp, C.c_int32, C.POINTER(AlignResult)]),
@@ -285,6 +293,7 @@ SYMBOLS = {
     "prs_bruteforce_match": (C.c_int, [_vp, C.POINTER(BruteforceParams), _vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
     "prs_extract_features_batch": (C.c_int, [_vp, C.POINTER(ExtractorParams), C.POINTER(ExtractBatch)]),
     "prs_pose_compose_batch": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),
+    "prs_motion_predict_batch": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),
     "prs_merge_batch_run": (C.c_int, [_vp, C.POINTER(MergerParams), C.POINTER(MergeBatch)]),
     "prs_scene_clip_batch": (C.c_int, [_vp, C.POINTER(Projector), _vp, C.POINTER(ClipBatch)]),
     "prs_scene_clip": (C.c_int, [_vp, C.POINTER(Projector), _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, C.c_int32, _i32p]),

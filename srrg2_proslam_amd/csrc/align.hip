@@ -46,6 +46,8 @@ typedef unsigned int au32x4 __attribute__((ext_vector_type(4)));
 
 struct AlignShared {
   float X[16];
+  float A[16];      // points -> camera: X, or sensor_in_robot^-1 * X (...WithSensor factors)
+  float Sinv[16];   // sensor_in_robot^-1
   float T[16];      // finder's local_map_in_sensor
   float Tprev[16];  // _local_map_in_sensor_previous
   float W[16];      // points -> camera used by the projector
@@ -57,6 +59,7 @@ struct AlignShared {
   int n_corr, n_filtered, n_projected, decision, flags, error;
   int n_inl, n_out, n_inv;
   int corr_changed, have_terms;
+  int have_cls;     // the last executed iteration linearised (cls[] holds its factor classes)
   int wave_tot[16];
 };
 
@@ -89,7 +92,8 @@ struct AlignArgs {
   uint32_t db_blob;        // bytes of that image (multiple of 16)
   unsigned long long* stamps;  // diagnostic: [batch][16] accumulated shader clocks per phase (NULL = off)
   int max_fixed;   // LDS capacity in fixed points (frames with more are rejected loudly)
-  uint32_t off_db, off_inv, off_cellstart, off_cfix, off_cmov, off_sh;  // persistent for the whole frame loop
+  uint32_t off_db, off_inv, off_cellstart, off_cfix, off_cmov, off_cls, off_sh;  // persistent for the whole frame loop
+  const float* prior_mean;  // optional [batch][16]: mean of the motion prior (NULL = identity)
   uint32_t off_u;                                              // phase-exclusive union region:
   uint32_t off_fdesc, off_fuv, off_best, off_second, off_lut;  //   search phase (relative to the LDS base)
   uint32_t off_terms;                                          //   GN phase / database build / disparity column
@@ -123,6 +127,47 @@ __device__ __forceinline__ int hamming_regs(const au32x4& a0, const au32x4& a1, 
   return (int) d;
 }
 
+// the pose the finder and the factors see: X, or sensor_in_robot^-1 * X for the ...WithSensor variants
+// (registration/aligner_slice_processor_projective.h:80-83,88-91); the perturbation stays on X
+__device__ __forceinline__ void pose_to_camera(const prs_aligner_params& a, const float* Sinv, const float* X, float* A) {
+  if (a.with_sensor) {
+    se3_mul(Sinv, X, A);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      A[i] = X[i];
+    }
+  }
+}
+
+// AlignerSliceMotionModel3D stand-in: prior factor e = t2tnq(Z^-1 X), J = I: H += diag(info), b += info * e
+// (Z = prior_mean, NULL = identity); re-evaluated at every iteration
+__device__ __forceinline__ void add_motion_prior(const prs_aligner_params& a, const float* Z, const float* X, float* H, float* b) {
+  float e[6];
+  if (Z) {
+    float z[16], Zi[16], D[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      z[i] = Z[i];
+    }
+    se3_inverse(z, Zi);
+    se3_mul(Zi, X, D);
+    t2tnq(D, e);
+  } else {
+    t2tnq(X, e);
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    H[7 * i] += a.motion_prior_info[i];
+    b[i] += a.motion_prior_info[i] * e[i];
+  }
+}
+
+// iterations of the inlier-only run that follows the max_iterations loop (prs_aligner_params.enable_inlier_only_runs)
+__host__ __device__ __forceinline__ int inlier_run_length(const prs_aligner_params& a) {
+  return a.enable_inlier_only_runs ? (a.inlier_only_iterations > 0 ? a.inlier_only_iterations : a.max_iterations) : 0;
+}
+
 // One correspondence of SE3{,Depth,RectifiedStereo}ProjectiveErrorFactor::errorAndJacobian + saturated
 // robustifier: the 21 upper-triangle entries of J^T Omega J, the 6 of J^T Omega e, chi (inliers only) and
 // chi (kernelised).  z = fixed measurement, p = moving point (w = information scale).
@@ -139,7 +184,7 @@ __device__ __forceinline__ bool pose_is_finite(const PoseRegs& X) {
 // DIM: the factor type as a compile-time constant (0 = read it from the parameters)
 template <int DIM = 0>
 __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const PoseRegs& X, const float4 z, const float4 p_in,
-                                             const float mean_dsp, const bool active, float* tv, int& cls) {
+                                             const float mean_dsp, const bool active, float* tv, int& cls, const bool inlier_only = false) {
   // Straight-line on purpose: with `tv` live out of nested divergent branches the compiler re-materialises
   // all 29 zeros at every nesting level (~150 v_mov per call, as many as the arithmetic).  A correspondence
   // that is inactive (slot past the end) or invalid (behind the camera / outside the image) runs the same
@@ -236,7 +281,7 @@ __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const 
   float chi = fmaf(o2 * e2, e2, fmaf(o1 * e1, e1, (o0 * e0) * e0));
   // saturated kernel: o *= threshold / chi (a factor of exactly 1 leaves the unsaturated weights untouched)
   const bool saturated = valid && chi > a.chi_threshold;
-  const float ratio    = a.chi_threshold / chi;
+  const float ratio    = inlier_only ? 0.0f : a.chi_threshold / chi;  // inlier-only run: kernelised factors are suppressed
   const float scale    = saturated ? ratio : 1.0f;
   o0 *= scale;
   o1 *= scale;
@@ -314,6 +359,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
   uint32_t* second    = reinterpret_cast<uint32_t*>(smem + g.off_second);
   uint16_t* lut       = reinterpret_cast<uint16_t*>(smem + g.off_lut);
   float* terms        = reinterpret_cast<float*>(smem + g.off_terms);     // aliases the search-phase arrays
+  uint8_t* clsbuf     = smem + g.off_cls;                                  // factor class per correspondence (last linearisation)
   AlignShared& sh     = *reinterpret_cast<AlignShared*>(smem + g.off_sh);
   const int R         = g.rows_table;
   const int stype     = STYPE >= 0 ? STYPE : g.f.search_type;
@@ -347,8 +393,24 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
     sh.mean_disp           = (split_search && ctl->it_align != 0) ? gres->mean_disparity : g.a.mean_disparity;
     sh.corr_changed        = 1;
     sh.have_terms          = 0;
+    sh.have_cls            = 0;
     if (sh.n_corr < 0 || sh.n_corr > nF) {
       sh.n_corr = 0;
+    }
+    {
+      float x[16], a16[16], si[16];
+      const float* gx = g.b.X + (size_t) frame * 16;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        x[i] = gx[i];
+      }
+      se3_inverse(g.a.sensor_in_robot, si);
+      pose_to_camera(g.a, si, x, a16);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        sh.Sinv[i] = si[i];
+        sh.A[i]    = a16[i];
+      }
     }
     if (nF > g.max_fixed) {
       sh.error = PRS_ERR_CAPACITY;  // the caller's max_fixed hint was too small for this frame
@@ -430,21 +492,30 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
 #define SUB_ACC(v) do { if (g.stamps && tid == 0) { const unsigned long long now_ = (unsigned long long) clock64(); v += now_ - t_sub; t_sub = now_; } } while (0)
 #define ALIGN_MARK() (t_mark = (g.stamps && tid == 0) ? (unsigned long long) clock64() : 0ull)
 #define ALIGN_ACC(v) do { if (g.stamps && tid == 0) { v += (unsigned long long) clock64() - t_mark; } } while (0)
-  const int max_it = (g.mode == PRS_MODE_ALIGN && !sh.error) ? g.a.max_iterations : (sh.error ? 0 : 1);
+  // PRS_MODE_ALIGN: max_iterations of finder + GN, then the inlier-only run (frozen correspondences, no finder)
+  const int max_it = (g.mode == PRS_MODE_ALIGN && !sh.error) ? g.a.max_iterations + inlier_run_length(g.a) : (sh.error ? 0 : 1);
   if (split_search && sh.error && tid == 0) {
     ctl->done = 1;  // loud per-frame error, the GN kernel never touches this frame
   }
   int executed     = 0;
   int it_align     = 0;
+  bool ran_inlier_phase = false;
   for (; it_align < max_it; ++it_align) {
+    const bool inlier_run = g.mode == PRS_MODE_ALIGN && it_align >= g.a.max_iterations;
+    if (g.mode == PRS_MODE_ALIGN && it_align == g.a.max_iterations) {
+      if (sh.n_inl < g.a.min_num_inliers) {
+        break;  // not enough inliers for an inlier-only run (block-uniform: sh.n_inl was written before the last barrier)
+      }
+      ran_inlier_phase = true;
+    }
     ++executed;
     // ============================================================================================
     // finder.setLocalMapInSensor(X); finder.compute()
     // ============================================================================================
     ALIGN_MARK();
-    if (g.mode != PRS_MODE_LINEARIZE) {
+    if (g.mode != PRS_MODE_LINEARIZE && !inlier_run) {
       if (tid < 16) {
-        sh.T[tid] = sh.X[tid];
+        sh.T[tid] = sh.A[tid];
       }
       __syncthreads();
       for (;;) {  // the reference re-enters compute() recursively (projective_base_impl.cpp:262)
@@ -1001,6 +1072,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
       if (tid == 0) {
         sh.n_inl = sh.n_out = sh.n_inv = 0;
         sh.chi_in = sh.chi_tot = 0.0f;
+        sh.have_cls = 0;
       }
       for (int i = tid; i < 36; i += T) {
         sh.H[i] = 0.0f;
@@ -1009,19 +1081,27 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
         sh.b[tid] = 0.0f;
       }
       __syncthreads();
-      if (g.a.stop_at_fixed_point && sh.converged) {
-        break;  // nothing can change any more
+      if (g.a.stop_at_fixed_point && (sh.converged || inlier_run)) {
+        // nothing can change any more; the inlier-only run (if any) needs n_inl = 0 >= min_num_inliers and would not move X either
+        ran_inlier_phase = ran_inlier_phase || (inlier_run_length(g.a) > 0 && 0 >= g.a.min_num_inliers);
+        break;
       }
       continue;  // slice has too few correspondences: no update this iteration
     }
     {
-      const PoseRegs pose  = {sh.X[0], sh.X[1], sh.X[2], sh.X[3], sh.X[4], sh.X[5], sh.X[6], sh.X[7], sh.X[8], sh.X[9], sh.X[10], sh.X[11]};
+      const PoseRegs pose  = {sh.A[0], sh.A[1], sh.A[2], sh.A[3], sh.A[4], sh.A[5], sh.A[6], sh.A[7], sh.A[8], sh.A[9], sh.A[10], sh.A[11]};
       const float mean_dsp = sh.mean_disp;
       // a pose with a NaN / inf entry: every correspondence is invalid, all sums stay zero
       const bool pose_ok   = __all(pose_is_finite(pose));  // (uniform by construction; __all makes the branch scalar)
       if (tid == 0) {
         sh.n_inl = sh.n_out = 0;
         sh.n_inv = pose_ok ? 0 : nc;
+        sh.have_cls = 1;
+      }
+      if (!pose_ok) {
+        for (int c = tid; c < nc; c += T) {
+          clsbuf[c] = 2;
+        }
       }
       float run = 0.0f;  // lanes 0..28 of wave 0: running sum of their term in correspondence order
       __syncthreads();
@@ -1031,9 +1111,10 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
         float tv[kTerms];
         int cls;
         const int cc = c < nc ? c : 0;
-        factor_terms(g.a, pose, cfix[cc], cmov[cc], mean_dsp, c < nc, tv, cls);
+        factor_terms(g.a, pose, cfix[cc], cmov[cc], mean_dsp, c < nc, tv, cls, inlier_run);
         if (c < nc) {
           atomicAdd(cls == 0 ? &sh.n_inl : (cls == 1 ? &sh.n_out : &sh.n_inv), 1);
+          clsbuf[c] = (uint8_t) cls;
         }
 #pragma unroll
         for (int t = 0; t < kTerms; ++t) {
@@ -1119,6 +1200,9 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
       for (int i = 0; i < 16; ++i) {
         X[i] = sh.X[i];
       }
+      if (g.a.enable_motion_prior) {
+        add_motion_prior(g.a, g.prior_mean ? g.prior_mean + (size_t) frame * 16 : nullptr, X, H, b);
+      }
       gn_step(H, b, g.a.damping, X);
       uint32_t changed_bits = 0;  // (bitwise, no short-circuit: sixteen compares would be sixteen branches)
 #pragma unroll
@@ -1126,15 +1210,59 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
         changed_bits |= __float_as_uint(X[i]) ^ __float_as_uint(sh.X[i]);
         sh.X[i] = X[i];
       }
-      // fixed point: finder latched + pose reproduced bit-for-bit => every later iteration repeats this one
-      sh.decision = (g.a.stop_at_fixed_point && changed_bits == 0u && sh.converged) ? 1 : 0;
+      float a16[16];
+      pose_to_camera(g.a, sh.Sinv, X, a16);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        sh.A[i] = a16[i];
+      }
+      // fixed point: finder latched (or out of the loop: inlier-only run) + pose reproduced bit-for-bit
+      // => every later iteration of this phase repeats this one
+      sh.decision = (g.a.stop_at_fixed_point && changed_bits == 0u && (sh.converged || inlier_run)) ? 1 : 0;
     }
     __syncthreads();
     ALIGN_ACC(acc_solve);
     if (sh.decision) {
+      if (!inlier_run && inlier_run_length(g.a) > 0) {
+        it_align = g.a.max_iterations - 1;  // the rest of the first phase repeats this iteration: go on with the inlier-only run
+        continue;
+      }
       ++it_align;
       break;
     }
+  }
+
+  // ---- keep_only_inlier_correspondences: the returned vector keeps the inliers of the last linearisation, in order ----
+  __syncthreads();
+  if (g.mode == PRS_MODE_ALIGN && !split_search && g.a.keep_only_inlier_correspondences && sh.have_cls && !sh.error) {
+    const int nc = sh.n_corr;
+    int base     = 0;
+    for (int c0 = 0; c0 < nc; c0 += T) {
+      const int c     = c0 + tid;
+      const bool keep = c < nc && clsbuf[c] == 0;
+      prs_corr cr;
+      if (keep) {
+        cr = gcorr[c];
+      }
+      const unsigned long long bal = __ballot(keep);
+      if (lane == 0) {
+        sh.wave_tot[wave] = __popcll(bal);
+      }
+      __syncthreads();  // (also: every entry of this chunk has been read before any slot <= c is overwritten)
+      int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+      for (int w = 0; w < T / 64; ++w) {
+        pos += w < wave ? sh.wave_tot[w] : 0;
+        base += sh.wave_tot[w];
+      }
+      if (keep) {
+        gcorr[pos] = cr;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      sh.n_corr = base;
+    }
+    __syncthreads();
   }
 
   // ---- write back --------------------------------------------------------------------------------
@@ -1168,7 +1296,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
     gres->num_invalid            = sh.n_inv;
     gres->num_correspondences    = sh.n_corr;
     gres->status                 = sh.n_inl >= g.a.min_num_inliers ? 1 : 0;
-    gres->iterations             = g.mode == PRS_MODE_ALIGN ? g.a.max_iterations : 1;
+    gres->iterations             = g.mode == PRS_MODE_ALIGN ? (ran_inlier_phase ? max_it : g.a.max_iterations) : 1;
     gres->iterations_executed    = executed;
     gres->warnings               = sh.error ? sh.error : sh.flags;
     if (split_search) {
@@ -1207,9 +1335,12 @@ constexpr int kGnSlots   = 4;  // max_fixed <= 1024 either way
 struct GnShared {
   float X[16], T[16], Tprev[16], H[36], b[6];
   float chi_in, chi_tot;
+  float A[16];     // points -> camera: X, or sensor_in_robot^-1 * X
+  float Sinv[16];
   unsigned long long it;
   int converged, need_search, n_inl, n_out, n_inv, stop, flags;
-  int pose_ok;  // every entry of X is finite (kept by whoever writes X)
+  int pose_ok;  // every entry of A is finite (kept by whoever writes X)
+  int wave_tot[4];
 };
 
 // THREADS per frame; SLOTS = correspondences per thread the instantiation keeps in registers (ceil(max_fixed / THREADS))
@@ -1251,7 +1382,19 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
     sh.chi_tot     = gres->chi_total;
     sh.stop        = 0;
     const float* gx = g.b.X + (size_t) frame * 16;
-    const PoseRegs x0 = {gx[0], gx[1], gx[2], gx[3], gx[4], gx[5], gx[6], gx[7], gx[8], gx[9], gx[10], gx[11]};
+    float x[16], a16[16], si[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      x[i] = gx[i];
+    }
+    se3_inverse(g.a.sensor_in_robot, si);
+    pose_to_camera(g.a, si, x, a16);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      sh.Sinv[i] = si[i];
+      sh.A[i]    = a16[i];
+    }
+    const PoseRegs x0 = {a16[0], a16[1], a16[2], a16[3], a16[4], a16[5], a16[6], a16[7], a16[8], a16[9], a16[10], a16[11]};
     sh.pose_ok        = pose_is_finite(x0) ? 1 : 0;
   }
   for (int i = tid; i < 36; i += THREADS) {
@@ -1295,13 +1438,32 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
   int executed = ctl->executed;
   bool first   = true;
   bool done    = false;
+  const int extra = inlier_run_length(g.a);  // iterations of the inlier-only run after the max_iterations loop
+  uint32_t cls_bits = 0;                     // factor classes of this thread's correspondences in the last linearisation (2 bits each)
+  bool have_cls     = false;                 // (block-uniform) the last executed iteration linearised
+  // one aligner iteration is over: advance, change phase, report whether the frame is finished (block-uniform)
+  auto advance = [&](bool fixed_point) -> bool {
+    const bool was_inlier_run = it_align >= g.a.max_iterations;
+    ++it_align;
+    if (fixed_point && !was_inlier_run && extra > 0) {
+      it_align    = g.a.max_iterations;  // the rest of the first phase repeats this iteration
+      fixed_point = false;
+    }
+    if (fixed_point) {
+      return true;
+    }
+    if (it_align == g.a.max_iterations && extra > 0) {
+      return sh.n_inl < g.a.min_num_inliers;  // not enough inliers for an inlier-only run
+    }
+    return it_align >= g.a.max_iterations + extra;
+  };
   while (true) {
-    if (!first) {
+    if (!first && it_align < g.a.max_iterations) {
       // finder.setLocalMapInSensor(X); finder.compute() for aligner iteration it_align, as long as it
       // needs no projective search (CF/correspondence_finder_projective_base_impl.cpp:138-178)
       if (stid == 0) {
         for (int i = 0; i < 16; ++i) {
-          sh.T[i] = sh.X[i];
+          sh.T[i] = sh.A[i];
         }
         if (!sh.converged) {
           const unsigned long long k = g.f.number_of_solver_iterations_per_projection;
@@ -1338,14 +1500,17 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
         sh.b[tid] = 0.0f;
       }
       __syncthreads();
-      ++it_align;
-      if (it_align >= g.a.max_iterations || (g.a.stop_at_fixed_point && sh.converged)) {
+      have_cls = false;
+      if (advance(g.a.stop_at_fixed_point && (sh.converged || it_align >= g.a.max_iterations))) {
         done = true;
         break;
       }
       continue;
     }
-    const PoseRegs pose = {sh.X[0], sh.X[1], sh.X[2], sh.X[3], sh.X[4], sh.X[5], sh.X[6], sh.X[7], sh.X[8], sh.X[9], sh.X[10], sh.X[11]};
+    const bool inlier_run = it_align >= g.a.max_iterations;
+    have_cls              = true;
+    cls_bits              = 0;
+    const PoseRegs pose = {sh.A[0], sh.A[1], sh.A[2], sh.A[3], sh.A[4], sh.A[5], sh.A[6], sh.A[7], sh.A[8], sh.A[9], sh.A[10], sh.A[11]};
     // a pose with a NaN / inf entry: every correspondence is invalid, all sums stay zero
     const bool pose_ok  = __builtin_amdgcn_readfirstlane(sh.pose_ok) != 0;
     if (tid == 0) {
@@ -1361,7 +1526,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
       if (c0 < nc && pose_ok) {
         float tv[kTerms];
         int cls;
-        factor_terms<DIM>(g.a, pose, zf[k], pm[k], mean_dsp, c0 + tid < nc, tv, cls);
+        factor_terms<DIM>(g.a, pose, zf[k], pm[k], mean_dsp, c0 + tid < nc, tv, cls, inlier_run);
+        cls_bits |= (uint32_t) (cls & 3) << (2 * k);
         // inlier / outlier / invalid counts of the wave (scalar), added to the frame's counters once per iteration
         wave_inl += (int) __popcll(__ballot(cls == 0));
         wave_out += (int) __popcll(__ballot(cls == 1));
@@ -1386,6 +1552,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
           }
         }
         __syncthreads();
+      } else if (c0 < nc) {
+        cls_bits |= 2u << (2 * k);  // non-finite pose: every correspondence is invalid
       }
     }
     if (stid >= 0 && stid < kTerms) {
@@ -1423,6 +1591,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
       for (int i = 0; i < 16; ++i) {
         X[i] = sh.X[i];
       }
+      if (g.a.enable_motion_prior) {
+        add_motion_prior(g.a, g.prior_mean ? g.prior_mean + (size_t) frame * 16 : nullptr, X, H, b);
+      }
       gn_step(H, b, g.a.damping, X);
       uint32_t changed_bits = 0;  // (bitwise, no short-circuit: sixteen compares would be sixteen branches)
 #pragma unroll
@@ -1430,16 +1601,58 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
         changed_bits |= __float_as_uint(X[i]) ^ __float_as_uint(sh.X[i]);
         sh.X[i] = X[i];
       }
-      sh.stop = (g.a.stop_at_fixed_point && changed_bits == 0u && sh.converged) ? 1 : 0;
-      const PoseRegs xn = {X[0], X[1], X[2], X[3], X[4], X[5], X[6], X[7], X[8], X[9], X[10], X[11]};
+      sh.stop = (g.a.stop_at_fixed_point && changed_bits == 0u && (sh.converged || inlier_run)) ? 1 : 0;
+      float a16[16];
+      pose_to_camera(g.a, sh.Sinv, X, a16);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        sh.A[i] = a16[i];
+      }
+      const PoseRegs xn = {a16[0], a16[1], a16[2], a16[3], a16[4], a16[5], a16[6], a16[7], a16[8], a16[9], a16[10], a16[11]};
       sh.pose_ok        = pose_is_finite(xn) ? 1 : 0;
     }
     __syncthreads();
-    ++it_align;
-    if (it_align >= g.a.max_iterations || sh.stop) {
+    if (advance(sh.stop != 0)) {
       done = true;
       break;
     }
+  }
+
+  // ---- keep_only_inlier_correspondences: the returned vector keeps the inliers of the last linearisation, in order ----
+  int nc_out = nc;
+  __syncthreads();
+  if (done && g.a.keep_only_inlier_correspondences && have_cls) {
+    prs_corr* __restrict__ gcorr = g.b.corr + (size_t) frame * (size_t) g.b.fixed_stride;
+    const int lane = tid & 63, wave = tid >> 6;
+    int base       = 0;
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+      const int c0 = k * THREADS;
+      if (c0 < nc) {
+        const int c     = c0 + tid;
+        const bool keep = c < nc && ((cls_bits >> (2 * k)) & 3u) == 0u;
+        prs_corr cr;
+        if (keep) {
+          cr = gcorr[c];
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) {
+          sh.wave_tot[wave] = __popcll(bal);
+        }
+        __syncthreads();  // (every entry of this chunk has been read before any slot <= c is overwritten)
+        int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+#pragma unroll
+        for (int w = 0; w < THREADS / 64; ++w) {
+          pos += w < wave ? sh.wave_tot[w] : 0;
+          base += sh.wave_tot[w];
+        }
+        if (keep) {
+          gcorr[pos] = cr;
+        }
+        __syncthreads();
+      }
+    }
+    nc_out = base;
   }
 
   __syncthreads();
@@ -1461,9 +1674,12 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
     gres->num_inliers         = sh.n_inl;
     gres->num_outliers        = sh.n_out;
     gres->num_invalid         = sh.n_inv;
-    gres->num_correspondences = nc;
+    gres->num_correspondences = nc_out;
+    if (nc_out != nc) {
+      g.b.n_corr[frame] = nc_out;
+    }
     gres->status              = sh.n_inl >= g.a.min_num_inliers ? 1 : 0;
-    gres->iterations          = g.a.max_iterations;
+    gres->iterations          = it_align > g.a.max_iterations ? g.a.max_iterations + extra : g.a.max_iterations;
     gres->iterations_executed = executed;
     ctl->flags |= sh.flags;
     gres->warnings   = ctl->flags;
@@ -1560,6 +1776,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   g.a          = *aligner;
   g.b          = *batch;
   g.mode       = mode;
+  g.prior_mean = batch->prior_mean;
   g.rows_table = finder->projector.canvas_rows;
   const int max_fixed = batch->max_fixed > 0 && batch->max_fixed < batch->fixed_stride ? batch->max_fixed : batch->fixed_stride;
   g.max_fixed       = max_fixed;
@@ -1599,6 +1816,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
     g.off_cellstart = off; off = align_up16(off + ((uint32_t) g.ncells + 2) * 2);
     g.off_cfix     = off; off = align_up16(off + (with_operands ? nf * 16 : 0));
     g.off_cmov     = off; off = align_up16(off + (with_operands ? nf * 16 : 0));
+    g.off_cls      = off; off = align_up16(off + (with_operands ? nf : 0));
     g.off_sh       = off; off = align_up16(off + (uint32_t) sizeof(AlignShared));
     g.off_u        = off;
     // search-phase arrays
@@ -1697,7 +1915,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   // 4 rounds); retries can shift it, so completion is confirmed by reading back the pending counter
   int rounds_left = 5;
   int total       = 0;
-  const int limit = 2 * aligner->max_iterations + 8;
+  const int limit = 2 * (aligner->max_iterations + inlier_run_length(*aligner)) + 8;
   for (;;) {
     for (int r = 0; r < rounds_left; ++r) {
       (void) hipMemsetAsync(g.pending, 0, sizeof(int), stream);

@@ -656,6 +656,14 @@ int prs_pose_compose_batch(prs_context* ctx, int32_t batch, const float* predict
   return pose_compose_launch(ctx, batch, prediction, X, pose_out);
 }
 
+int prs_motion_predict_batch(prs_context* ctx, int32_t batch, const float* pose_prev2, const float* pose_prev1, float* pose_pred) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  (void) hipSetDevice(ctx->device);
+  return motion_predict_launch(ctx, batch, pose_prev2, pose_prev1, pose_pred);
+}
+
 int prs_extract_features_batch(prs_context* ctx, const prs_extractor_params* params, const prs_extract_batch* batch) {
   if (!ctx) {
     return PRS_ERR_NULL;

@@ -1524,6 +1524,43 @@ __global__ __launch_bounds__(256) void pose_compose_kernel(int batch, const floa
   }
 }
 
+// MotionModelConstantVelocity3D: pose_pred = pose_prev1 * (pose_prev2^-1 * pose_prev1)
+__global__ __launch_bounds__(256) void motion_predict_kernel(int batch, const float* __restrict__ prev2, const float* __restrict__ prev1,
+                                                             float* __restrict__ pred) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) {
+    return;
+  }
+  float P2[16], P1[16], I2[16], M[16], R[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    P2[i] = prev2[(size_t) b * 16 + i];
+    P1[i] = prev1[(size_t) b * 16 + i];
+  }
+  se3_inverse(P2, I2);
+  se3_mul(I2, P1, M);
+  se3_mul(P1, M, R);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    pred[(size_t) b * 16 + i] = R[i];
+  }
+}
+
+int motion_predict_launch(prs_context* ctx, int batch, const float* prev2, const float* prev1, float* pred) {
+  if (!prev2 || !prev1 || !pred) {
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_motion_predict_batch: pose arrays not set");
+  }
+  if (batch <= 0) {
+    return PRS_OK;
+  }
+  hipLaunchKernelGGL(motion_predict_kernel, dim3((batch + 255) / 256), dim3(256), 0, ctx_stream(ctx), batch, prev2, prev1, pred);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_motion_predict_batch launch");
+  }
+  return PRS_OK;
+}
+
 int pose_compose_launch(prs_context* ctx, int batch, const float* prediction, const float* X, float* pose_out) {
   if (!prediction || !X || !pose_out) {
     return ctx_fail(ctx, PRS_ERR_NULL, "prs_pose_compose_batch: pose arrays not set");

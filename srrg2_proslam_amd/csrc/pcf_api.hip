@@ -28,6 +28,8 @@ struct prs_pcf {
   float local_map_in_sensor[16];
   std::vector<prs_corr> corr;  // the persisting correspondence vector (host mirror)
   int n_corr = 0;
+  bool has_prior_mean = false;  // mean of the motion prior (prs_pcf_set_motion_prior_mean)
+  float prior_mean[16];
 };
 
 namespace {
@@ -41,6 +43,7 @@ struct SmallLayout {
   float* X;
   prs_align_result* result;
   float* prior;
+  float* prior_mean;
   float* H;
   float* b;
   int* ok;
@@ -58,6 +61,7 @@ SmallLayout small_layout(unsigned char* d) {
   s.X        = reinterpret_cast<float*>(d + 512);
   s.result   = reinterpret_cast<prs_align_result*>(d + 1024);
   s.prior    = reinterpret_cast<float*>(d + 2048);
+  s.prior_mean = reinterpret_cast<float*>(d + 2304);
   s.H        = reinterpret_cast<float*>(d + 2560);
   s.b        = reinterpret_cast<float*>(d + 2816);
   s.ok       = reinterpret_cast<int*>(d + 2880);
@@ -153,6 +157,10 @@ int run(prs_pcf* h, const prs_aligner_params* aligner, int mode, const float* X_
   b.n_corr         = sl.n_corr;
   b.result         = sl.result;
   b.prior          = prior42 ? sl.prior : nullptr;
+  if (h->has_prior_mean) {
+    PCF_TRY(hipMemcpyAsync(sl.prior_mean, h->prior_mean, sizeof(float) * 16, hipMemcpyHostToDevice, s));
+    b.prior_mean = sl.prior_mean;
+  }
   const int rc     = prs::align_batch_launch(h->ctx, &h->params, &ap, &b, mode);
   if (rc != PRS_OK) {
     return rc;
@@ -324,6 +332,17 @@ int prs_pcf_get_state(prs_pcf* h, prs_pcf_state* out) {
   }
   *out = h->state;
   memcpy(out->local_map_in_sensor, h->local_map_in_sensor, sizeof(float) * 16);
+  return PRS_OK;
+}
+
+int prs_pcf_set_motion_prior_mean(prs_pcf* h, const float* Z16) {
+  if (!h) {
+    return PRS_ERR_NULL;
+  }
+  h->has_prior_mean = Z16 != nullptr;
+  if (Z16) {
+    memcpy(h->prior_mean, Z16, sizeof(float) * 16);
+  }
   return PRS_OK;
 }
 

@@ -72,6 +72,7 @@ int gn_step_launch(prs_context* ctx, const float* dH, const float* db, float dam
 int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* params, const prs_bruteforce_batch* batch);
 int extract_features_launch(prs_context* ctx, const prs_extractor_params* params, const prs_extract_batch* batch);
 int pose_compose_launch(prs_context* ctx, int batch, const float* prediction, const float* X, float* pose_out);
+int motion_predict_launch(prs_context* ctx, int batch, const float* prev2, const float* prev1, float* pred);
 int merge_batch_launch(prs_context* ctx, const prs_merger_params* params, const prs_merge_batch* batch);
 int scene_clip_launch(prs_context* ctx, const prs_projector* projector, const float* sensor_in_robot, const prs_clip_batch* batch);
 int triangulate_launch(prs_context* ctx, const prs_triangulator_params* params, const float* d_uvuv, int64_t n, float* d_xyz4);

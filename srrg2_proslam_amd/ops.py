@@ -24,9 +24,15 @@ def _check(ctx, rc, what):
 
 
 class Context:
-    """prs_context: one device, one stream, scratch. Not re-entrant (like the reference's finders)."""
+    """prs_context: one device, one stream, scratch. Not re-entrant (like the reference's finders).
 
-    def __init__(self, device=0):
+    Stream policy: the `*_batch` operators read and write torch tensors, whose fills and copies run on torch's current
+    stream; a context that launched on its own (non-blocking) stream would not be ordered against them.  By default the
+    context therefore enqueues on torch's current stream of `device` (stream="torch").  stream="own" keeps the
+    context's private stream: the caller then orders the two streams itself (events) or only uses host-array entry
+    points, which synchronise internally."""
+
+    def __init__(self, device=0, stream="torch"):
         lib = _lib.load()
         h = C.c_void_p()
         rc = lib.prs_context_create(int(device), C.byref(h))
@@ -35,6 +41,10 @@ class Context:
         self._h = h
         self.device = int(device)
         self._children = weakref.WeakSet()  # handles that hold a pointer to this context
+        if stream == "torch":
+            self.use_torch_stream()
+        elif stream != "own":
+            raise ValueError("stream must be 'torch' or 'own'")
 
     def close(self):
         if getattr(self, "_h", None):
@@ -218,6 +228,30 @@ def aligner_params(cfg, mean_disparity=-1.0, stop_at_fixed_point=1, **overrides)
     p.min_num_inliers = int(al["min_num_inliers"])
     p.min_num_correspondences = int(al["min_num_correspondences"])
     p.stop_at_fixed_point = int(stop_at_fixed_point)
+    # MultiAligner3DQR flags of the RGB-D configurations (icl.conf:50-64, tum.conf:90-104)
+    p.enable_inlier_only_runs = int(al.get("enable_inlier_only_runs", 0))
+    p.keep_only_inlier_correspondences = int(al.get("keep_only_inlier_correspondences", 0))
+    p.inlier_only_iterations = int(al.get("inlier_only_iterations", 0))
+    if al.get("sensor_in_robot") is not None:
+        set_sensor_in_robot(p, al["sensor_in_robot"])
+    if al.get("motion_prior_info") is not None:
+        set_motion_prior(p, al["motion_prior_info"])
+    return p
+
+
+def set_sensor_in_robot(p, S):
+    """...WithSensor factor variants (aligner_slice_processor_projective.h:80-83): X is the robot's movingInFixed"""
+    p.with_sensor = 1
+    for i, v in enumerate(np.asarray(S, np.float32).reshape(16)):
+        p.sensor_in_robot[i] = float(v)
+    return p
+
+
+def set_motion_prior(p, info=(1.0,) * 6):
+    """AlignerSliceMotionModel3D stand-in (kitti.conf:747-772): prior on movingInFixed with diagonal information"""
+    p.enable_motion_prior = 1
+    for i in range(6):
+        p.motion_prior_info[i] = float(info[i])
     return p
 
 
@@ -322,6 +356,11 @@ class ProjectiveFinder:
         _check(self.ctx, rc, "prs_pcf_compute")
         return out[: n.value].copy(), rc
 
+    def set_motion_prior_mean(self, Z):
+        """mean of the motion prior (None = identity)"""
+        z = None if Z is None else _np(Z, np.float32, (16,))
+        _check(self.ctx, _lib.load().prs_pcf_set_motion_prior_mean(self._h, None if z is None else _p(z)), "prs_pcf_set_motion_prior_mean")
+
     def align(self, params, X_init, prior=None):
         """the whole per-frame loop; returns (X [4,4], correspondences, prs_align_result, warnings)"""
         X0 = _np(X_init, np.float32, (16,))
@@ -364,6 +403,7 @@ class AlignFrames:
         self.n_corr = z((batch,), torch.int32)
         self.result = z((batch, C.sizeof(AlignResult)), torch.uint8)
         self.prior = z((batch, 42), torch.float32) if with_prior else None
+        self.prior_mean = None  # optional [batch, 16] float32 device tensor: mean of the motion prior
         self.max_fixed = 0  # 0 = fixed_stride; smaller bound = less LDS per frame = more frames per CU
         self.reset_state()
 
@@ -407,6 +447,7 @@ class AlignFrames:
         d.inputs_changed, d.state, d.X = self.inputs_changed.data_ptr(), self.state.data_ptr(), self.X.data_ptr()
         d.corr, d.n_corr, d.result = self.corr.data_ptr(), self.n_corr.data_ptr(), self.result.data_ptr()
         d.prior = self.prior.data_ptr() if self.prior is not None else None
+        d.prior_mean = self.prior_mean.data_ptr() if self.prior_mean is not None else None
         d.max_fixed = int(self.max_fixed)
         return d
 
@@ -655,6 +696,14 @@ def pose_compose_batch(ctx, prediction, X, pose_out):
     batch = int(prediction.shape[0])
     rc = _lib.load().prs_pose_compose_batch(ctx._h, batch, prediction.data_ptr(), X.data_ptr(), pose_out.data_ptr())
     _check(ctx, rc, "prs_pose_compose_batch")
+    return rc
+
+
+def motion_predict_batch(ctx, pose_prev2, pose_prev1, pose_pred):
+    """MotionModelConstantVelocity3D on the device: pose_pred = pose_prev1 * (pose_prev2^-1 * pose_prev1), [B, 4, 4] float32"""
+    batch = int(pose_prev1.shape[0])
+    rc = _lib.load().prs_motion_predict_batch(ctx._h, batch, pose_prev2.data_ptr(), pose_prev1.data_ptr(), pose_pred.data_ptr())
+    _check(ctx, rc, "prs_motion_predict_batch")
     return rc
 
 

@@ -1,0 +1,174 @@
+"""HIP aligner vs the CPU oracle for the rows finished in round 2: ...WithSensor factor variants, the inlier flags of
+MultiAligner3DQR (icl.conf / tum.conf), the motion-model prior slice and the constant-velocity prediction -- host-pointer
+handle and batched (split and fused) pipelines -- plus the reference's aligner tests on its own KITTI / ICL images."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import ref_pins as rp
+from helpers import aligner_params as oracle_aligner_params, corr_equal, make_align_case, pcf_params, pcf_params_from_cfg
+from srrg2_proslam_amd import configs, ops
+from test_oracle_aligner_ext import _cfg_for, _icl_case, _set_sensor, with_sensor_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("mode", [2, 3, 4])
+def test_with_sensor_parity(oracle, hip_ctx, mode):
+    pts, desc, K, S, pose, fixed, idx, baseline_px = with_sensor_scene(mode)
+    cfg = _cfg_for(K, mode, baseline_px)
+    cfg["projector"] = {"range_min": 0.1, "range_max": 1000.0}
+    cfg["projective_finder"] = dict(search_type=2, maximum_descriptor_distance=75.0, maximum_distance_ratio_to_second_best=0.5, minimum_matching_ratio=0.25,
+                                    minimum_descriptor_distance=25.0, descriptor_distance_step_size_pixels=5.0, maximum_search_radius_pixels=50,
+                                    minimum_search_radius_pixels=10, search_radius_step_size_pixels=5, minimum_number_of_iterations=10,
+                                    maximum_estimate_change_norm_for_convergence=1e-5, number_of_solver_iterations_per_projection=25)
+    of = oracle.ProjectiveFinder(pcf_params_from_cfg(oracle, cfg))
+    of.set_fixed(fixed, desc[idx])
+    of.set_moving(pts, desc)
+    oap = oracle_aligner_params(oracle, cfg)
+    _set_sensor(oap, S)
+    res, rcorr = oracle.align_frame(of, oap, fixed, pts, None, np.eye(4, dtype=np.float32))
+    gf = ops.ProjectiveFinder(hip_ctx, ops.pcf_params(cfg))
+    gf.set_fixed(fixed, desc[idx])
+    gf.set_moving(pts, desc)
+    gap = ops.set_sensor_in_robot(ops.aligner_params(cfg, mean_disparity=0.0, stop_at_fixed_point=0), S)
+    Xg, gcorr, gres, _ = gf.align(gap, np.eye(4, dtype=np.float32))
+    assert corr_equal(rcorr, gcorr) and len(rcorr) > 40
+    assert np.array_equal(_bits(np.array(res.X).reshape(4, 4)), _bits(Xg))
+    err = oracle.t2tnq(oracle.se3_mul(Xg, pose.astype(np.float32)))
+    assert np.all(np.abs(err[:3]) < 0.15) and np.all(np.abs(err[3:]) < 0.005), err  # tests/test_aligners.cpp:271-278
+
+
+@pytest.mark.parametrize("flags", [(1, 0, 0), (0, 1, 0), (1, 1, 0), (1, 1, 7)])
+@pytest.mark.parametrize("stop", [0, 1])
+def test_inlier_flags_parity_host_handle(oracle, hip_ctx, flags, stop):
+    cfg, fixed, dfix, mp, T, X0, bad = _icl_case()
+    kw = dict(enable_inlier_only_runs=flags[0], keep_only_inlier_correspondences=flags[1], inlier_only_iterations=flags[2])
+    of = oracle.ProjectiveFinder(pcf_params_from_cfg(oracle, cfg))
+    of.set_fixed(fixed, dfix)
+    of.set_moving(mp["xyz"], mp["desc"])
+    res, rcorr = oracle.align_frame(of, oracle_aligner_params(oracle, cfg, **kw), fixed, mp["xyz"], None, X0)
+    gf = ops.ProjectiveFinder(hip_ctx, ops.pcf_params(cfg))
+    gf.set_fixed(fixed, dfix)
+    gf.set_moving(mp["xyz"], mp["desc"])
+    Xg, gcorr, gres, _ = gf.align(ops.aligner_params(cfg, stop_at_fixed_point=stop, **kw), X0)
+    assert corr_equal(rcorr, gcorr)
+    assert np.array_equal(_bits(np.array(res.X).reshape(4, 4)), _bits(Xg))
+    assert (res.status, res.num_inliers, res.num_correspondences, res.iterations) == (gres.status, gres.num_inliers, gres.num_correspondences, gres.iterations)
+    if flags[1]:
+        assert len(gcorr) == gres.num_inliers and not set(gcorr["fixed_idx"].tolist()) & set(bad.tolist())
+
+
+def _batched_case(oracle, cfg_name, B, seed0, n_kp=320, n_mv=420, **al_kw):
+    cases, refs = [], []
+    for b in range(B):
+        cfg, fixed, dfix, mp, T, X0 = make_align_case(cfg_name, seed0 + b, n_kp, n_mv)
+        if b % 3 == 1 and fixed.shape[1] == 3:
+            fixed = fixed.copy()
+            fixed[:: 9, 2] += 3.0  # gross depth outliers: the kernelised class is populated
+        scale = oracle.info_scale_from_nopt(mp["n_opt"])
+        cases.append((fixed, dfix, mp, scale, X0))
+    return cfg, cases
+
+
+@pytest.mark.parametrize("cfg_name", ["icl", "tum", "kitti"])
+@pytest.mark.parametrize("fused", [0, 1])
+def test_inlier_flags_and_prior_parity_batched(oracle, cfg_name, fused):
+    """prs_align_batch_run (split pipeline and, with PRS_FUSED_ALIGN=1 in a child process, the fused kernel)"""
+    if fused:
+        env = dict(os.environ, PRS_FUSED_ALIGN="1", PRS_EXT_CHILD="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__ + "::test_inlier_flags_and_prior_parity_batched", "-k", "0-" + cfg_name, "-m", "gpu"],
+                           env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        return
+    B = 12
+    kw = dict(enable_inlier_only_runs=1, keep_only_inlier_correspondences=1, inlier_only_iterations=9)
+    cfg, cases = _batched_case(oracle, cfg_name, B, 300)
+    ctx = ops.Context(0)
+    ctx.use_torch_stream()
+    try:
+        fs = max(len(c[0]) for c in cases) + 5
+        ms = max(len(c[2]["xyz"]) for c in cases) + 3
+        frames = ops.AlignFrames(0, B, fs, ms)
+        rng = np.random.default_rng(17)
+        Z = np.stack([np.asarray(c[4], np.float32) for c in cases])  # prior mean = the initial guess
+        frames.prior_mean = torch.from_numpy(Z.reshape(B, 16).copy()).cuda()
+        for b, (fixed, dfix, mp, scale, X0) in enumerate(cases):
+            frames.upload(b, fixed, dfix, mp["xyz"], scale, mp["desc"], X0)
+        gap = ops.set_motion_prior(ops.aligner_params(cfg, stop_at_fixed_point=0, **kw), (3.0, 3.0, 3.0, 50.0, 50.0, 50.0))
+        ops.align_batch(ctx, ops.pcf_params(cfg), gap, frames)
+        ctx.synchronize()
+        for b, (fixed, dfix, mp, scale, X0) in enumerate(cases):
+            of = oracle.ProjectiveFinder(pcf_params_from_cfg(oracle, cfg))
+            of.set_fixed(fixed, dfix)
+            of.set_moving(mp["xyz"], mp["desc"])
+            md = oracle.mean_disparity(fixed) if fixed.shape[1] == 4 else 0.0
+            oap = oracle_aligner_params(oracle, cfg, mean_disparity=md, **kw)
+            oap.enable_motion_prior = 1
+            for i, v in enumerate((3.0, 3.0, 3.0, 50.0, 50.0, 50.0)):
+                oap.motion_prior_info[i] = v
+            res, rcorr = oracle.align_frame(of, oap, fixed, mp["xyz"], scale, X0, prior_mean=Z[b])
+            X, gres = frames.X[b].cpu().numpy().reshape(4, 4), frames.result_of(b)
+            assert corr_equal(rcorr, frames.corr_of(b)), b
+            assert np.array_equal(_bits(np.array(res.X).reshape(4, 4)), _bits(X)), b
+            assert (res.status, res.num_inliers, res.num_correspondences, res.iterations) == (gres.status, gres.num_inliers, gres.num_correspondences, gres.iterations), b
+    finally:
+        ctx.close()
+
+
+def test_motion_predict_batch(oracle, hip_ctx):
+    rng = np.random.default_rng(2)
+    from srrg2_proslam_amd import synthetic as syn
+    p2 = np.stack([syn.make_transform(rng.normal(0, 1, 3), rng.normal(0, 0.2, 3)) for _ in range(300)]).astype(np.float32)
+    p1 = np.stack([(p2[i].astype(np.float64) @ syn.make_transform(rng.normal(0, 0.5, 3), rng.normal(0, 0.05, 3))).astype(np.float32) for i in range(300)])
+    hip_ctx.use_torch_stream()
+    d2, d1 = torch.from_numpy(p2).cuda(), torch.from_numpy(p1).cuda()
+    out = torch.zeros_like(d1)
+    ops.motion_predict_batch(hip_ctx, d2, d1, out)
+    hip_ctx.synchronize()
+    got = out.cpu().numpy()
+    for i in range(300):
+        assert np.array_equal(_bits(got[i]), _bits(oracle.motion_predict(p2[i], p1[i]))), i
+
+
+class _Hip:
+    """the aligner call of tests/ref_pins.py on the HIP path"""
+    name = "hip"
+
+    def __init__(self, ctx):
+        from test_ref_pins_gpu import HipBackend
+        self._b = HipBackend(ctx)
+        self.ctx = ctx
+
+    def __getattr__(self, k):
+        return getattr(self._b, k)
+
+    def align(self, cfg, finder, aligner, fixed, dfix, moving, dmov, X0):
+        c = dict(cfg)
+        c["projective_finder"], c["aligner"] = finder, aligner
+        gf = ops.ProjectiveFinder(self.ctx, ops.pcf_params(c))
+        gf.set_fixed(fixed, dfix)
+        gf.set_moving(moving, dmov)
+        X, corr, res, _ = gf.align(ops.aligner_params(c, stop_at_fixed_point=0), X0)
+        return X, corr, res.status, res.num_inliers
+
+
+def test_reference_aligner_tests_on_the_reference_images(oracle, hip_ctx):
+    from test_ref_pins import OracleBackend
+    B, O = _Hip(hip_ctx), OracleBackend()
+    got, ref = rp.kitti_aligner_circle(B), rp.kitti_aligner_circle(O)
+    err = got["error"]
+    assert got["status"] == 1  # tests/test_aligners.cpp:1246
+    assert abs(err[0]) < 0.05 and abs(err[1]) < 0.05 and abs(err[2]) < 0.20 and np.all(np.abs(err[3:]) < 0.01), err  # :1255-1260
+    assert np.array_equal(_bits(got["X"]), _bits(ref["X"])) and got["n_corr"] == ref["n_corr"]
+    got, ref = rp.icl_aligner_depth(B), rp.icl_aligner_depth(O)
+    assert got["status"] == 1 and np.all(np.abs(got["error"]) < 0.01), got["error"]  # :1089, :1098-1103
+    assert np.array_equal(_bits(got["X"]), _bits(ref["X"])) and got["n_corr"] == ref["n_corr"]
