@@ -79,6 +79,7 @@ private:
 };
 using PropertyFloat       = Property_<float>;
 using PropertyUnsignedInt = Property_<uint64_t>;
+using PropertyBool        = Property_<bool>;
 
 // one prs_context shared by the plugin objects of a process (one device, one stream)
 class Context {
@@ -518,6 +519,20 @@ public:
   float param_diagonal_info_matrix[3]     = {1, 1, 1};
   bool param_enable_inverse_depth_weighting = false;
   float baseline_left_in_right_pixels[3]    = {0, 0, 0};  // K * t_left_in_right (aligner_slice_processor_projective.cpp:98-104)
+  // MultiAligner3DQR flags the RGB-D configurations switch on (configurations/icl.conf:50-64, tum.conf:90-104)
+  PropertyBool param_enable_inlier_only_runs{false};
+  PropertyBool param_keep_only_inlier_correspondences{false};
+  // AlignerSliceMotionModel3D (kitti.conf:747-772): prior on movingInFixed around setMotionPriorMean() (identity by default)
+  PropertyBool param_enable_motion_model_slice{false};
+  float param_motion_model_information[6] = {1, 1, 1, 1, 1, 1};
+
+  // the ...WithSensor slice processors read sensor_in_robot from the Platform (setPlatform,
+  // aligner_slice_processor_projective.h:80-83): row-major 4x4; the estimate is then the ROBOT's movingInFixed
+  void setSensorInRobot(const float* T16_row_major) {
+    std::memcpy(_sensor_in_robot, T16_row_major, sizeof(_sensor_in_robot));
+    _with_sensor = true;
+  }
+  void setMotionPriorMean(const float* T16_row_major) { prs_pcf_set_motion_prior_mean(param_finder->handle(), T16_row_major); }
 
   void setFixed(const FixedType* fixed_) { param_finder->setFixed(fixed_); _n_fixed = fixed_ ? fixed_->size() : 0; }
   void setMoving(const MovingType* moving_) { param_finder->setMoving(moving_); }
@@ -547,6 +562,12 @@ public:
     a.min_num_inliers                = (int32_t) param_min_num_inliers.value();
     a.min_num_correspondences        = (int32_t) param_min_num_correspondences.value();
     a.stop_at_fixed_point            = 1;
+    a.enable_inlier_only_runs          = param_enable_inlier_only_runs.value() ? 1 : 0;
+    a.keep_only_inlier_correspondences = param_keep_only_inlier_correspondences.value() ? 1 : 0;
+    a.with_sensor                      = _with_sensor ? 1 : 0;
+    std::memcpy(a.sensor_in_robot, _sensor_in_robot, sizeof(_sensor_in_robot));
+    a.enable_motion_prior = param_enable_motion_model_slice.value() ? 1 : 0;
+    for (int i = 0; i < 6; ++i) a.motion_prior_info[i] = param_motion_model_information[i];
     std::vector<prs_corr> out(_n_fixed + 1);
     int32_t n = 0;
     float X[16];
@@ -561,6 +582,8 @@ protected:
   ContextPtr _ctx;
   size_t _n_fixed = 0;
   float _moving_in_fixed[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  float _sensor_in_robot[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  bool _with_sensor          = false;
   Status _status = Fail;
   CorrespondenceVector _correspondences;
   prs_align_result _result;

@@ -185,6 +185,53 @@ static void test_AlignerSliceProcessorProjective(ContextPtr ctx) {
   ASSERT_TRUE(aligner.correspondences().size() > 40);
 }
 
+// SyntheticWorldWithDescriptorsSE3.AlignerSliceProcessorProjectiveDepthWithSensor (tests/test_aligners.cpp:281-426):
+// sensor_in_robot = ((0.2, 0.3, 0.4), a2r(0, 0.05 pi, 0)), robot 1 at (0, 0, -1); the estimate is the ROBOT's motion.
+// The MultiAligner3DQR flags of icl.conf (inlier-only runs, keep only inliers) are switched on as well.
+static void test_AlignerSliceProcessorProjectiveDepthWithSensor(ContextPtr ctx) {
+  SyntheticWorld world(3);
+  const float ang = 0.05f * 3.14159265358979f, cs = std::cos(ang), sn = std::sin(ang);
+  const float R9[9] = {cs, 0, sn, 0, 1, 0, -sn, 0, cs};                      // rotation about y, rows
+  const float S16[16] = {cs, 0, sn, 0.2f, 0, 1, 0, 0.3f, -sn, 0, cs, 0.4f, 0, 0, 0, 1};
+  const float t3[3] = {0.2f, 0.3f, 0.4f - 1.0f};                              // sensor 1 in world = pose * sensor_in_robot
+  PointIntensityDescriptorVectorCloud<3> points_in_camera_fixed;
+  std::vector<int> truth;
+  world.project<3>(R9, t3, points_in_camera_fixed, truth);
+  using Finder = CorrespondenceFinderProjectiveKDTreeHIP<PointIntensityDescriptorVectorCloud<3>, PointIntensityDescriptorVectorCloud<3>>;
+  AlignerProjectiveHIP<Finder> aligner(ctx);
+  Finder& finder = *aligner.param_finder;
+  finder.param_maximum_descriptor_distance.setValue(75);
+  finder.param_minimum_descriptor_distance.setValue(25);
+  finder.param_maximum_distance_ratio_to_second_best.setValue(0.5f);
+  finder.param_maximum_search_radius_pixels.setValue(50);
+  finder.param_projector->param_canvas_cols.setValue(1000);
+  finder.param_projector->param_canvas_rows.setValue(1000);
+  finder.param_projector->param_range_min.setValue(0.1f);
+  finder.param_projector->param_range_max.setValue(1000);
+  finder.param_projector->setCameraMatrix(world.K);
+  aligner.param_max_iterations.setValue(10);
+  aligner.param_enable_inlier_only_runs.setValue(true);
+  aligner.param_keep_only_inlier_correspondences.setValue(true);
+  aligner.setSensorInRobot(S16);
+  aligner.setFixed(&points_in_camera_fixed);
+  aligner.setMoving(&world.points_in_world);
+  const float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  aligner.setMovingInFixed(I16);
+  aligner.compute();
+  ASSERT_EQ(aligner.status(), AlignerProjectiveHIP<Finder>::Success);
+  ASSERT_EQ(aligner.result().iterations, 20);  // 10 + the inlier-only run
+  // movingInFixed * pose ~ identity with pose = (I | (0, 0, -1)): X ~ (I | (0, 0, 1))
+  const float* X = aligner.movingInFixed();
+  ASSERT_LT_ABS(X[3], 0.15f);
+  ASSERT_LT_ABS(X[7], 0.15f);
+  ASSERT_LT_ABS(X[11] - 1.0f, 0.15f);
+  ASSERT_LT_ABS(0.25f * (X[9] - X[6]), 0.005f);
+  ASSERT_LT_ABS(0.25f * (X[2] - X[8]), 0.005f);
+  ASSERT_LT_ABS(0.25f * (X[4] - X[1]), 0.005f);
+  ASSERT_TRUE(aligner.correspondences().size() > 40);
+  ASSERT_EQ((int) aligner.correspondences().size(), aligner.result().num_inliers);
+}
+
 // triangulate(project(p)) = p and size preservation (tests/fixtures.hpp:939-944, triangulator_rigid_stereo.cpp:39-55)
 static void test_TriangulatorRigidStereo(ContextPtr ctx) {
   TriangulatorRigidStereoHIP triangulator(ctx);
@@ -309,6 +356,7 @@ int main() {
   RUN(test_Epipolar_ThrowsWhenUnset);
   RUN(test_ProjectiveCircle_NoMotionNoNoise);
   RUN(test_AlignerSliceProcessorProjective);
+  RUN(test_AlignerSliceProcessorProjectiveDepthWithSensor);
   RUN(test_TriangulatorRigidStereo);
   RUN(test_SceneClipperProjective3D);
   RUN(test_Bruteforce_CloudVersusItself);
