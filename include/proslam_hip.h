@@ -93,8 +93,7 @@ typedef struct {
   int32_t maximum_disparity_pixels;            /* CF/..epipolar.h:22-26 */
   int32_t epipolar_line_thickness_pixels;      /* CF/..epipolar.h:28-32 */
   int32_t image_rows;                          /* extent of the row table: 0 <= v < image_rows */
-  int32_t image_cols;                          /* 0 = unknown (general kernel); > 0: 0 <= u < image_cols is required and the
-                                                  (row, column-block) binned kernel is used for <= 2048 keypoints per image */
+  int32_t image_cols;                          /* reserved (the column-binned kernel of round 1 was removed); ignored */
 } prs_stereo_params;
 
 /* triangulation parameters, TriangulatorRigidStereo (mapping/triangulator_rigid_stereo.h:34-58,

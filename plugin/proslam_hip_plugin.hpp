@@ -123,7 +123,7 @@ public:
   PropertyUnsignedInt param_epipolar_line_thickness_pixels{0};
   // extent of the row table (image rows); the reference needs none because it compare-sorts
   PropertyUnsignedInt param_image_rows{4096};
-  PropertyUnsignedInt param_image_cols{0};  // 0 = unknown; the image width selects the faster binned kernel
+  PropertyUnsignedInt param_image_cols{0};  // reserved
 
   void setFixed(const FixedType* fixed_) {
     _fixed              = fixed_;

@@ -64,7 +64,6 @@ void ctx_report_stamps(prs_context* ctx, int blocks, int n_stamps, const char* l
 // evaluated on the host with the same IEEE float operations the reference performs:
 // accept iff best < *best_lim && best <= bmax[second] (index 257 = no second candidate)
 void fill_accept_table(const prs_stereo_params* params, int* best_lim, int16_t* bmax258);
-int stereo_match_v4_launch(prs_context* ctx, const prs_stereo_params* params, const prs_stereo_batch* batch);
 int stereo_match_v5_launch(prs_context* ctx, const prs_stereo_params* params, const prs_stereo_batch* batch);
 int stereo_match_batch_launch(prs_context* ctx, const prs_stereo_params* params, const prs_stereo_batch* batch);
 int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs_aligner_params* aligner, const prs_align_batch* batch, int mode);

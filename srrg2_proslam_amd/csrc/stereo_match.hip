@@ -750,6 +750,27 @@ static hipError_t launch_variant(const StereoArgs& a, size_t lds, hipStream_t st
   return hipGetLastError();
 }
 
+void fill_accept_table(const prs_stereo_params* params, int* best_lim, int16_t* bmax) {
+  const float max_dist = params->maximum_descriptor_distance, ratio = params->maximum_distance_ratio_to_second_best;
+  int lim = 0;
+  while (lim <= 256 && (float) lim < max_dist) {
+    ++lim;
+  }
+  *best_lim = lim;
+  for (int s = 0; s <= 257; ++s) {
+    const float fs = s == 257 ? 3.402823466e+38f : (float) s;
+    int bm         = -1;
+    for (int b = 0; b <= 256; ++b) {
+      if ((float) b / fs < ratio) {
+        bm = b;  // monotone in b for fs > 0; for fs == 0 the quotient is NaN or +inf: never accepted
+      } else if (s != 0) {
+        break;
+      }
+    }
+    bmax[s] = (int16_t) (s == 0 ? -1 : bm);
+  }
+}
+
 int stereo_match_batch_launch(prs_context* ctx, const prs_stereo_params* params, const prs_stereo_batch* batch) {
   if (!params || !batch || !batch->left_kp || !batch->left_desc || !batch->n_left || !batch->right_kp ||
       !batch->right_desc || !batch->n_right || !batch->matches || !batch->n_matches || !batch->status) {
@@ -766,11 +787,6 @@ int stereo_match_batch_launch(prs_context* ctx, const prs_stereo_params* params,
     return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_stereo_match_batch: epipolar_line_thickness_pixels > 120");
   }
   {
-    // second-generation kernel when the image width is stated and the frame fits it
-    const int rc4 = stereo_match_v4_launch(ctx, params, batch);
-    if (rc4 != 1) {
-      return rc4;
-    }
     // instruction-lean staged kernel for frames of <= 2048 keypoints (stereo_match_v5.hip)
     const int rc5 = stereo_match_v5_launch(ctx, params, batch);
     if (rc5 != 1) {

@@ -70,7 +70,7 @@ class Context:
 
 
 def stereo_params(cfg_matcher, image_rows, image_cols=0):
-    """image_cols > 0 states the image width and selects the binned kernel (stride <= 2048)"""
+    """image_cols is reserved (ignored)"""
     return StereoParams(
         float(cfg_matcher["maximum_descriptor_distance"]),
         float(cfg_matcher["maximum_distance_ratio_to_second_best"]),
