@@ -12,11 +12,17 @@ shard them with no data-path collective (weak scaling: per-GPU work is fixed).
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline      achieved algorithmic HBM GB/s of the stereo matcher kernel (the kernel the
-                north star prices) + the same for the time-dominant aligner kernel
-  cpu_baseline  the single-threaded CPU restatement (oracle, "port") timed on a bounded sample
-                of the same frames on this box's host cores (rank 0, N=1 only)
+Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
+  roofline          the time-dominant kernel (the aligner's Gauss-Newton kernel, VALU-bound): achieved algorithmic
+                    fp32 TFLOP/s against the 157.3 TFLOP/s vector peak, live HIP-event time of its launches
+  roofline_search   the projective search kernel, roofline_matcher the stereo matcher kernel (the one BASELINE.json's
+                    north star prices: achieved algorithmic HBM GB/s against 8 TB/s)
+  steady_state      the same step with the finder objects carried over from frame to frame (the reference's adaptive
+                    radius / threshold schedule live) instead of fresh finders
+  cpu_baseline      the single-threaded CPU restatement (oracle, "port") timed on a bounded sample
+                    of the same frames on this box's host cores (rank 0, N=1 only)
+`--mode closed-loop` runs the whole per-frame loop (matcher -> clipper -> finder / aligner -> pose update -> merger)
+along the KITTI-00 ground-truth trajectory instead (tools/bench_tracking.py) and prints its line.
 """
 import argparse
 import json
@@ -30,7 +36,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_VECTOR_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
+FLOP_PER_CORRESPONDENCE = 250.0  # one linearised correspondence of one GN iteration
 
 
 def parse():
@@ -48,7 +56,10 @@ def parse():
     ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames generated on the host and tiled")
     ap.add_argument("--cpu-frames", type=int, default=1024, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--binned-matcher", action="store_true", help="use the second-generation (row, column-block) binned matcher kernel")
+    ap.add_argument("--mode", choices=["frame", "closed-loop"], default="frame",
+                    help="frame: the section-8(a) hot path on B independent frames per step (the headline); closed-loop: the "
+                         "stateful per-frame loop incl. clipper and merger along the KITTI-00 trajectory (tools/bench_tracking.py)")
+    ap.add_argument("--frames", type=int, default=60, help="closed-loop mode: frames per sequence")
     ap.add_argument("--all-iterations", action="store_true", help="disable the exact fixed-point early exit of the GN loop")
     ap.add_argument("--cpu-all-cores", type=int, default=-1,
                     help="worker processes of the all-core CPU figure (one independent sequence per core, SURVEY 8d); "
@@ -150,55 +161,61 @@ def cpu_all_cores(args, n_workers, frames_each):
     return total, ok, time.perf_counter() - t0
 
 
-def valu_busy_fractions():
-    """VALU-busy fraction of the aligner kernels from the committed PMC passes (profiles/rNN/align_pmc.json:
-    SQ_ACTIVE_INST_VALU / (8 x SQ_BUSY_CYCLES)); None when the file is absent.  Evidence, not a live measurement."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "align_pmc.json")
-    try:
-        with open(path) as f:
-            frac = json.load(f)["valu_busy_fraction"]
-        return {k.split("prs::")[-1]: round(v, 3) for k, v in frac.items() if isinstance(v, float) and ("align_kernel" in k or "gn_kernel<128, 7, 4>" in k)}
-    except (OSError, KeyError, ValueError):
-        return None
-
-
-def pmc_traffic_bytes(kernel_substrings, frames_per_launch, keypoints):
-    """HBM bytes per bench step of the named kernels (= per launch for the matcher) from the committed rocprofv3 PMC passes of this same
-    command (profiles/rNN/rocprof_summary.json, written by tools/profile_round.sh: FETCH_SIZE and
-    WRITE_SIZE collected in separate passes).  Per /opt/skills/guides/MI355X_MICROARCH.md the
-    counters are KiB and FETCH_SIZE reports half of wide coalesced reads on gfx950, so it is doubled.
-    Returns (bytes, source) or (None, None) when no summary matches this configuration."""
+def profile_evidence(frames_per_launch, keypoints):
+    """HBM bytes per bench step and VALU-busy fractions of the kernels from the COMMITTED rocprofv3 passes of this same command
+    (profiles/rNN/rocprof_summary.json, written by tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in separate passes).
+    Per /opt/skills/guides/MI355X_MICROARCH.md the counters are KiB and FETCH_SIZE reports half of wide coalesced reads on
+    gfx950, so it is doubled.  Evidence from a file, not a live measurement: every figure carries its source.  Kernels are
+    matched by the exact prefix of their demangled name."""
     import glob
+    prefixes = {"matcher": "prs::v5::stereo_match5_kernel<", "search": "prs::align_kernel<", "gn": "prs::gn_kernel<"}
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "rocprof_summary.json")), reverse=True):
         try:
             summ = json.load(open(path))
             if int(summ.get("frames_per_launch", 0)) != int(frames_per_launch) or int(summ.get("keypoints_per_image", 2000)) != int(keypoints):
                 continue
-            total = 0.0
-            steps = [v["FETCH_SIZE"]["launches"] for k, v in summ["pmc_fetch"].items() if "stereo_match" in k][0]
-            for sub in kernel_substrings:
-                f = [v["FETCH_SIZE"] for k, v in summ["pmc_fetch"].items() if sub in k]
-                w = [v["WRITE_SIZE"] for k, v in summ["pmc_write"].items() if sub in k]
-                if not f or not w:
-                    raise KeyError(sub)
-                # launches of this kernel per bench step (the matcher is launched once per step)
-                total += (2.0 * f[0]["mean"] + w[0]["mean"]) * 1024.0 * (f[0]["launches"] / steps)
-            return total, os.path.relpath(path, ROOT)
-        except (OSError, KeyError, ValueError):
+
+            def pick(table, prefix):
+                hits = [(k, v) for k, v in table.items() if k.replace("void ", "").startswith(prefix)]
+                if len(hits) != 1:
+                    raise KeyError(prefix)
+                return hits[0]
+
+            names = {k: pick(summ["pmc_fetch"], pre)[0] for k, pre in prefixes.items()}
+            assert len(set(names.values())) == 3, names  # three distinct kernels
+            steps = pick(summ["pmc_fetch"], prefixes["matcher"])[1]["FETCH_SIZE"]["launches"]
+            out = {"source": os.path.relpath(path, ROOT), "unit": "bytes per bench step (2 * FETCH_SIZE + WRITE_SIZE, separate PMC passes)"}
+            for k, pre in prefixes.items():
+                f = pick(summ["pmc_fetch"], pre)[1]["FETCH_SIZE"]
+                w = pick(summ["pmc_write"], pre)[1]["WRITE_SIZE"]
+                out[k] = (2.0 * f["mean"] + w["mean"]) * 1024.0 * (f["launches"] / steps)
+            return out
+        except (OSError, KeyError, ValueError, AssertionError):
             continue
-    return None, None
+    return None
+
+
+def closed_loop(args):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_tracking
+    out = bench_tracking.run(batch=min(args.batch, 4096), frames=args.frames, keypoints=args.keypoints, check=1 if not args.no_cpu_baseline else 0)
+    out.update({"steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "u64 popcount (Hamming) + f32 (projection, Jacobians, 6x6 normal equations) + f64 (landmark filters)", "data": "synthetic"})
+    print(json.dumps(out))
+
 
 def main():
     args = parse()
     if args.cpu_worker > 0:
         cpu_worker(args)
         return
+    if args.mode == "closed-loop":
+        closed_loop(args)
+        return
     import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from srrg2_proslam_amd import sharding
+    rank, world, local_rank = sharding.rank_world()
     # test hook for 1-GPU boxes: all ranks share device 0 and the rendezvous runs on gloo, so that the
     # multi-rank control flow (barriers, MAX over ranks, rank-0 reporting) can be exercised without 8 GPUs
     shared = os.environ.get("PRS_BENCH_SHARE_GPU", "0") == "1"
@@ -207,12 +224,8 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if shared:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    sharding.init_distributed("gloo" if shared else "nccl", local_rank)
+    red_dev = "cpu" if shared else torch.device("cuda", local_rank)
 
     from srrg2_proslam_amd import _lib, configs, ops, synthetic as syn
 
@@ -247,14 +260,16 @@ def main():
 
     ctx = ops.Context(local_rank)
     stream = torch.cuda.Stream(device=dev)
-    sp = ops.stereo_params(cfg["stereo_matcher"], cfg["camera"]["rows"], cfg["camera"]["cols"] if args.binned_matcher else 0)
+    sp = ops.stereo_params(cfg["stereo_matcher"], cfg["camera"]["rows"])
     tp = ops.triangulator_params(cfg)
     pp = ops.pcf_params(cfg)
     ap = ops.aligner_params(cfg, stop_at_fixed_point=0 if args.all_iterations else 1)
 
-    def step(ev=None):
-        # fresh finder objects + motion-model guess for every frame of the batch
-        aframes.state.copy_(state0, non_blocking=True)
+    def step(ev=None, fresh_finders=True):
+        # the motion-model guess for every frame of the batch; fresh finder objects (heaviest case: maximum search radius)
+        # or the finders of the previous step (the reference's objects live across frames)
+        if fresh_finders:
+            aframes.state.copy_(state0, non_blocking=True)
         aframes.X.copy_(X0_all, non_blocking=True)
         aframes.n_corr.zero_()
         if ev:
@@ -268,47 +283,68 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        sharding.barrier()
 
     with torch.cuda.stream(stream):
         ctx.use_torch_stream()
         for _ in range(args.warmup):
             step()
         events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        ctx.enable_timing(True)  # HIP events around every launch of the aligner's two kernels, on this stream
         barrier()
         t0 = time.perf_counter()
         for k in range(args.steps):
             step(events[k])
         barrier()
-        elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed_local = time.perf_counter() - t0
+        timing = ctx.align_timing()
+        ctx.enable_timing(False)
+        fps, elapsed = sharding.aggregate_throughput(B * args.steps, elapsed_local, red_dev)
+        # results of the timed configuration, before the steady-state leg overwrites them
+        n_match = sframes.n_matches.float().mean().item()
+        n_fixed = sframes.n_fixed.float().mean().item()
+        n_corr = aframes.n_corr.float().mean().item()
+        results = aframes.result.cpu().numpy()
+        Xg = aframes.X.cpu().numpy()
+        corr_g = [aframes.corr_of(u) for u in range(min(len(uniq), B))]
+        # ---- steady state: the same frames again with the finders carried over (radius / threshold schedule adapted) ----
+        steady = None
+        if rank == 0 and world == 1:
+            for _ in range(6):  # radius 50 -> 10 px in steps of 10, threshold 25 -> 50
+                step(fresh_finders=False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(max(args.steps // 2, 1)):
+                step(fresh_finders=False)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            st = aframes.state_of(0)
+            steady = {"value": B * max(args.steps // 2, 1) / dt, "unit": "frames/s", "ms_per_step": dt / max(args.steps // 2, 1) * 1e3,
+                      "search_radius_pixels": int(st.search_radius_pixels), "descriptor_distance": float(st.descriptor_distance),
+                      "aligner_correspondences_per_frame": aframes.n_corr.float().mean().item(),
+                      "note": "finder objects live across steps like the reference's (correspondence_finder_projective_base_impl.cpp:277-287): "
+                              "after six tracked frames the search radius has shrunk to its minimum and the descriptor threshold has grown"}
 
-    # ---- per-kernel time (HIP events on the launch stream) + algorithmic bytes ------------------
+    # ---- per-kernel time (HIP events on the launch stream) + algorithmic bytes / flops ------------------
     ms_match = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
     ms_align = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
-    n_match = sframes.n_matches.float().mean().item()
-    n_fixed = sframes.n_fixed.float().mean().item()
-    n_corr = aframes.n_corr.float().mean().item()
-    results = aframes.result.cpu().numpy()
-    res0 = _lib.AlignResult.from_buffer_copy(results[0].tobytes())
+    ms_search = timing["search_ms"] / args.steps
+    ms_gn = timing["gn_ms"] / args.steps
+    res = [_lib.AlignResult.from_buffer_copy(results[b].tobytes()) for b in range(min(B, 256))]
     warn_min = min(_lib.AlignResult.from_buffer_copy(results[b].tobytes()).warnings for b in range(B))
     if warn_min < 0:
         raise SystemExit("align kernel reported error %d (raise --max-fixed?)" % warn_min)
-    status_ok = float(np.mean([_lib.AlignResult.from_buffer_copy(results[b].tobytes()).status for b in range(min(B, 256))]))
-    it_exec = float(np.mean([_lib.AlignResult.from_buffer_copy(results[b].tobytes()).iterations_executed for b in range(min(B, 256))]))
+    status_ok = float(np.mean([r.status for r in res]))
+    it_exec = float(np.mean([r.iterations_executed for r in res]))
     # matcher 40 (N_L + N_R) + 12 M, triangulator 16 M + 13 M: the launch runs both (fused epilogue)
     bytes_match = 40.0 * (2 * N) + 12.0 * n_match + 29.0 * n_fixed
-    bytes_align = 48.0 * NM + 48.0 * n_fixed + 64 + 12.0 * n_corr + 64  # single pass: map + fixed cloud + pose in, corr + pose out
+    bytes_search = 44.0 * NM + 40.0 * n_fixed + 64 + 12.0 * n_corr  # projective finder, per recompute
+    searches = timing["search_launches"] / args.steps
     gbps_match = B * bytes_match / (ms_match * 1e-3) / 1e9
-    gbps_align = B * bytes_align / (ms_align * 1e-3) / 1e9
-    fps = world * B * args.steps / elapsed
-    traffic_match, traffic_src = pmc_traffic_bytes(["stereo_match"], B, N)
-    # all search + GN rounds of one step
-    traffic_align, _ = pmc_traffic_bytes(["align_kernel", "gn_kernel"], B, N)
+    gbps_search = B * bytes_search * searches / (ms_search * 1e-3) / 1e9 if ms_search > 0 else 0.0
+    flops_gn = FLOP_PER_CORRESPONDENCE * n_corr * it_exec * B  # per step
+    tflops_gn = flops_gn / (ms_gn * 1e-3) / 1e12 if ms_gn > 0 else 0.0
+    evidence = profile_evidence(B, N)
 
     out = {
         "metric": "tracked frames/sec on KITTI-00 stereo (1241x376, ~2k kp); SE(3) vs ref",
@@ -324,9 +360,9 @@ def main():
         "dtype": "u64 popcount (Hamming) + f32 (projection, Jacobians, 6x6 normal equations)",
         "data": "synthetic",
         "config": {
-            "workload": "KITTI 00 stereo shaped (1241x376, FAST+BRIEF-like ~%d kp/image, 256-bit descriptors), "
+            "workload": "KITTI 00 stereo shaped (1241x376, FAST+ORB-like ~%d kp/image, 256-bit descriptors), "
                         "kitti.conf parameters: epipolar matcher + triangulator + projective circle finder + "
-                        "stereo GN aligner, %d iterations/frame" % (N, cfg["aligner"]["max_iterations"]),
+                        "stereo GN aligner, %d iterations/frame; fresh finder objects every step (maximum search radius)" % (N, cfg["aligner"]["max_iterations"]),
             "frames_per_step_per_gpu": B,
             "keypoints_per_image": N,
             "local_map_points": NM,
@@ -337,46 +373,58 @@ def main():
             "aligner_success_fraction": status_ok,
         },
         "roofline": {
+            "kernel": "gn_kernel<128, SLOTS, stereo> (reprojection-error Gauss-Newton rounds: factor linearisation, ordered H / b sums, "
+                      "6x6 solve; the time-dominant kernel, all its launches of one step)",
+            "bound": "valu",
+            "achieved": tflops_gn,
+            "peak": FP32_VECTOR_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": tflops_gn / FP32_VECTOR_TFLOPS,
+            "traffic": evidence["gn"] if evidence else None,
+            "traffic_unit": evidence["unit"] if evidence else None,
+            "traffic_source": evidence["source"] if evidence else None,
+            "ms_per_step": ms_gn,
+            "launches_per_step": timing["gn_launches"] / args.steps,
+            "algorithmic_flop_per_step": flops_gn,
+            "flop_per_correspondence_iteration": FLOP_PER_CORRESPONDENCE,
+            "note": "fp32 vector arithmetic, no MFMA: 6x6 normal equations are not a dense contraction; the kernel is bound by "
+                    "instruction issue (VALU-busy fraction in profiles/), frac prices only the algorithmic flops",
+        },
+        "roofline_search": {
+            "kernel": "align_kernel<512, split, circle> (projective search: projection, cell-grid circle search, Hamming, candidate filter)",
+            "bound": "hbm", "achieved": gbps_search, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps_search / HBM_PEAK_GBPS,
+            "traffic": evidence["search"] if evidence else None, "traffic_source": evidence["source"] if evidence else None,
+            "ms_per_step": ms_search, "launches_per_step": searches, "algorithmic_bytes_per_frame_and_launch": bytes_search, "frames_per_launch": B,
+        },
+        "roofline_matcher": {
             "kernel": "stereo_match5_kernel<%d> (the kernel BASELINE.json north_star prices; matcher + fused adaptor / triangulator epilogue)" % (1 if N <= 1024 else 2),
             "bound": "hbm",
             "achieved": gbps_match,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": gbps_match / HBM_PEAK_GBPS,
-            "traffic": traffic_match,
-            "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate PMC passes)",
-            "traffic_source": traffic_src,
+            "traffic": evidence["matcher"] if evidence else None,
+            "traffic_unit": evidence["unit"] if evidence else None,
+            "traffic_source": evidence["source"] if evidence else None,
             "ms_per_launch": ms_match,
             "algorithmic_bytes_per_frame": bytes_match,
             "frames_per_launch": B,
         },
-        "roofline_align": {
-            "kernel": "align_kernel<512> (projective search) + gn_kernel, all rounds of one step "
-                      "(time-dominant; VALU-bound, not HBM-bound: see valu_busy_frac)",
-            "valu_busy_frac": valu_busy_fractions(),
-            "bound": "hbm",
-            "achieved": gbps_align,
-            "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s",
-            "frac": gbps_align / HBM_PEAK_GBPS,
-            "traffic": traffic_align,
-            "ms_per_launch": ms_align,
-            "algorithmic_bytes_per_frame": bytes_align,
-            "frames_per_launch": B,
-        },
-        "kernel_time_share": {"stereo_match5_kernel": ms_match / (ms_match + ms_align), "align_kernel": ms_align / (ms_match + ms_align)},
+        "kernel_time_share": {"stereo_match5_kernel": ms_match / (ms_match + ms_align), "align_kernel (search)": ms_search / (ms_match + ms_align),
+                              "gn_kernel": ms_gn / (ms_match + ms_align)},
     }
+    if steady:
+        out["steady_state"] = steady
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_frames > 0:
         cpu_fps, cpu_s, poses = cpu_baseline(cfg, uniq, args.cpu_frames)
         # the same run doubles as an end-to-end check of the device pipeline on the bench inputs
-        Xg = aframes.X.cpu().numpy()
         worst = 0.0
         exact_corr = True
         for u in range(min(len(uniq), B)):
             Xr, c = poses[u]
             worst = max(worst, float(np.linalg.norm(Xg[u] - Xr) / np.linalg.norm(Xr)))
-            gc = aframes.corr_of(u)
+            gc = corr_g[u]
             exact_corr = exact_corr and len(gc) == len(c) and bool(np.array_equal(gc["fixed_idx"], c["fixed_idx"])) and bool(np.array_equal(gc["moving_idx"], c["moving_idx"]))
         out["cpu_baseline"] = {
             "value": cpu_fps,
@@ -398,9 +446,7 @@ def main():
             }
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
-    del res0
+    sharding.shutdown()
 
 
 if __name__ == "__main__":

@@ -77,6 +77,10 @@ PRS_API int prs_context_set_stream(prs_context* ctx, void* hip_stream);
 /* go back to the non-blocking stream the context created for itself (the initial state) */
 PRS_API int prs_context_use_own_stream(prs_context* ctx);
 PRS_API int prs_context_synchronize(prs_context* ctx);
+/* measurement: when on, prs_align_batch_run brackets every launch of its two kernels (projective search, Gauss-Newton
+ * rounds) with HIP events on the context's stream and accumulates their durations; enabling resets the sums */
+PRS_API int prs_context_enable_timing(prs_context* ctx, int32_t on);
+PRS_API int prs_context_get_align_timing(prs_context* ctx, double* search_ms, double* gn_ms, int64_t* search_launches, int64_t* gn_launches);
 PRS_API const char* prs_last_error(const prs_context* ctx);
 PRS_API const char* prs_status_string(int status);
 PRS_API int prs_version(void);
@@ -577,7 +581,8 @@ PRS_API int prs_merge_batch_run(prs_context* ctx, const prs_merger_params* param
 PRS_API int prs_pose_compose_batch(prs_context* ctx, int32_t batch, const float* prediction, const float* X, float* pose_out);
 
 /* MotionModelConstantVelocity3D (external; configurations/kitti.conf:257-260): the tracker's guess for the next pose
- * repeats the last inter-frame motion, pose_pred[b] = pose_prev1[b] * (pose_prev2[b]^-1 * pose_prev1[b]).
+ * repeats the last inter-frame motion, pose_pred[b] = pose_prev1[b] * (pose_prev2[b]^-1 * pose_prev1[b]), with the
+ * rotation block renormalised through its unit quaternion (the recursion amplifies rounding otherwise).
  * Device arrays of [batch][16] row-major float; pose_pred may alias pose_prev2. */
 PRS_API int prs_motion_predict_batch(prs_context* ctx, int32_t batch, const float* pose_prev2, const float* pose_prev1, float* pose_pred);
 

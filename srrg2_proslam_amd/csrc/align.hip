@@ -1916,10 +1916,35 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   int rounds_left = 5;
   int total       = 0;
   const int limit = 2 * (aligner->max_iterations + inlier_run_length(*aligner)) + 8;
+  int ev_used = 0;
+  auto tick = [&]() {  // measurement only (prs_context_enable_timing): one event per kernel boundary
+    if (ctx->timing && ev_used < 3 * 64) {
+      if (!ctx->timing_ev[ev_used]) {
+        (void) hipEventCreate(&ctx->timing_ev[ev_used]);
+      }
+      (void) hipEventRecord(ctx->timing_ev[ev_used], stream);
+      ++ev_used;
+    }
+  };
+  auto collect = [&]() {  // after a stream synchronisation: add up (search, GN) pairs of [e0, e1, e2] triples
+    for (int i = 0; i + 2 < ev_used; i += 3) {
+      float a = 0.f, b = 0.f;
+      if (hipEventElapsedTime(&a, ctx->timing_ev[i], ctx->timing_ev[i + 1]) == hipSuccess &&
+          hipEventElapsedTime(&b, ctx->timing_ev[i + 1], ctx->timing_ev[i + 2]) == hipSuccess) {
+        ctx->t_search_ms += a;
+        ctx->t_gn_ms += b;
+        ++ctx->n_search;
+        ++ctx->n_gn;
+      }
+    }
+    ev_used = 0;
+  };
   for (;;) {
     for (int r = 0; r < rounds_left; ++r) {
       (void) hipMemsetAsync(g.pending, 0, sizeof(int), stream);
+      tick();
       hipLaunchKernelGGL(skernel, dim3(batch->batch), dim3(kSearchThreads), lds_search, stream, gs);
+      tick();
       if (stamps_split) {
         ctx_report_stamps(ctx, batch->batch, 10, "search launch (split): - | - | - | - || lattice build | projection+search | second-best pass | filter | commit");
       }
@@ -1950,6 +1975,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
       } else {
         hipLaunchKernelGGL((gn_kernel<kGnThreads, 4>), dim3(batch->batch), dim3(kGnThreads), lds_gn, stream, g);
       }
+      tick();
       ++total;
     }
     e = hipGetLastError();
@@ -1964,6 +1990,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
     if (e != hipSuccess) {
       return ctx_fail_hip(ctx, e, "prs_align_batch_run split completion check");
     }
+    collect();
     if (pending == 0) {
       break;
     }

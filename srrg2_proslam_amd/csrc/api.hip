@@ -233,7 +233,33 @@ int prs_context_destroy(prs_context* ctx) {
   if (ctx->own) {
     (void) hipStreamDestroy(ctx->own);
   }
+  for (hipEvent_t e : ctx->timing_ev) {
+    if (e) {
+      (void) hipEventDestroy(e);
+    }
+  }
   delete ctx;
+  return PRS_OK;
+}
+
+int prs_context_enable_timing(prs_context* ctx, int32_t on) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  ctx->timing      = on != 0;
+  ctx->t_search_ms = ctx->t_gn_ms = 0.0;
+  ctx->n_search = ctx->n_gn = 0;
+  return PRS_OK;
+}
+
+int prs_context_get_align_timing(prs_context* ctx, double* search_ms, double* gn_ms, int64_t* search_launches, int64_t* gn_launches) {
+  if (!ctx || !search_ms || !gn_ms || !search_launches || !gn_launches) {
+    return PRS_ERR_NULL;
+  }
+  *search_ms       = ctx->t_search_ms;
+  *gn_ms           = ctx->t_gn_ms;
+  *search_launches = ctx->n_search;
+  *gn_launches     = ctx->n_gn;
   return PRS_OK;
 }
 

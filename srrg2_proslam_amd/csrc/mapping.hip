@@ -1531,7 +1531,7 @@ __global__ __launch_bounds__(256) void motion_predict_kernel(int batch, const fl
   if (b >= batch) {
     return;
   }
-  float P2[16], P1[16], I2[16], M[16], R[16];
+  float P2[16], P1[16], I2[16], M[16], raw[16], R[16], v[6];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     P2[i] = prev2[(size_t) b * 16 + i];
@@ -1539,7 +1539,11 @@ __global__ __launch_bounds__(256) void motion_predict_kernel(int batch, const fl
   }
   se3_inverse(P2, I2);
   se3_mul(I2, P1, M);
-  se3_mul(P1, M, R);
+  se3_mul(P1, M, raw);
+  // through the unit quaternion: the recursion would otherwise amplify the rotation block's drift from orthonormality
+  // by ~2.4x per frame (se3_inverse transposes)
+  t2tnq(raw, v);
+  tnq2t(v, R);
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     pred[(size_t) b * 16 + i] = R[i];

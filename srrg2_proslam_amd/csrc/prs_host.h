@@ -27,6 +27,11 @@ struct prs_context {
   float* d_info_lut     = nullptr;  // information scale by landmark age, 4096 entries (scene clipper)
   void* h_pinned        = nullptr;
   size_t h_pinned_size  = 0;
+  // per-kernel HIP-event timing of the split aligner pipeline (prs_context_enable_timing; measurement only)
+  bool timing           = false;
+  double t_search_ms = 0.0, t_gn_ms = 0.0;
+  long long n_search = 0, n_gn = 0;
+  hipEvent_t timing_ev[3 * 64] = {};
   // diagnostic phase stamps (PRS_STAMPS=1): never enabled in timed runs
   bool stamps_enabled   = false;
   unsigned long long* d_stamps = nullptr;

@@ -68,6 +68,16 @@ class Context:
     def synchronize(self):
         _check(self, _lib.load().prs_context_synchronize(self._h), "prs_context_synchronize")
 
+    def enable_timing(self, on=True):
+        """HIP-event timing of the aligner's two kernels inside align_batch (measurement only)"""
+        _check(self, _lib.load().prs_context_enable_timing(self._h, 1 if on else 0), "prs_context_enable_timing")
+
+    def align_timing(self):
+        """-> dict(search_ms, gn_ms, search_launches, gn_launches) accumulated since enable_timing()"""
+        a, b, c, d = C.c_double(0), C.c_double(0), C.c_int64(0), C.c_int64(0)
+        _check(self, _lib.load().prs_context_get_align_timing(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "prs_context_get_align_timing")
+        return {"search_ms": a.value, "gn_ms": b.value, "search_launches": c.value, "gn_launches": d.value}
+
 
 def stereo_params(cfg_matcher, image_rows, image_cols=0):
     """image_cols is reserved (ignored)"""

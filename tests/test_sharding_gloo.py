@@ -21,8 +21,8 @@ def _free_port():
 
 
 def _worker(rank, world, port, n_sequences, out_dir):
-    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world)})
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
+    assert sharding.init_distributed("gloo") == (rank, world)  # the rendezvous bench.py uses
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
     from helpers import kitti_frame, oracle_stereo_params
@@ -35,13 +35,14 @@ def _worker(rank, world, port, n_sequences, out_dir):
         corr, _ = ob.stereo_match(fr["uv_left"], fr["desc_left"], fr["uv_right"], fr["desc_right"], oracle_stereo_params(ob, cfg["stereo_matcher"]))
         digest.append((s, int(len(corr)), int(corr["moving_idx"].sum())))
         frames += 1
-    dist.barrier()
+    sharding.barrier()
     elapsed = 0.5 + 0.25 * rank  # deterministic stand-in for a measured time
-    t_max = sharding.max_over_ranks(elapsed)
+    fps, t_max = sharding.aggregate_throughput(frames, elapsed)  # bench.py's own aggregation
     total = sharding.sum_over_ranks(frames)
+    assert fps == total / t_max
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.array([t_max, total] + [v for d in digest for v in d], dtype=np.float64))
-    dist.barrier()
-    dist.destroy_process_group()
+    sharding.barrier()
+    sharding.shutdown()
 
 
 def test_two_ranks_shard_sequences_without_overlap(tmp_path):
@@ -68,3 +69,17 @@ def test_sharding_is_a_partition():
         parts = [sharding.sequences_of_rank(11, r, world) for r in range(world)]
         assert sorted(sum(parts, [])) == list(range(11))
     assert sharding.max_over_ranks(1.5) == 1.5 and sharding.sum_over_ranks(3) == 3.0
+    assert sharding.aggregate_throughput(10, 2.0) == (5.0, 2.0)
+
+
+def test_uneven_sequences_are_balanced():
+    """config 5: KITTI 00-07 have 4541, 1101, 4661, 801, 271, 2761, 1101, 1101 frames; one per GPU leaves seven GPUs idle while
+    00 / 02 finish.  With fewer ranks than sequences the longest-first assignment evens the load out."""
+    lengths = [4541, 1101, 4661, 801, 271, 2761, 1101, 1101]
+    for world in (1, 2, 4, 8):
+        parts = [sharding.balanced_sequences_of_rank(lengths, r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == list(range(8))
+        loads = [sum(lengths[s] for s in part) for part in parts]
+        assert max(loads) <= max(max(lengths), -(-sum(lengths) // world) + max(lengths) // 2)
+    two = [sum(lengths[s] for s in sharding.balanced_sequences_of_rank(lengths, r, 2)) for r in range(2)]
+    assert abs(two[0] - two[1]) <= 300
