@@ -1,7 +1,7 @@
 /*
  * proslam_oracle.c -- CPU restatement of srrg2_proslam's per-frame tracking hot path.
- * TEST INFRASTRUCTURE ONLY (see proslam_oracle.h): parity unpinned for exact values, behaviour
- * pinned against the reference tests' own gates.  Single-threaded, C99, -O2 -ffp-contract=off.
+ * TEST INFRASTRUCTURE ONLY (see proslam_oracle.h): pinned against the counts and tolerances the reference's
+ * gtests assert on its own test images (tests/test_ref_pins.py).  Single-threaded, C99, -O2 -ffp-contract=off.
  *
  * Every function cites the reference file:line it follows.  Paths are relative to
  * /root/reference/srrg2_proslam/src/srrg2_proslam/ unless they start with tests/ or configurations/.

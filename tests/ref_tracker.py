@@ -1,0 +1,115 @@
+"""The tracker loop of tests/test_trackers.cpp restated on the pieces of the hot path: adaptor -> (scene clipper ->
+projective finder + aligner) -> merger, on the reference's own KITTI / ICL images (tests/golden/ref_*.npz).
+
+`Tracker` is written against a small stage interface (`stages`) so that the CPU checker (tests/test_ref_tracker.py) and the
+HIP path (tests/test_ref_tracker_gpu.py) run the same loop; the scenarios and the bounds the reference asserts live here.
+robotInLocalMap of frame k = prediction * X^-1, X = local map in sensor as estimated by the aligner
+(multi_tracker: the measurement is the fixed cloud, the clipped local map the moving one)."""
+import numpy as np
+
+import ref_pins as rp
+
+I4 = np.eye(4, dtype=np.float32)
+
+
+def kitti_measurements(B, i):
+    """KITTI fixture adaptor (fixtures.hpp:800-1050): FAST 15, 500 keypoints in 3x3 bins, epipolar matcher (50, Lowe 0.8)"""
+    key = ("kitti_meas", B.name, i)
+    if key not in rp._cache:
+        pts, desc, _ = rp.stereo_adaptor(B, rp.kitti_image("left", i), rp.kitti_image("right", i), 15, "epipolar", 50.0, 0.8)
+        rp._cache[key] = (pts, desc)
+    return rp._cache[key]
+
+
+def icl_measurements(B, k):
+    m = rp.icl_measurements(B, k)
+    return np.concatenate([m["uv"], m["depth"][:, None]], axis=1).astype(np.float32), m["desc"]
+
+
+def kitti_setup(no_merges):
+    """KITTI 00To04_Tracker_* (tests/test_trackers.cpp:258-360 / :362-470): kitti.conf tracker, robustifier chi 1000, circle finder
+    with distance 25..100, Lowe 0.5, radius 50..5, matching ratio 0.1; `no_merges`: appearance and geometry thresholds 0"""
+    from srrg2_proslam_amd import configs
+    cfg = dict(configs.get("kitti"))
+    f = dict(cfg["projective_finder"])
+    f.update(minimum_descriptor_distance=25.0, maximum_descriptor_distance=100.0, maximum_distance_ratio_to_second_best=0.5,
+             minimum_search_radius_pixels=5, maximum_search_radius_pixels=50, minimum_matching_ratio=0.1, search_type=rp.CIRCLE)
+    a = dict(cfg["aligner"])
+    a["chi_threshold"] = 1000.0
+    cfg["projective_finder"], cfg["aligner"] = f, a
+    if no_merges:
+        merger = dict(variant="stereo_triangulation", estimator="weighted_mean", max_appearance=0.0, max_dist2=0.0)
+    else:  # :380-388: merger_triangulation, appearance 50, weighted mean with 25 m^2
+        merger = dict(variant="stereo_triangulation", estimator="weighted_mean", max_appearance=50.0, max_dist2=25.0)
+    return cfg, merger
+
+
+def icl_setup():
+    """ICL 00To50_Tracker_ProjectiveBruteforce (tests/test_trackers.cpp:90-162): icl.conf tracker + cf_projective_circle"""
+    from srrg2_proslam_amd import configs
+    cfg = dict(configs.get("icl"))
+    f = dict(cfg["projective_finder"])
+    f["search_type"] = rp.CIRCLE
+    cfg["projective_finder"] = f
+    return cfg, dict(variant="depth_ekf", estimator="ekf3", max_appearance=50.0, max_dist2=1.0)
+
+
+class Tracker:
+    """stages: object with
+         clip(cfg, pose, map) -> (xyzw, desc, scene indices)
+         align(cfg, fixed, fixed_desc, xyzw, desc, guess, prior_info) -> (X, corr (fixed = measurement, moving = clipped), status, inliers)
+         new_map(cfg, merger, capacity) -> map;  merge(map, pose, fixed, fixed_desc, corr, scene_indices) -> (n_merged, n_added)
+         map_size(map), predict(prev, pose) -> pose, compose(guess, X) -> guess * X^-1, reset()"""
+
+    def __init__(self, stages, cfg, merger, capacity=4096, use_prediction=False, prior_info=0.0):
+        self.s, self.cfg, self.prior_info, self.use_prediction = stages, cfg, prior_info, use_prediction
+        stages.reset()  # a new tracker: new finder state
+        self.map = stages.new_map(cfg, merger, capacity)
+        self.pose, self.prev = I4.copy(), I4.copy()
+        self.frames = 0
+        self.log = []
+
+    def process(self, fixed, desc):
+        s = self.s
+        entry = dict(n_measured=len(fixed))
+        corr, idx = None, None
+        if self.frames > 0:
+            guess = s.predict(self.prev, self.pose) if self.use_prediction else self.pose
+            xyzw, cdesc, idx = s.clip(self.cfg, guess, self.map)
+            X, corr, status, inliers = s.align(self.cfg, fixed, desc, xyzw, cdesc, I4, self.prior_info)
+            self.prev = self.pose
+            self.pose = s.compose(guess, X)
+            entry.update(status=status, inliers=inliers, n_corr=len(corr), n_clipped=len(xyzw))
+        merged, added = s.merge(self.map, self.pose, fixed, desc, corr, idx)
+        self.frames += 1
+        entry.update(pose=self.pose.copy(), map_size=s.map_size(self.map), merged=merged, added=added)
+        self.log.append(entry)
+        return entry
+
+
+def same_frame_three_times(stages, B, dataset):
+    """..00To00_Tracker_.._MergerDefault (tests/test_trackers.cpp:7-88, :164-256): the robot does not move, the map does not grow"""
+    if dataset == "kitti":
+        cfg, merger = kitti_setup(no_merges=False)
+        fixed, desc = kitti_measurements(B, 0)
+    else:
+        cfg, merger = icl_setup()
+        fixed, desc = icl_measurements(B, 0)
+    t = Tracker(stages, cfg, merger)
+    return [t.process(fixed, desc) for _ in range(3)]
+
+
+def kitti_00_to_04(stages, B, no_merges, **kw):
+    cfg, merger = kitti_setup(no_merges)
+    t = Tracker(stages, cfg, merger, **kw)
+    log = [t.process(*kitti_measurements(B, i)) for i in range(5)]
+    error = rp.t2tnq(np.linalg.inv(np.asarray(t.pose, np.float64)) @ rp.kitti_relative(4, 0))
+    return log, error
+
+
+def icl_00_01_50(stages, B, **kw):
+    cfg, merger = icl_setup()
+    t = Tracker(stages, cfg, merger, **kw)
+    log = [t.process(*icl_measurements(B, k)) for k in (0, 1, 50)]
+    error = rp.t2tnq(np.linalg.inv(np.asarray(t.pose, np.float64)) @ rp.icl_relative(50, 0))
+    return log, error

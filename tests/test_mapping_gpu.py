@@ -90,7 +90,8 @@ def _frame_pose(rng, k):
     return T.astype(np.float32)
 
 
-CASES = [("weighted_mean", om.MERGER_STEREO_TRIANGULATION, 0), ("smoother", om.MERGER_STEREO_TRIANGULATION, 8), ("stereo_ekf", om.MERGER_STEREO_EKF, 0)]
+CASES = [("weighted_mean", om.MERGER_STEREO_TRIANGULATION, 0), ("smoother", om.MERGER_STEREO_TRIANGULATION, 8), ("stereo_ekf", om.MERGER_STEREO_EKF, 0),
+         ("depth_ekf", om.MERGER_DEPTH_EKF, 0)]
 
 
 def _estimator(kind, K, bpx):
@@ -98,6 +99,8 @@ def _estimator(kind, K, bpx):
         return om.estimator_params(om.EST_WEIGHTED_MEAN, 4, K, max_dist2=25.0)
     if kind == "smoother":
         return om.estimator_params(om.EST_SMOOTHER, 4, K, max_dist2=100.0, chi2_delta=1e-6)  # kitti.conf:503-517
+    if kind == "depth_ekf":
+        return om.estimator_params(om.EST_EKF, 3, K, max_dist2=1.0)  # MergerProjectiveDepthEKF + LandmarkEstimatorProjectiveEKF3D3D (icl.conf:506)
     return om.estimator_params(om.EST_EKF, 4, K, baseline_px=bpx, max_dist2=25.0, max_cov_norm2=0.25)  # kitti.conf:1-17
 
 
@@ -106,7 +109,8 @@ def _estimator(kind, K, bpx):
 def test_sequence_of_frames_merges_identically(oracle, hip_ctx, kind, variant, max_meas, binning):
     """frame 0 seeds the map (no correspondences), frames 1..4 merge with descriptor-derived correspondences"""
     rng = np.random.default_rng(31)
-    cfg = configs.get("kitti")
+    depth = variant == om.MERGER_DEPTH_EKF  # RGB-D: measurements are (u, v, depth) of the ICL camera
+    cfg = configs.get("icl" if depth else "kitti")
     K = (cfg["camera"]["fx"], cfg["camera"]["fy"], cfg["camera"]["cx"], cfg["camera"]["cy"])
     po = oracle_merger_params(cfg, variant, _estimator(kind, K, (configs.baseline_pixels(cfg), 0.0)), enable_binning=binning,
                               target_merges=10 ** 6 if binning else 50)
@@ -118,7 +122,11 @@ def test_sequence_of_frames_merges_identically(oracle, hip_ctx, kind, variant, m
     _upload_map(maps, 0, m, poses)
     prev = None
     for k in range(5):
-        _, fixed, desc, xyz = stereo_scene(40 + k, n_kp=500)
+        if depth:
+            fr = hp.syn.rgbd_frame(np.random.default_rng(40 + k), cfg, 500)
+            fixed, desc = fr["fixed"][:, :3].astype(np.float32), fr["desc_fixed"].copy()
+        else:
+            _, fixed, desc, xyz = stereo_scene(40 + k, n_kp=500)
         # the same world seen again: reuse part of the previous frame's descriptors so that correspondences exist
         if prev is not None:
             reuse = min(len(fixed), len(prev[1])) // 2
@@ -150,7 +158,7 @@ def test_sequence_of_frames_merges_identically(oracle, hip_ctx, kind, variant, m
         _assert_map_equal(maps, 0, m, poses, k + 1)
         prev = (fixed, desc)
     assert m.n_points > 300
-    if kind != "stereo_ekf":
+    if kind not in ("stereo_ekf", "depth_ekf"):
         assert m.n_opt[: m.n_points].max() >= 2
 
 

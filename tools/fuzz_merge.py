@@ -34,7 +34,10 @@ def run(sequences, seed, ctx=None, verbose=True):
         kw = {"enable_binning": binning, "target_merges": int(rng.choice([5, 50, 10 ** 6])),
               "row_bins": int(rng.choice([4, 20, 47])), "col_bins": int(rng.choice([6, 60, 155])),
               "max_appearance": float(rng.choice([25.0, 50.0, 70.0]))}
-        po = oracle_merger_params(cfg, variant, tm._estimator(kind, K, (configs.baseline_pixels(cfg), 0.0)), **kw)
+        depth = variant == om.MERGER_DEPTH_EKF  # RGB-D: (u, v, depth) measurements of the ICL camera
+        fcfg = configs.get("icl") if depth else cfg
+        fK = (fcfg["camera"]["fx"], fcfg["camera"]["fy"], fcfg["camera"]["cx"], fcfg["camera"]["cy"])
+        po = oracle_merger_params(fcfg, variant, tm._estimator(kind, fK, (configs.baseline_pixels(cfg), 0.0)), **kw)
         pg = tm._gpu_params(po)
         n_frames = int(rng.integers(3, 8))
         n_kp = int(rng.choice([60, 200, 500, 900]))
@@ -45,7 +48,11 @@ def run(sequences, seed, ctx=None, verbose=True):
         tm._upload_map(maps, 0, m, poses)
         prev, ok = None, True
         for k in range(n_frames):
-            _, fixed, desc, xyz = stereo_scene(int(rng.integers(1 << 30)), n_kp=n_kp)
+            if depth:
+                fr = tm.hp.syn.rgbd_frame(np.random.default_rng(int(rng.integers(1 << 30))), fcfg, n_kp)
+                fixed, desc = fr["fixed"][:, :3].astype(np.float32), fr["desc_fixed"].copy()
+            else:
+                _, fixed, desc, xyz = stereo_scene(int(rng.integers(1 << 30)), n_kp=n_kp)
             fixed, desc = fixed[:1024], desc[:1024]
             if prev is not None:
                 reuse = int(min(len(fixed), len(prev[1])) * rng.choice([0.2, 0.5, 0.9]))
