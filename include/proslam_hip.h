@@ -314,6 +314,10 @@ typedef struct {
                                     gets PRS_ERR_CAPACITY in result[].warnings */
 } prs_align_batch;
 
+/* mode PRS_MODE_FINDER only enqueues.  mode PRS_MODE_ALIGN BLOCKS THE CALLING THREAD until the batch is done: the loop
+ * alternates a search launch and a Gauss-Newton launch over the frames that are still pending and reads one 4-byte
+ * counter back after every round (4-5 rounds at kitti.conf settings); results are complete in device memory when it
+ * returns.  A caller that must stay asynchronous runs it on its own thread (a context has a single owner). */
 PRS_API int prs_align_batch_run(prs_context* ctx,
                                 const prs_pcf_params* finder,
                                 const prs_aligner_params* aligner,
