@@ -22,6 +22,8 @@
  *     - adaptors 213 / 177 (KITTI), 321 (ICL), SceneFlow 83 points / 43 inliers, 115 / 59
  *                                      (tests/test_measurement_adaptors.cpp, tests/test_triangulators.cpp)
  *     - projective finders 319 (ICL identity, every search shape), 2, 90 (KITTI circle)   (:297-1140)
+ *     - scene clipper 49872 / 136022 / 51 / 242 / 52 visible points, depth-EKF merger 321 -> 337 points
+ *                                      (tests/test_scene_clippers.cpp:7-462, tests/test_mergers.cpp:248-355)
  *     - aligner and tracker tolerances against the ground-truth poses
  *                                      (tests/test_aligners.cpp:1035-1261, tests/test_trackers.cpp:7-470)
  *   The KD-tree finder counts (120, 21, 82, 36 -> 104, 56) are pinned as bounds only: the reference's
