@@ -182,7 +182,19 @@ __device__ __forceinline__ bool pose_is_finite(const PoseRegs& X) {
   return (s - s) == 0.0f;
 }
 // DIM: the factor type as a compile-time constant (0 = read it from the parameters)
-template <int DIM = 0>
+// inverse-depth weight of a stereo measurement (aligner_slice_processor_projective.cpp:107-112): a function of the measurement and
+// the frame's mean disparity only, so callers that iterate over fixed correspondences evaluate it once (PRE_WT: z.w carries it)
+__device__ __forceinline__ float inverse_depth_weight(const float4 z, const float mean_dsp) {
+  float wt = (z.x - z.z) / mean_dsp;
+  if (wt < 0.01f) {
+    wt = 0.01f;
+  }
+  if (wt > 1.0f) {
+    wt = 1.0f;
+  }
+  return wt;
+}
+template <int DIM = 0, bool PRE_WT = false>
 __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const PoseRegs& X, const float4 z, const float4 p_in,
                                              const float mean_dsp, const bool active, float* tv, int& cls, const bool inlier_only = false) {
   // Straight-line on purpose: with `tv` live out of nested divergent branches the compiler re-materialises
@@ -236,13 +248,7 @@ __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const 
   e2 = valid ? e2 : 0.0f;
   float wt = 1.0f;
   if (dim == PRS_FACTOR_STEREO && a.enable_inverse_depth_weighting) {
-    wt = (z.x - z.z) / mean_dsp;
-    if (wt < 0.01f) {
-      wt = 0.01f;
-    }
-    if (wt > 1.0f) {
-      wt = 1.0f;
-    }
+    wt = PRE_WT ? z.w : inverse_depth_weight(z, mean_dsp);
     wt = valid ? wt : 1.0f;
   }
   const float ax = 2.0f * px, ay = 2.0f * py, az = 2.0f * pz;
@@ -1410,6 +1416,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
     const int c = k * THREADS + tid;
     zf[k]       = c < nc ? gops[2 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
     pm[k]       = c < nc ? gops[2 * c + 1] : make_float4(0.f, 0.f, 1.f, 1.f);
+    zf[k].w     = inverse_depth_weight(zf[k], mean_dsp);  // (the factors read x, y, z of the measurement only)
   }
   __syncthreads();
 
@@ -1526,7 +1533,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(con
       if (c0 < nc && pose_ok) {
         float tv[kTerms];
         int cls;
-        factor_terms<DIM>(g.a, pose, zf[k], pm[k], mean_dsp, c0 + tid < nc, tv, cls, inlier_run);
+        factor_terms<DIM, true>(g.a, pose, zf[k], pm[k], mean_dsp, c0 + tid < nc, tv, cls, inlier_run);
         cls_bits |= (uint32_t) (cls & 3) << (2 * k);
         // inlier / outlier / invalid counts of the wave (scalar), added to the frame's counters once per iteration
         wave_inl += (int) __popcll(__ballot(cls == 0));
