@@ -499,7 +499,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_compact_kernel(const FeatureA
 
 // ---- GNU libstdc++ std::sort (bits/stl_algo.h, bits/stl_heap.h) on packed items, comparator a.response > b.response
 // (intensity_feature_extractor_binned.cpp:182-186): the response is the low byte of an item, the rest rides along.
-// One lane runs it for one region (tests compare the permutation with what g++ itself produces).
+// One wave runs it for one region (tests compare the permutation with what g++ itself produces).
 __device__ __forceinline__ bool scomp(uint32_t a, uint32_t b) {
   return (a & 0xffu) > (b & 0xffu);
 }
@@ -545,101 +545,149 @@ __device__ void std_heapsort(uint32_t* first, int len) {  // __partial_sort(firs
   }
 }
 
-__device__ __forceinline__ void std_unguarded_linear_insert(uint32_t* v, int last) {
-  const uint32_t val = v[last];
-  int next           = last - 1;
-  while (scomp(val, v[next])) {
-    v[last] = v[next];
-    last    = next;
-    --next;
-  }
-  v[last] = val;
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // LDS written by one lane is read by other lanes of the wave
+  __builtin_amdgcn_wave_barrier();
 }
 
-__device__ void std_insertion_sort(uint32_t* v, int first, int last) {
-  for (int i = first + 1; i < last; ++i) {
-    if (scomp(v[i], v[first])) {
-      const uint32_t val = v[i];
-      for (int j = i; j > first; --j) {
-        v[j] = v[j - 1];
-      }
-      v[first] = val;
+// __unguarded_partition_pivot on [first, last) (more than 16 items) by ONE WAVE, same permutation and same cut as the serial
+// loop.  The serial scan pairs the k-th "left stop" (an item that does not compare before the pivot, from the left) with the
+// k-th "right stop" (an item the pivot does not compare before, from the right) and swaps them until they cross; where a scan
+// stops only depends on values that no earlier swap of the same partition has touched, or on swapped items, which always
+// stop it.  So 64 positions from each side are classified at once (ballot), the stops are ranked into tl[] / tr[], pair j is
+// swapped by lane j, and the first pair that has crossed gives the cut; memory is re-read after every round, which makes
+// swapped items act as the sentinels they are in the serial loop.  tl, tr: 64 ints of LDS each.
+__device__ int std_partition_wave(uint32_t* v, const int first, const int last, const int lane, int* tl, int* tr) {
+  if (lane == 0) {  // __move_median_to_first(first, first + 1, mid, last - 1)
+    const int a = first + 1, b = first + (last - first) / 2, c = last - 1;
+    int pick;
+    if (scomp(v[a], v[b])) {
+      pick = scomp(v[b], v[c]) ? b : (scomp(v[a], v[c]) ? c : a);
     } else {
-      std_unguarded_linear_insert(v, i);
+      pick = scomp(v[a], v[c]) ? a : (scomp(v[b], v[c]) ? c : b);
     }
+    const uint32_t t = v[first];
+    v[first]         = v[pick];
+    v[pick]          = t;
+  }
+  wave_sync_lds();
+  const uint32_t pr              = v[first] & 0xffu;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int lo = first + 1, hi = last;
+  for (;;) {
+    const int pl  = lo + lane;
+    const int ph  = hi - 1 - lane;
+    const bool fl = pl < last && !((v[pl < last ? pl : first] & 0xffu) > pr);
+    const bool fr = ph >= first && !(pr > (v[ph >= first ? ph : first] & 0xffu));
+    const unsigned long long bl = __ballot(fl), br = __ballot(fr);
+    if (fl) {
+      tl[__popcll(bl & below)] = pl;
+    }
+    if (fr) {
+      tr[__popcll(br & below)] = ph;
+    }
+    wave_sync_lds();
+    const int nl = __popcll(bl), nr = __popcll(br);
+    const int m  = nl < nr ? nl : nr;
+    int pa = 0, pb = 0;
+    if (lane < m) {
+      pa = tl[lane];
+      pb = tr[lane];
+    }
+    const unsigned long long crossed = __ballot(lane < m && !(pa < pb));
+    const int jstar                  = crossed ? (int) __ffsll((long long) crossed) - 1 : m;
+    if (lane < jstar) {
+      const uint32_t va = v[pa], vb = v[pb];
+      v[pa]             = vb;
+      v[pb]             = va;
+    }
+    wave_sync_lds();
+    if (crossed) {
+      const int l = tl[jstar];
+      if (jstar == 0) {
+        return l;
+      }
+      const int r = tr[jstar - 1];
+      return l < r ? l : r;
+    }
+    const int lo_next = jstar > 0 ? tl[jstar - 1] + 1 : (nl == 0 ? lo + 64 : lo);
+    const int hi_next = jstar > 0 ? tr[jstar - 1] : (nr == 0 ? hi - 64 : hi);
+    lo                = lo_next;
+    hi                = hi_next;
+    wave_sync_lds();  // tl / tr are rewritten by the next round
   }
 }
 
-__device__ void std_sort_desc(uint32_t* v, int n) {
-  if (n <= 0) {
+// __final_insertion_sort restricted to a range of <= 16 items that no item enters or leaves (everything left of a partition
+// cut compares "not after" everything right of it): a stable sort by decreasing response, one lane per item
+__device__ __forceinline__ void std_leaf_sort_wave(uint32_t* v, const int first, const int last, const int lane) {
+  const int s      = last - first;
+  const uint32_t x = lane < s ? v[first + lane] : 0u;
+  const uint32_t r = x & 0xffu;
+  int rank         = 0;
+  for (int j = 0; j < s; ++j) {
+    const uint32_t rj = (uint32_t) __shfl((int) r, j) ;
+    rank += (rj > r || (rj == r && j < lane)) ? 1 : 0;
+  }
+  wave_sync_lds();
+  if (lane < s) {
+    v[first + rank] = x;
+  }
+  wave_sync_lds();
+}
+
+// One WAVE replays GNU libstdc++'s std::sort of one region: __introsort_loop with the recursion on an explicit stack (the right
+// part is pushed, the loop continues on the left; the parts are disjoint, so the order in which they are finished does not
+// change the result), every partition by the whole wave, heapsort (depth limit) on one lane, and the final insertion sort per
+// leaf.  q: 256 ints of LDS owned by this wave (tl | tr | stack).
+__device__ void std_sort_desc_wave(uint32_t* v, const int n, const int lane, int* q) {
+  if (n <= 1) {
     return;
   }
   int lg = 0;
   for (int m = n; m > 1; m >>= 1) {
     ++lg;
   }
-  // __introsort_loop with an explicit stack: the recursion takes the right part, the loop continues on the left; the
-  // parts are disjoint, so the order in which they are finished does not change the result
-  int st_first[64], st_last[64], st_depth[64];
-  int sp       = 0;
-  st_first[0]  = 0;
-  st_last[0]   = n;
-  st_depth[0]  = 2 * lg;
-  sp           = 1;
+  int* tl    = q;
+  int* tr    = q + 64;
+  int* stack = q + 128;  // (first, last, depth) triples; at most 2 lg + 1 <= 31 of them
+  int sp     = 0;
+  if (lane == 0) {
+    stack[0] = 0;
+    stack[1] = n;
+    stack[2] = 2 * lg;
+  }
+  sp = 1;
+  wave_sync_lds();
   while (sp > 0) {
     --sp;
-    const int first = st_first[sp];
-    int last = st_last[sp], depth = st_depth[sp];
+    const int first = stack[3 * sp];
+    int last = stack[3 * sp + 1], depth = stack[3 * sp + 2];
+    wave_sync_lds();
+    bool leaf = true;
     while (last - first > 16) {
       if (depth == 0) {
-        std_heapsort(v + first, last - first);
+        if (lane == 0) {
+          std_heapsort(v + first, last - first);
+        }
+        wave_sync_lds();
+        leaf = false;  // heap-sorted: the final insertion pass finds nothing to move
         break;
       }
       --depth;
-      {  // __move_median_to_first(first, first + 1, mid, last - 1)
-        const int a = first + 1, b = first + (last - first) / 2, c = last - 1;
-        int pick;
-        if (scomp(v[a], v[b])) {
-          pick = scomp(v[b], v[c]) ? b : (scomp(v[a], v[c]) ? c : a);
-        } else {
-          pick = scomp(v[a], v[c]) ? a : (scomp(v[b], v[c]) ? c : b);
-        }
-        const uint32_t t = v[first];
-        v[first]         = v[pick];
-        v[pick]          = t;
+      const int cut = std_partition_wave(v, first, last, lane, tl, tr);
+      if (lane == 0) {
+        stack[3 * sp]     = cut;
+        stack[3 * sp + 1] = last;
+        stack[3 * sp + 2] = depth;
       }
-      int lo = first + 1, hi = last;  // __unguarded_partition(first + 1, last, first)
-      const uint32_t pivot = v[first];
-      for (;;) {
-        while (scomp(v[lo], pivot)) {
-          ++lo;
-        }
-        --hi;
-        while (scomp(pivot, v[hi])) {
-          --hi;
-        }
-        if (!(lo < hi)) {
-          break;
-        }
-        const uint32_t t = v[lo];
-        v[lo]            = v[hi];
-        v[hi]            = t;
-        ++lo;
-      }
-      st_first[sp] = lo;
-      st_last[sp]  = last;
-      st_depth[sp] = depth;
       ++sp;
-      last = lo;
+      wave_sync_lds();
+      last = cut;
     }
-  }
-  if (n > 16) {  // __final_insertion_sort
-    std_insertion_sort(v, 0, 16);
-    for (int i = 16; i < n; ++i) {
-      std_unguarded_linear_insert(v, i);
+    if (leaf && last - first > 1) {
+      std_leaf_sort_wave(v, first, last, lane);
     }
-  } else {
-    std_insertion_sort(v, 0, n);
   }
 }
 
@@ -723,10 +771,11 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const Feat
       __syncthreads();
     }
   }
-  if (std_order) {  // one lane per region runs the reference's std::sort on the region's keypoints (wave-uniform branch)
+  if (std_order) {  // one wave per region replays the reference's std::sort on the region's keypoints (wave-uniform branch)
+    int* q = reinterpret_cast<int*>(patch + wave * kMaxCells);  // (the descriptor phase's staging area is not in use yet)
     for (int g = wave; g < a.regions; g += kSelThreads / 64) {
-      if (lane == 0 && count[g] >= (uint32_t) a.target_per) {
-        std_sort_desc(keys + start[g], (int) count[g]);
+      if (count[g] >= (uint32_t) a.target_per) {
+        std_sort_desc_wave(keys + start[g], (int) count[g], lane, q);
       }
     }
     __syncthreads();

@@ -27,15 +27,17 @@ def _run(hip_ctx, params, images, stride):
     return kp.cpu().numpy(), desc.cpu().numpy(), inten.cpu().numpy(), n.cpu().numpy(), st.cpu().numpy()
 
 
-@pytest.mark.parametrize("threshold,nms,target,grid", [(15, 1, 1000, (3, 3)), (25, 1, 300, (2, 5)), (60, 1, 2000, (1, 1)), (40, 1, 10 ** 6, (4, 4))])
-def test_extractor_parity_on_synthetic_stereo_images(oracle, hip_ctx, threshold, nms, target, grid):
+@pytest.mark.parametrize("order", ["canonical", "libstdcxx"])
+@pytest.mark.parametrize("threshold,nms,target,grid", [(15, 1, 1000, (3, 3)), (25, 1, 300, (2, 5)), (60, 1, 2000, (1, 1)), (40, 1, 10 ** 6, (4, 4)), (8, 1, 400, (1, 1))])
+def test_extractor_parity_on_synthetic_stereo_images(oracle, hip_ctx, threshold, nms, target, grid, order):
     cfg = configs.get("kitti")
     images = []
     for seed in (11, 12):
         l, r, _ = syn.stereo_images(np.random.default_rng(seed), cfg)
         images += [l, r]
-    po = of.extractor_params(threshold, nms, target, grid[0], grid[1])
-    pg = ops.extractor_params(threshold, nms, target, grid[0], grid[1])
+    std = order == "libstdcxx"  # the reference's std::sort tie order (one wave per region replays introsort)
+    po = of.extractor_params(threshold, nms, target, grid[0], grid[1], of.SELECT_LIBSTDCXX if std else of.SELECT_CANONICAL)
+    pg = ops.extractor_params(threshold, nms, target, grid[0], grid[1], ops.SELECT_LIBSTDCXX if std else ops.SELECT_CANONICAL, 32768)
     stride = 8192
     kp, desc, inten, n, st = _run(hip_ctx, pg, images, stride)
     for b, img in enumerate(images):

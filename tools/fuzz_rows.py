@@ -92,8 +92,10 @@ def fuzz_features(cases, rng, ctx):
         target = int(rng.choice([50, 300, 1000, 10 ** 6]))
         grid = (int(rng.integers(1, 5)), int(rng.integers(1, 6)))
         stride = 8192
-        po = of.extractor_params(threshold, nms, target, grid[0], grid[1])
-        pg = ops.extractor_params(threshold, nms, target, grid[0], grid[1])
+        std = int(rng.random() < 0.5)  # selection in the reference's std::sort order (wave-cooperative introsort replay on the device)
+        raw_cap = int(rng.choice([0, 0, 16384, 32768]))
+        po = of.extractor_params(threshold, nms, target, grid[0], grid[1], of.SELECT_LIBSTDCXX if std else of.SELECT_CANONICAL)
+        pg = ops.extractor_params(threshold, nms, target, grid[0], grid[1], ops.SELECT_LIBSTDCXX if std else ops.SELECT_CANONICAL, raw_cap)
         try:
             uv, oi, od = of.extract_features(po, img, capacity=1 << 20)
         except RuntimeError:
@@ -117,7 +119,7 @@ def fuzz_features(cases, rng, ctx):
               and np.array_equal(inten[0, :ng].cpu().numpy(), oi))
         if not ok:
             bad += 1
-            print("FEATURES MISMATCH case %d %dx%d pitch %d threshold %d nms %d target %d grid %s: %d vs %d" % (c, rows, cols, cols + pad, threshold, nms, target, grid, len(uv), ng))
+            print("FEATURES MISMATCH case %d %dx%d pitch %d threshold %d nms %d target %d grid %s std %d raw_cap %d: %d vs %d" % (c, rows, cols, cols + pad, threshold, nms, target, grid, std, raw_cap, len(uv), ng))
     return bad, total
 
 
