@@ -1335,8 +1335,8 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
 // Instantiated for 128 threads x {4, 6, 7, 8} correspondences per thread (the default) and 256 x {2, 3, 4}.
 // The row stride of the term matrix is THREADS + 4 floats, so that the 29 summing lanes (one row each,
 // 16-B reads) start 16 B apart in the bank space instead of all on the same four banks.
-constexpr int kGnThreads = 256;
-constexpr int kGnSlots   = 4;  // max_fixed <= 1024 either way
+constexpr int kGnThreads = 128;  // two waves per frame
+constexpr int kGnSlots   = 8;    // the split pipeline serves max_fixed <= 1024
 
 struct GnShared {
   float X[16], T[16], Tprev[16], H[36], b[6];
@@ -1351,7 +1351,7 @@ struct GnShared {
 
 // THREADS per frame; SLOTS = correspondences per thread the instantiation keeps in registers (ceil(max_fixed / THREADS))
 template <int THREADS, int SLOTS, int DIM = 0>
-__global__ __launch_bounds__(THREADS, THREADS == 128 ? 4 : 5) void gn_kernel(const AlignArgs g) {
+__global__ __launch_bounds__(THREADS, 4) void gn_kernel(const AlignArgs g) {
   constexpr int kRow = THREADS + 4;  // row stride of the term matrix (see kGnRow)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid   = threadIdx.x;
@@ -1910,9 +1910,8 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
                         : (finder->search_type == PRS_SEARCH_RHOMBUS ? align_kernel<kSearchThreads, true, PRS_SEARCH_RHOMBUS>
                                                                      : align_kernel<kSearchThreads, true, PRS_SEARCH_KDTREE>));
   // two waves per frame (eight frames resident per CU: the kernel is bound by its single-wave phases and by
-  // instruction issue, more independent frames fill the idle slots); PRS_GN_THREADS=256 selects the four-wave form
-  const int gn_threads = (max_fixed <= 128 * 8 && !ctx->gn_four_waves) ? 128 : kGnThreads;
-  const size_t lds_gn  = (size_t) kTerms * (gn_threads + 4) * sizeof(float) + sizeof(GnShared) + 16;
+  // instruction issue, more independent frames fill the idle slots)
+  const size_t lds_gn  = (size_t) kTerms * (kGnThreads + 4) * sizeof(float) + sizeof(GnShared) + 16;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(skernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_search);
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_align_batch_run attribute");
@@ -1955,7 +1954,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
       if (stamps_split) {
         ctx_report_stamps(ctx, batch->batch, 10, "search launch (split): - | - | - | - || lattice build | projection+search | second-best pass | filter | commit");
       }
-      if (gn_threads == 128) {
+      {
         // (the rectified-stereo factor, the one kitti.conf / euroc.conf use, has its own instantiations: the factor
         // type as a compile-time constant removes ~10 selects per linearised correspondence)
         const bool stereo = aligner->factor_type == PRS_FACTOR_STEREO;
@@ -1975,12 +1974,6 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
         } else {
           launch_gn(gn_kernel<128, 8>, gn_kernel<128, 8, PRS_FACTOR_STEREO>);
         }
-      } else if (max_fixed <= 2 * kGnThreads) {
-        hipLaunchKernelGGL((gn_kernel<kGnThreads, 2>), dim3(batch->batch), dim3(kGnThreads), lds_gn, stream, g);
-      } else if (max_fixed <= 3 * kGnThreads) {
-        hipLaunchKernelGGL((gn_kernel<kGnThreads, 3>), dim3(batch->batch), dim3(kGnThreads), lds_gn, stream, g);
-      } else {
-        hipLaunchKernelGGL((gn_kernel<kGnThreads, 4>), dim3(batch->batch), dim3(kGnThreads), lds_gn, stream, g);
       }
       tick();
       ++total;

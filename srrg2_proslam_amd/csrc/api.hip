@@ -201,8 +201,6 @@ int prs_context_create(int device_id, prs_context** out) {
   ctx->stamps_split    = ssplit && ssplit[0] == '1';
   const char* mfused   = getenv("PRS_MERGE_FUSED");
   ctx->merge_fused     = mfused && mfused[0] == '1';
-  const char* gnt      = getenv("PRS_GN_THREADS");
-  ctx->gn_four_waves   = gnt && atoi(gnt) == 256;
   *out                 = ctx;
   return PRS_OK;
 }

@@ -16,7 +16,6 @@ struct prs_context {
   bool fused_align      = false;    // PRS_FUSED_ALIGN=1: one fused kernel per frame loop instead of the split search/GN pipeline
   bool matcher_v3       = false;    // PRS_MATCHER_V3=1: always use the first-generation matcher kernel
   bool force_unstaged   = false;    // test hook: PRS_FORCE_UNSTAGED=1 selects the no-LDS-staging variant
-  bool gn_four_waves    = false;    // PRS_GN_THREADS=256: Gauss-Newton kernel with four waves per frame instead of two
   bool merge_fused      = false;    // PRS_MERGE_FUSED=1: pose-based smoother merger as one kernel instead of front | smoother | back
   bool stamps_split     = false;    // PRS_STAMPS_SPLIT=1 (with PRS_STAMPS=1): phase stamps of the split search kernel
   // reusable device scratch for the host-pointer entry points
