@@ -643,6 +643,23 @@ typedef struct {
 
 PRS_API int prs_extract_features_batch(prs_context* ctx, const prs_extractor_params* params, const prs_extract_batch* batch);
 
+/* host pointers, one image: what an adapter's IntensityFeatureExtractorBase_::compute(const cv::Mat&) binds
+ * (intensity_feature_extractor_binned.cpp:47-196): uploads the image, runs the three kernels, downloads the features,
+ * synchronises.  image: rows x cols 8-bit pixels, `pitch` bytes between rows; keypoints [capacity][2] (u, v) floats,
+ * intensity [capacity] or NULL, descriptors [capacity][32]; *n_features = features written.  More features than
+ * `capacity` or more raw detections than max_raw_detections: PRS_ERR_CAPACITY (nothing is returned). */
+PRS_API int prs_extract_features(prs_context* ctx,
+                                 const prs_extractor_params* params,
+                                 const uint8_t* image,
+                                 int32_t rows,
+                                 int32_t cols,
+                                 int32_t pitch,
+                                 float* keypoints,
+                                 float* intensity,
+                                 uint8_t* descriptors,
+                                 int32_t capacity,
+                                 int32_t* n_features);
+
 #ifdef __cplusplus
 }
 #endif

@@ -654,4 +654,53 @@ protected:
   Status _status = Error;
 };
 
+// IntensityFeatureExtractorBinned_ (sensor_processing/feature_extractors/intensity_feature_extractor_binned.{h,cpp},
+// base class intensity_feature_extractor_base.h): same PARAM names, setFeatures() / compute(image); the image is a plain
+// 8-bit buffer here where the reference takes a cv::Mat.  Features are (u, v) points with intensity and a 256-bit descriptor.
+class IntensityFeatureExtractorBinnedHIP {
+public:
+  using PointCloudType = PointIntensityDescriptorVectorCloud<2>;
+  explicit IntensityFeatureExtractorBinnedHIP(ContextPtr ctx) : _ctx(std::move(ctx)) {}
+  PropertyFloat param_detector_threshold{10.f};                  // intensity_feature_extractor_base.h:36-40
+  PropertyBool param_enable_non_maximum_suppression{true};       // :48-52
+  Property_<int> param_target_number_of_keypoints{500};          // :54-58
+  PropertyUnsignedInt param_number_of_detectors_vertical{1};     // intensity_feature_extractor_binned.h:17-22
+  PropertyUnsignedInt param_number_of_detectors_horizontal{1};   // :23-28
+  // which members of a response class survive the per-region cut: the reference's std::sort order (GCC) by default
+  Property_<int> param_selection_order{PRS_SELECT_LIBSTDCXX};
+  void setFeatures(PointCloudType* features_) { _features = features_; }
+  void compute(const uint8_t* image, int rows, int cols, int pitch) {
+    if (!image || rows <= 0 || cols <= 0) throw std::runtime_error("IntensityFeatureExtractor::compute|ERROR: image not set");
+    if (!_features) throw std::runtime_error("IntensityFeatureExtractor::compute|ERROR: target feature buffer not set");
+    prs_extractor_params p;
+    p.detector_threshold             = (int32_t) param_detector_threshold.value();
+    p.enable_non_maximum_suppression = param_enable_non_maximum_suppression.value() ? 1 : 0;
+    p.target_number_of_keypoints     = param_target_number_of_keypoints.value();
+    p.number_of_detectors_vertical   = (int32_t) param_number_of_detectors_vertical.value();
+    p.number_of_detectors_horizontal = (int32_t) param_number_of_detectors_horizontal.value();
+    p.selection_order                = param_selection_order.value();
+    p.max_raw_detections             = 32768;
+    const int32_t capacity = 8192;
+    std::vector<float> kp(2 * (size_t) capacity), inten((size_t) capacity);
+    std::vector<uint8_t> desc(PRS_DESC_BYTES * (size_t) capacity);
+    int32_t n    = 0;
+    const int rc = prs_extract_features(_ctx->get(), &p, image, rows, cols, pitch, kp.data(), inten.data(), desc.data(), capacity, &n);
+    if (rc < 0) throw std::runtime_error(std::string("IntensityFeatureExtractorBinnedHIP::compute|ERROR: ") + prs_last_error(_ctx->get()));
+    _features->clear();
+    _features->reserve((size_t) n);
+    for (int32_t i = 0; i < n; ++i) {
+      PointIntensityDescriptor_<2> q;
+      q.coords[0] = kp[2 * (size_t) i];
+      q.coords[1] = kp[2 * (size_t) i + 1];
+      q.intensity_value = inten[(size_t) i];
+      std::memcpy(q.descriptor_row, &desc[PRS_DESC_BYTES * (size_t) i], PRS_DESC_BYTES);
+      _features->push_back(q);
+    }
+  }
+
+protected:
+  ContextPtr _ctx;
+  PointCloudType* _features = nullptr;
+};
+
 }  // namespace proslam_hip

@@ -696,4 +696,86 @@ int prs_extract_features_batch(prs_context* ctx, const prs_extractor_params* par
   return extract_features_launch(ctx, params, batch);
 }
 
+int prs_extract_features(prs_context* ctx,
+                         const prs_extractor_params* params,
+                         const uint8_t* image,
+                         int32_t rows,
+                         int32_t cols,
+                         int32_t pitch,
+                         float* keypoints,
+                         float* intensity,
+                         uint8_t* descriptors,
+                         int32_t capacity,
+                         int32_t* n_features) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  if (!params || !image) {
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_extract_features: image not set");
+  }
+  if (!keypoints || !descriptors || !n_features) {
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_extract_features: target feature buffer not set");
+  }
+  if (rows <= 0 || cols <= 0 || pitch < cols || capacity <= 0) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_extract_features: invalid image size, pitch or capacity");
+  }
+  (void) hipSetDevice(ctx->device);
+  const size_t cap    = (size_t) capacity;
+  const size_t b_img  = align256((size_t) rows * (size_t) pitch);
+  const size_t b_kp   = align256(cap * sizeof(prs_kp2));
+  const size_t b_int  = align256(cap * sizeof(float));
+  const size_t b_desc = align256(cap * PRS_DESC_BYTES);
+  const size_t b_small = 256;
+  const size_t total   = b_img + b_small + b_kp + b_int + b_desc;
+  unsigned char* d     = static_cast<unsigned char*>(ctx_device_scratch(ctx, total));
+  unsigned char* h     = static_cast<unsigned char*>(ctx_pinned_scratch(ctx, total));
+  if (!d || !h) {
+    return ctx_fail(ctx, PRS_ERR_HIP, "prs_extract_features: scratch allocation failed");
+  }
+  // staging layout (same on both sides): image | n_features, status | keypoints | intensity | descriptors
+  const size_t o_small = b_img, o_kp = o_small + b_small, o_int = o_kp + b_kp, o_desc = o_int + b_int;
+  memcpy(h, image, (size_t) rows * (size_t) pitch);
+  hipStream_t s = ctx->stream;
+  hipError_t e  = hipMemcpyAsync(d, h, (size_t) rows * (size_t) pitch, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_extract_features upload");
+  }
+  prs_extract_batch b;
+  b.batch       = 1;
+  b.rows        = rows;
+  b.cols        = cols;
+  b.pitch       = pitch;
+  b.images      = d;
+  b.stride      = capacity;
+  b.keypoints   = reinterpret_cast<prs_kp2*>(d + o_kp);
+  b.intensity   = reinterpret_cast<float*>(d + o_int);
+  b.descriptors = d + o_desc;
+  b.n_features  = reinterpret_cast<int32_t*>(d + o_small);
+  b.status      = reinterpret_cast<int32_t*>(d + o_small + 4);
+  const int rc  = extract_features_launch(ctx, params, &b);
+  if (rc != PRS_OK) {
+    return rc;
+  }
+  e = hipMemcpyAsync(h + o_small, d + o_small, total - o_small, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) {
+    e = hipStreamSynchronize(s);
+  }
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_extract_features download");
+  }
+  const int32_t* hs = reinterpret_cast<const int32_t*>(h + o_small);
+  const int32_t n = hs[0], status = hs[1];
+  if (status < 0) {
+    *n_features = 0;
+    return ctx_fail(ctx, status, "prs_extract_features: more raw detections or features than the buffers hold");
+  }
+  memcpy(keypoints, h + o_kp, (size_t) n * sizeof(prs_kp2));
+  if (intensity) {
+    memcpy(intensity, h + o_int, (size_t) n * sizeof(float));
+  }
+  memcpy(descriptors, h + o_desc, (size_t) n * PRS_DESC_BYTES);
+  *n_features = n;
+  return status;
+}
+
 }  // extern "C"

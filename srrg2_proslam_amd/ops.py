@@ -728,6 +728,20 @@ def extractor_params(threshold=15, nms=1, target=1000, vertical=3, horizontal=3,
     return _lib.ExtractorParams(threshold, nms, target, vertical, horizontal, selection_order, max_raw_detections)
 
 
+def extract_features(ctx, params, image, capacity=4096):
+    """host arrays, one 8-bit image [rows, cols] -> (uv [n, 2] f32, intensity [n] f32, descriptors [n, 32] u8); synchronises"""
+    img = np.ascontiguousarray(image, dtype=np.uint8)
+    rows, cols = img.shape
+    uv = np.zeros((capacity, 2), dtype=np.float32)
+    inten = np.zeros(capacity, dtype=np.float32)
+    desc = np.zeros((capacity, 32), dtype=np.uint8)
+    n = C.c_int32(0)
+    rc = _lib.load().prs_extract_features(ctx._h, C.byref(params), _p(img), rows, cols, cols, _p(uv), _p(inten), _p(desc), capacity, C.byref(n))
+    _check(ctx, rc, "prs_extract_features")
+    k = n.value
+    return uv[:k].copy(), inten[:k].copy(), desc[:k].copy()
+
+
 def extract_features_batch(ctx, params, images, keypoints, descriptors, n_features, status, intensity=None):
     """images: uint8 device tensor [B, rows, cols(pitch)]; outputs are device tensors laid out like the stereo
     matcher's inputs (keypoints [B, stride, 2] f32, descriptors [B, stride, 32] u8, n_features [B] i32)."""

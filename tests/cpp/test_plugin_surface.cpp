@@ -338,6 +338,68 @@ static void test_Bruteforce_CloudVersusItself(ContextPtr ctx) {
   ASSERT_EQ(correspondences.size(), (size_t) 3);
 }
 
+// KITTI 00_FAST_ORB256 / IntensityFeatureExtractorBinned (tests/test_feature_extractors.cpp:7-262) shape on a synthetic image: features
+// come back inside the descriptor border, strongest first per region, and the extractor's output feeds the epipolar finder
+static void test_IntensityFeatureExtractorBinned(ContextPtr ctx) {
+  const int rows = 376, cols = 1241;
+  std::vector<uint8_t> image((size_t) rows * cols);
+  for (int r = 0; r < rows; ++r) {
+    for (int c = 0; c < cols; ++c) {
+      // blocks of random brightness (corners of every strength) + a small per-pixel pattern: on perfectly flat blocks the
+      // corner responses form plateaus and the strict non-maximum suppression leaves nothing
+      std::mt19937 cell((uint32_t) ((r / 12) * 977 + (c / 12)));
+      const int v = (int) (cell() & 0xff) + ((r * 7919 + c * 104729 + (r * c) % 31) % 13) - 6;
+      image[(size_t) r * cols + c] = (uint8_t) (v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+  }
+  IntensityFeatureExtractorBinnedHIP extractor(ctx);
+  bool thrown = false;
+  try {
+    extractor.compute(image.data(), rows, cols, cols);  // target feature buffer not set
+  } catch (const std::runtime_error&) {
+    thrown = true;
+  }
+  ASSERT_TRUE(thrown);
+  IntensityFeatureExtractorBinnedHIP::PointCloudType features, again;
+  extractor.param_detector_threshold.setValue(15);
+  extractor.param_target_number_of_keypoints.setValue(500);
+  extractor.param_number_of_detectors_vertical.setValue(3);
+  extractor.param_number_of_detectors_horizontal.setValue(3);
+  extractor.setFeatures(&features);
+  extractor.compute(image.data(), rows, cols, cols);
+  ASSERT_TRUE(features.size() > 200 && features.size() <= 500);
+  for (const auto& p : features) {
+    ASSERT_TRUE(p.coords[0] >= 31 && p.coords[0] < cols - 31 && p.coords[1] >= 31 && p.coords[1] < rows - 31);  // cv::ORB border
+    ASSERT_EQ(p.intensity_value, (float) image[(size_t) p.coords[1] * cols + (size_t) p.coords[0]]);
+  }
+  extractor.setFeatures(&again);
+  extractor.compute(image.data(), rows, cols, cols);  // deterministic
+  ASSERT_EQ(again.size(), features.size());
+  // the features of an image against themselves through the epipolar finder: mirror matches (test_correspondence_finders.cpp:152-181)
+  PointIntensityDescriptorVectorCloud<3> cloud(features.size());
+  for (size_t i = 0; i < features.size(); ++i) {
+    ASSERT_TRUE(std::memcmp(again[i].descriptor_row, features[i].descriptor_row, PRS_DESC_BYTES) == 0 && again[i].coords[0] == features[i].coords[0]);
+    cloud[i].coords[0] = features[i].coords[0];
+    cloud[i].coords[1] = features[i].coords[1];
+    cloud[i].coords[2] = 0;
+    std::memcpy(cloud[i].descriptor_row, features[i].descriptor_row, PRS_DESC_BYTES);
+  }
+  CorrespondenceFinderDescriptorBasedEpipolarHIP3D3D finder(ctx);
+  finder.param_maximum_descriptor_distance.setValue(50);
+  finder.param_maximum_distance_ratio_to_second_best.setValue(0.8f);
+  finder.param_image_rows.setValue(rows);
+  CorrespondenceVector correspondences;
+  finder.setFixed(&cloud);
+  finder.setMoving(&cloud);
+  finder.setCorrespondences(&correspondences);
+  finder.compute();
+  ASSERT_EQ(correspondences.size(), cloud.size());
+  for (const Correspondence& c : correspondences) {
+    ASSERT_EQ(c.fixed_idx, c.moving_idx);
+    ASSERT_EQ(c.response, 0.0f);
+  }
+}
+
 int main() {
   ContextPtr ctx;
   try {
@@ -360,6 +422,7 @@ int main() {
   RUN(test_TriangulatorRigidStereo);
   RUN(test_SceneClipperProjective3D);
   RUN(test_Bruteforce_CloudVersusItself);
+  RUN(test_IntensityFeatureExtractorBinned);
   std::printf("%d failure(s)\n", g_failures);
   return g_failures ? 1 : 0;
 }

@@ -94,3 +94,19 @@ def test_images_to_matches_on_device(oracle, hip_ctx):
         ref, _ = oracle.stereo_match(uvl, dl, uvr, dr, oracle_stereo_params(oracle, cfg["stereo_matcher"]))
         assert len(ref) > 200
         assert corr_equal(ref, sf.matches_of(b)), b
+
+
+def test_host_pointer_entry_point_on_a_reference_image(oracle, hip_ctx):
+    """prs_extract_features (one image, host buffers: what an adapter's compute(image) binds) = the oracle on KITTI frame 00,
+    in the reference's selection order; a capacity below the result is a loud error"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_kitti.npz"))
+    img = z["city_left"][0]
+    pg = ops.extractor_params(5, 1, 500, 3, 3, ops.SELECT_LIBSTDCXX, 32768)
+    uv, inten, desc = ops.extract_features(hip_ctx, pg, img)
+    ouv, ointen, odesc = of.extract_features(of.extractor_params(5, 1, 500, 3, 3, of.SELECT_LIBSTDCXX), img)
+    assert len(uv) == 446  # tests/test_feature_extractors.cpp / fixtures.hpp: 446 features on the left image
+    assert np.array_equal(uv, ouv) and np.array_equal(inten, ointen) and np.array_equal(desc, odesc)
+    with pytest.raises(ops.ProslamHipError) as ei:
+        ops.extract_features(hip_ctx, pg, img, capacity=100)
+    assert ei.value.status == ops._lib.ERR_CAPACITY
