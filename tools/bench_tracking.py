@@ -162,7 +162,7 @@ def unroll(local_poses, splits):
     return out
 
 
-def run(batch=4096, frames=60, unique=4, keypoints=2000, cap=6144, check=1, prior_info=1.0, trajectory=""):
+def run(batch=4096, frames=60, unique=4, keypoints=2000, cap=6144, check=1, prior_info=1.0, trajectory="", max_fixed=1024):
     import torch
     from bench_merge import merger_params
     from srrg2_proslam_amd import configs, ops, synthetic as syn
@@ -194,7 +194,7 @@ def run(batch=4096, frames=60, unique=4, keypoints=2000, cap=6144, check=1, prio
     af = ops.AlignFrames(0, B, N, cap)
     af.fixed, af.fixed_desc, af.n_fixed = sf.fixed_uvuv, sf.fixed_desc, sf.n_fixed
     af.moving, af.moving_desc, af.n_moving = clip.clipped_xyzw, clip.clipped_desc, clip.n_clipped
-    af.max_fixed = 1024  # stereo matches per frame the split aligner pipeline is sized for; more is a loud per-frame error
+    af.max_fixed = max_fixed  # stereo matches per frame the aligner is sized for (<= 1024: search / GN pipeline); more is a loud per-frame error
     maps.corr, maps.corr_from_aligner, maps.scene_index_map = af.corr, 1, clip.global_indices
     zero_corr = torch.zeros((B,), dtype=torch.int32, device=dev)
     eye = torch.eye(4, dtype=torch.float32, device=dev).repeat(B, 1, 1).contiguous()
@@ -333,8 +333,9 @@ def main():
     ap.add_argument("--prior", type=float, default=1.0, help="information of the motion-model prior slice (0 = off)")
     ap.add_argument("--trajectory", default="", help="write sequence 0's estimated trajectory as <prefix>_kitti.txt and <prefix>_tum.txt "
                     "(the reference benchmark's formats, apps/app_benchmark.cpp:205-259; 10 Hz timestamps)")
+    ap.add_argument("--max-fixed", type=int, default=1024, help="bound on the stereo matches per frame (above 1024 the one-kernel aligner runs)")
     args = ap.parse_args()
-    print(json.dumps(run(args.batch, args.frames, args.unique, args.keypoints, args.cap, args.check, args.prior, args.trajectory)))
+    print(json.dumps(run(args.batch, args.frames, args.unique, args.keypoints, args.cap, args.check, args.prior, args.trajectory, args.max_fixed)))
 
 
 if __name__ == "__main__":
