@@ -577,6 +577,59 @@ typedef struct {
 
 PRS_API int prs_merge_batch_run(prs_context* ctx, const prs_merger_params* params, const prs_merge_batch* batch);
 
+/* ---- host, one local map: stateful handle mirroring the reference's merger object ---------------------------------
+ * setScene / setMeasurement / setCorrespondences / setMeasurementInScene / setMeasurementInWorld / compute
+ * (mapping/mergers/merger_projective.h, tests/test_mergers.cpp:248-780).  The map lives on the device in the layout of
+ * prs_merge_batch; every merge uploads the frame, runs the merge kernel(s) with batch = 1 and synchronises. */
+typedef struct prs_map prs_map;
+/* capacity: landmarks; max_measurements: history slots per landmark (0 = none; the pose-based smoother needs them);
+ * max_frames: frames merged between two prs_map_clear calls (rows of the pose table); max_measured: measurements and
+ * correspondences per frame */
+PRS_API int prs_map_create(prs_context* ctx, int32_t capacity, int32_t max_measurements, int32_t max_frames, int32_t max_measured, prs_map** out);
+PRS_API int prs_map_destroy(prs_map* h);
+PRS_API int prs_map_clear(prs_map* h); /* a new local map: no landmarks, frame counter 0 */
+PRS_API int prs_map_size(prs_map* h, int32_t* n_points, int32_t* frames_merged /* may be NULL */);
+/* setScene with allocated statistics: coords_in_scene [n][3]; state_in_world [n][3] or NULL (= the coordinates,
+ * tests/test_mergers.cpp:268-271); covariance [n][9] or NULL (identity); desc [n][32]; n_opt [n] or NULL (0);
+ * first_measurement [n] or NULL: the camera measurement the landmark was created from (its .frame names a pose-table row set
+ * with prs_map_set_frame_pose; tests/test_mergers.cpp:425-433) */
+PRS_API int prs_map_set_scene(prs_map* h,
+                              const float* coords_in_scene,
+                              const float* state_in_world,
+                              const float* covariance,
+                              const uint8_t* desc,
+                              const uint32_t* n_opt,
+                              const prs_camera_measurement* first_measurement,
+                              int32_t n);
+/* pose of an earlier frame the scene's measurements refer to; frames merged afterwards continue behind the highest row set */
+PRS_API int prs_map_set_frame_pose(prs_map* h, int32_t frame, const float* sensor_in_world16);
+/* MergerProjective_::compute for one frame.  measurement: [n_measured][estimator.measurement_dim] image-space points;
+ * corr: fixed_idx -> scene, moving_idx -> measurement (corr_from_aligner = 0) or the aligner's vector (= 1, with
+ * scene_index_map = the clipper's global indices, or NULL when the aligner ran on the whole scene).  Returns the warning
+ * bits of result->status (>= 0) or a PRS_ERR_* code. */
+PRS_API int prs_map_merge(prs_map* h,
+                          const prs_merger_params* params,
+                          const float* measurement_in_world16,
+                          const float* measurement_in_scene16,
+                          const float* measurement,
+                          const uint8_t* measurement_desc,
+                          int32_t n_measured,
+                          const prs_corr* corr,
+                          int32_t n_corr,
+                          const int32_t* scene_index_map,
+                          int32_t corr_from_aligner,
+                          prs_merge_result* result);
+/* the scene after merging; any output may be NULL: coords_in_scene / state_in_world [capacity][3], desc [capacity][32],
+ * n_opt / inlier [capacity] */
+PRS_API int prs_map_get_scene(prs_map* h,
+                              int32_t capacity,
+                              float* coords_in_scene,
+                              float* state_in_world,
+                              uint8_t* desc,
+                              uint32_t* n_opt,
+                              uint8_t* inlier,
+                              int32_t* n_points);
+
 /* pose bookkeeping between the aligner and the merger / next clip, on the device:
  * pose_out[b] = prediction[b] * X[b]^-1.  The clipper expresses the local map in the predicted sensor
  * frame (scene_clipper_projective_3d.cpp:46-53), so the aligner's estimate X (moving in fixed) is the

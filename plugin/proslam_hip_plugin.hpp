@@ -703,4 +703,143 @@ protected:
   PointCloudType* _features = nullptr;
 };
 
+// MergerRigidStereoTriangulation with LandmarkEstimatorWeightedMean4D3D (mapping/mergers/merger_rigid_stereo_triangulation.h,
+// merger_projective.h, landmarks/landmark_estimator_weighted_mean.h): same setters and PARAM names; the scene is mirrored into a
+// device-resident map (prs_map) on setScene and read back after compute(), so a caller sees its scene cloud updated in place like
+// with the reference object.  Other variants / estimators only differ in the prs_merger_params they fill.
+class MergerRigidStereoTriangulationHIP {
+public:
+  using SceneType       = PointIntensityDescriptorVectorCloud<3>;
+  using MeasurementType = PointIntensityDescriptorVectorCloud<4>;
+  explicit MergerRigidStereoTriangulationHIP(ContextPtr ctx) : param_projector(new ProjectorPinholeHIP()), _ctx(std::move(ctx)) {
+    const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::memcpy(_measurement_in_scene, I, sizeof(I));
+    std::memcpy(_measurement_in_world, I, sizeof(I));
+  }
+  ~MergerRigidStereoTriangulationHIP() {
+    if (_map) prs_map_destroy(_map);
+  }
+  PropertyFloat param_maximum_distance_appearance{50.f};       // merger_projective.h:42-46
+  PropertyUnsignedInt param_number_of_row_bins{10};            // :47-51
+  PropertyUnsignedInt param_number_of_col_bins{30};            // :52-56
+  PropertyFloat param_target_merge_ratio{0.5f};                // :57-61
+  PropertyBool param_enable_binning{true};
+  PropertyUnsignedInt param_target_number_of_merges{100};
+  PropertyFloat param_maximum_distance_geometry_meters_squared{1.f};  // landmark_estimator_base.hpp:20-25 (of the landmark estimator)
+  PropertyFloat param_minimum_disparity_pixels{1.f};           // triangulator_rigid_stereo.h:34-38 (of the triangulator)
+  ProjectorPinholeHIPPtr param_projector;
+  void setBaselineRightInLeftPixels(float bx) { _baseline_px = bx; }
+  void setScene(SceneType* scene_) {
+    _scene         = scene_;
+    _scene_changed = true;
+  }
+  void setMeasurement(const MeasurementType* measurement_) { _measurement = measurement_; }
+  void setCorrespondences(const CorrespondenceVector* correspondences_) { _correspondences = correspondences_; }
+  void setMeasurementInScene(const float* T16) { std::memcpy(_measurement_in_scene, T16, sizeof(_measurement_in_scene)); }
+  void setMeasurementInWorld(const float* T16) { std::memcpy(_measurement_in_world, T16, sizeof(_measurement_in_world)); }
+  size_t numberOfMergedPoints() const { return _n_merged; }
+  size_t numberOfAddedPoints() const { return _n_added; }
+  void compute() {
+    // merger_projective_impl.cpp:12-27
+    if (!_scene) throw std::runtime_error("MergerProjective::compute|ERROR: scene not set");
+    if (!_measurement) throw std::runtime_error("MergerProjective::compute|ERROR: measurement not set");
+    if (!_correspondences) throw std::runtime_error("MergerProjective::compute|ERROR: correspondences not set");
+    if (!param_projector) throw std::runtime_error("MergerProjective::compute|ERROR: projector not set");
+    const int32_t capacity = (int32_t) (_scene->size() + _measurement->size() + 1024);
+    if (!_map || capacity > _capacity) {
+      if (_map) prs_map_destroy(_map);
+      _map           = nullptr;
+      _capacity      = 2 * capacity;
+      const int rc   = prs_map_create(_ctx->get(), _capacity, 0, 4096, 8192, &_map);
+      if (rc != PRS_OK) throw std::runtime_error(std::string("MergerRigidStereoTriangulationHIP|ERROR: ") + prs_last_error(_ctx->get()));
+      _scene_changed = true;
+    }
+    if (_scene_changed) {  // upload the scene once; afterwards the device copy is the master
+      const size_t n = _scene->size();
+      std::vector<float> xyz(3 * n);
+      std::vector<uint8_t> desc(PRS_DESC_BYTES * n);
+      std::vector<uint32_t> nopt(n);
+      for (size_t i = 0; i < n; ++i) {
+        std::memcpy(&xyz[3 * i], (*_scene)[i].coords, sizeof(float) * 3);
+        std::memcpy(&desc[PRS_DESC_BYTES * i], (*_scene)[i].descriptor_row, PRS_DESC_BYTES);
+        nopt[i] = (*_scene)[i].number_of_optimizations;
+      }
+      prs_map_clear(_map);
+      if (prs_map_set_scene(_map, xyz.data(), nullptr, nullptr, desc.data(), nopt.data(), nullptr, (int32_t) n) != PRS_OK) {
+        throw std::runtime_error(std::string("MergerRigidStereoTriangulationHIP|ERROR: ") + prs_last_error(_ctx->get()));
+      }
+      _scene_changed = false;
+    }
+    prs_merger_params p;
+    std::memset(&p, 0, sizeof(p));
+    const float* K = param_projector->camera_matrix;
+    p.variant                     = PRS_MERGER_STEREO_TRIANGULATION;
+    p.enable_binning              = param_enable_binning.value() ? 1 : 0;
+    p.number_of_row_bins          = (uint32_t) param_number_of_row_bins.value();
+    p.number_of_col_bins          = (uint32_t) param_number_of_col_bins.value();
+    p.canvas_rows                 = (int32_t) param_projector->param_canvas_rows.value();
+    p.canvas_cols                 = (int32_t) param_projector->param_canvas_cols.value();
+    p.maximum_distance_appearance = param_maximum_distance_appearance.value();
+    p.target_number_of_merges     = (uint32_t) param_target_number_of_merges.value();
+    p.target_merge_ratio          = param_target_merge_ratio.value();
+    p.triangulator.fx = K[0];
+    p.triangulator.fy = K[4];
+    p.triangulator.cx = K[2];
+    p.triangulator.cy = K[5];
+    p.triangulator.b_x                      = _baseline_px;
+    p.triangulator.minimum_disparity_pixels = param_minimum_disparity_pixels.value();
+    p.triangulator.infinity_depth_meters    = 1.8446743e19f;
+    p.fx = K[0];
+    p.fy = K[4];
+    p.cx = K[2];
+    p.cy = K[5];
+    p.estimator.type            = PRS_EST_WEIGHTED_MEAN;
+    p.estimator.measurement_dim = 4;
+    p.estimator.maximum_distance_geometry_meters_squared = param_maximum_distance_geometry_meters_squared.value();
+    const size_t nm = _measurement->size();
+    std::vector<float> z(4 * nm);
+    std::vector<uint8_t> zd(PRS_DESC_BYTES * nm);
+    for (size_t i = 0; i < nm; ++i) {
+      std::memcpy(&z[4 * i], (*_measurement)[i].coords, sizeof(float) * 4);
+      std::memcpy(&zd[PRS_DESC_BYTES * i], (*_measurement)[i].descriptor_row, PRS_DESC_BYTES);
+    }
+    static_assert(sizeof(Correspondence) == sizeof(prs_corr), "layout");
+    prs_merge_result res;
+    const int rc = prs_map_merge(_map, &p, _measurement_in_world, _measurement_in_scene, z.data(), zd.data(), (int32_t) nm,
+                                 reinterpret_cast<const prs_corr*>(_correspondences->data()), (int32_t) _correspondences->size(), nullptr, 0, &res);
+    if (rc < 0) throw std::runtime_error(std::string("MergerRigidStereoTriangulationHIP::compute|ERROR: ") + prs_last_error(_ctx->get()));
+    if (rc & PRS_WARN_NO_MATCHES) std::cerr << "MergerProjective::compute|WARNING: all merge attempts failed" << std::endl;
+    _n_merged = (size_t) res.n_merged;
+    _n_added  = (size_t) res.n_added;
+    // mirror the scene back: element order intact, new points appended (merger_projective_impl.cpp:230-308)
+    int32_t n = 0;
+    prs_map_size(_map, &n, nullptr);
+    std::vector<float> xyz(3 * (size_t) _capacity);
+    std::vector<uint8_t> desc(PRS_DESC_BYTES * (size_t) _capacity);
+    std::vector<uint32_t> nopt((size_t) _capacity);
+    if (prs_map_get_scene(_map, _capacity, xyz.data(), nullptr, desc.data(), nopt.data(), nullptr, &n) != PRS_OK) {
+      throw std::runtime_error(std::string("MergerRigidStereoTriangulationHIP|ERROR: ") + prs_last_error(_ctx->get()));
+    }
+    _scene->resize((size_t) n);
+    for (int32_t i = 0; i < n; ++i) {
+      std::memcpy((*_scene)[(size_t) i].coords, &xyz[3 * (size_t) i], sizeof(float) * 3);
+      std::memcpy((*_scene)[(size_t) i].descriptor_row, &desc[PRS_DESC_BYTES * (size_t) i], PRS_DESC_BYTES);
+      (*_scene)[(size_t) i].number_of_optimizations = nopt[(size_t) i];
+    }
+  }
+
+protected:
+  ContextPtr _ctx;
+  prs_map* _map      = nullptr;
+  int32_t _capacity  = 0;
+  SceneType* _scene  = nullptr;
+  bool _scene_changed = true;
+  const MeasurementType* _measurement          = nullptr;
+  const CorrespondenceVector* _correspondences = nullptr;
+  float _measurement_in_scene[16];
+  float _measurement_in_world[16];
+  float _baseline_px = 0.f;
+  size_t _n_merged = 0, _n_added = 0;
+};
+
 }  // namespace proslam_hip

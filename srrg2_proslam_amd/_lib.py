@@ -298,6 +298,14 @@ SYMBOLS = {
     "prs_pose_compose_batch": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),
     "prs_motion_predict_batch": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),
     "prs_merge_batch_run": (C.c_int, [_vp, C.POINTER(MergerParams), C.POINTER(MergeBatch)]),
+    "prs_map_create": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    "prs_map_destroy": (C.c_int, [_vp]),
+    "prs_map_clear": (C.c_int, [_vp]),
+    "prs_map_size": (C.c_int, [_vp, _i32p, _i32p]),
+    "prs_map_set_scene": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32]),
+    "prs_map_set_frame_pose": (C.c_int, [_vp, C.c_int32, _vp]),
+    "prs_map_merge": (C.c_int, [_vp, C.POINTER(MergerParams), _vp, _vp, _vp, _vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, _vp]),
+    "prs_map_get_scene": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _i32p]),
     "prs_scene_clip_batch": (C.c_int, [_vp, C.POINTER(Projector), _vp, C.POINTER(ClipBatch)]),
     "prs_scene_clip": (C.c_int, [_vp, C.POINTER(Projector), _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, C.c_int32, _i32p]),
 }

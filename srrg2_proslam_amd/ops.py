@@ -701,6 +701,78 @@ def merge_batch(ctx, params, maps):
     return rc
 
 
+class MapHandle:
+    """host-side merger object: one device-resident local map (prs_map), mirrors setScene / setMeasurement / compute of
+    mapping/mergers/merger_projective.h"""
+
+    def __init__(self, ctx, capacity, max_measurements=0, max_frames=64, max_measured=2048):
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        self.capacity = int(capacity)
+        rc = _lib.load().prs_map_create(ctx._h, int(capacity), int(max_measurements), int(max_frames), int(max_measured), C.byref(self._h))
+        _check(ctx, rc, "prs_map_create")
+
+    def close(self):
+        if self._h:
+            _lib.load().prs_map_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clear(self):
+        _check(self._ctx, _lib.load().prs_map_clear(self._h), "prs_map_clear")
+
+    def size(self):
+        n, f = C.c_int32(0), C.c_int32(0)
+        _check(self._ctx, _lib.load().prs_map_size(self._h, C.byref(n), C.byref(f)), "prs_map_size")
+        return n.value, f.value
+
+    def set_scene(self, coords, desc, state=None, covariance=None, n_opt=None, first_measurement=None):
+        c = _np(coords, np.float32, (-1, 3))
+        n = c.shape[0]
+        d = _np(desc, np.uint8, (-1, 32))
+        st = None if state is None else _np(state, np.float32, (-1, 3))
+        cov = None if covariance is None else _np(covariance, np.float32, (-1, 9))
+        no = None if n_opt is None else _np(n_opt, np.uint32, (-1,))
+        fm = None if first_measurement is None else np.ascontiguousarray(first_measurement)
+        rc = _lib.load().prs_map_set_scene(self._h, _p(c), None if st is None else _p(st), None if cov is None else _p(cov), _p(d),
+                                           None if no is None else _p(no), None if fm is None else fm.ctypes.data, n)
+        _check(self._ctx, rc, "prs_map_set_scene")
+
+    def set_frame_pose(self, frame, sensor_in_world):
+        T = _np(sensor_in_world, np.float32, (16,))
+        _check(self._ctx, _lib.load().prs_map_set_frame_pose(self._h, int(frame), _p(T)), "prs_map_set_frame_pose")
+
+    def merge(self, params, measurement_in_world, measurement_in_scene, measurement, measurement_desc, corr, scene_index_map=None, corr_from_aligner=0):
+        """-> (n_merged, n_added, status bits)"""
+        dim = int(params.estimator.measurement_dim)
+        z = _np(measurement, np.float32, (-1, dim))
+        d = _np(measurement_desc, np.uint8, (-1, 32))
+        c = np.ascontiguousarray(corr, dtype=CORR_DTYPE)
+        im = None if scene_index_map is None else _np(scene_index_map, np.int32, (-1,))
+        Tw, Ts = _np(measurement_in_world, np.float32, (16,)), _np(measurement_in_scene, np.float32, (16,))
+        res = (C.c_int32 * 3)()
+        rc = _lib.load().prs_map_merge(self._h, C.byref(params), _p(Tw), _p(Ts), _p(z), _p(d), z.shape[0], _p(c) if len(c) else None, len(c),
+                                       None if im is None else _p(im), int(corr_from_aligner), res)
+        _check(self._ctx, rc, "prs_map_merge")
+        return int(res[0]), int(res[1]), int(res[2])
+
+    def scene(self):
+        """-> dict(coords [n,3], state [n,3], desc [n,32], n_opt [n], inlier [n])"""
+        cap = self.capacity
+        coords, state = np.zeros((cap, 3), np.float32), np.zeros((cap, 3), np.float32)
+        desc, n_opt, inl = np.zeros((cap, 32), np.uint8), np.zeros(cap, np.uint32), np.zeros(cap, np.uint8)
+        n = C.c_int32(0)
+        rc = _lib.load().prs_map_get_scene(self._h, cap, _p(coords), _p(state), _p(desc), _p(n_opt), _p(inl), C.byref(n))
+        _check(self._ctx, rc, "prs_map_get_scene")
+        k = n.value
+        return dict(coords=coords[:k].copy(), state=state[:k].copy(), desc=desc[:k].copy(), n_opt=n_opt[:k].copy(), inlier=inl[:k].copy())
+
+
 def pose_compose_batch(ctx, prediction, X, pose_out):
     """pose_out[b] = prediction[b] * X[b]^-1 on device tensors of shape [B, 16] / [B, 4, 4] (asynchronous)"""
     batch = int(prediction.shape[0])

@@ -400,6 +400,73 @@ static void test_IntensityFeatureExtractorBinned(ContextPtr ctx) {
   }
 }
 
+// KITTI 00To00 / 00To01_MergerTriangulation_WeightedMean (tests/test_mergers.cpp:357-405, :464-519) on a synthetic stereo scene:
+// merging a cloud with its own measurements leaves it untouched, merging the view from a moved camera with partial
+// correspondences grows it by no more than the measurements, and unset buffers throw
+static void test_MergerRigidStereoTriangulation(ContextPtr ctx) {
+  const float K[9] = {718.856f, 0, 607.193f, 0, 718.856f, 185.216f, 0, 0, 1};
+  const float bx   = 386.1448f;
+  std::mt19937 rng(11);
+  std::uniform_real_distribution<float> ux(-8.f, 8.f), uy(-2.f, 1.5f), uz(6.f, 40.f);
+  PointIntensityDescriptorVectorCloud<3> scene;
+  PointIntensityDescriptorVectorCloud<4> measurements;
+  while (scene.size() < 150) {
+    const float X = ux(rng), Y = uy(rng), Z = uz(rng);
+    const float uL = std::round(K[0] * X / Z + K[2]), v = std::round(K[4] * Y / Z + K[5]), uR = std::round(uL - bx / Z);
+    if (uL < 1 || uL >= 1240 || v < 1 || v >= 375 || uL - uR < 1.f) continue;
+    PointIntensityDescriptor_<4> m;
+    m.coords[0] = uL;
+    m.coords[1] = v;
+    m.coords[2] = uR;
+    m.coords[3] = v;
+    randomDescriptor(rng, m.descriptor_row);
+    measurements.push_back(m);
+    // the scene point is what the triangulator makes of this measurement (fixtures.hpp:938-944)
+    const float d = uL - uR, z = bx / d;
+    PointIntensityDescriptor_<3> p;
+    p.coords[0] = (uL - K[2]) / K[0] * z;
+    p.coords[1] = (v - K[5]) / K[4] * z;
+    p.coords[2] = z;
+    std::memcpy(p.descriptor_row, m.descriptor_row, PRS_DESC_BYTES);
+    scene.push_back(p);
+  }
+  MergerRigidStereoTriangulationHIP merger(ctx);
+  merger.param_projector->setCameraMatrix(K);
+  merger.param_projector->param_canvas_rows.setValue(376);
+  merger.param_projector->param_canvas_cols.setValue(1241);
+  merger.setBaselineRightInLeftPixels(bx);
+  merger.param_maximum_distance_appearance.setValue(50);
+  merger.param_maximum_distance_geometry_meters_squared.setValue(25);
+  bool thrown = false;
+  try {
+    merger.compute();
+  } catch (const std::runtime_error&) {
+    thrown = true;
+  }
+  ASSERT_TRUE(thrown);
+  CorrespondenceVector mirror;
+  for (size_t i = 0; i < scene.size(); ++i) mirror.push_back(Correspondence{(int) i, (int) i, 0.f});
+  const PointIntensityDescriptorVectorCloud<3> backup(scene);
+  merger.setScene(&scene);
+  merger.setMeasurement(&measurements);
+  merger.setCorrespondences(&mirror);
+  merger.compute();
+  ASSERT_EQ(scene.size(), backup.size());  // :392
+  ASSERT_TRUE(merger.numberOfMergedPoints() > 0 && merger.numberOfAddedPoints() == 0);
+  for (size_t i = 0; i < backup.size(); ++i) {  // :395-402: element order intact, coordinates within 1e-5 (relative to the depth here)
+    for (int k = 0; k < 3; ++k) ASSERT_LT_ABS(scene[i].coords[k] - backup[i].coords[k], 1e-5f * backup[i].coords[2] + 1e-5f);
+  }
+  // a second frame: the same measurements, every other correspondence missing -> unmatched measurements may be added
+  CorrespondenceVector half;
+  for (size_t i = 0; i < mirror.size(); i += 2) half.push_back(mirror[i]);
+  merger.setCorrespondences(&half);
+  merger.compute();
+  ASSERT_TRUE(scene.size() >= backup.size() && scene.size() <= backup.size() + measurements.size());  // :503-506
+  for (size_t i = 0; i < backup.size(); ++i) {
+    ASSERT_TRUE(std::memcmp(scene[i].descriptor_row, backup[i].descriptor_row, PRS_DESC_BYTES) == 0);
+  }
+}
+
 int main() {
   ContextPtr ctx;
   try {
@@ -423,6 +490,7 @@ int main() {
   RUN(test_SceneClipperProjective3D);
   RUN(test_Bruteforce_CloudVersusItself);
   RUN(test_IntensityFeatureExtractorBinned);
+  RUN(test_MergerRigidStereoTriangulation);
   std::printf("%d failure(s)\n", g_failures);
   return g_failures ? 1 : 0;
 }

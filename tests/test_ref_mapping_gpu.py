@@ -50,3 +50,38 @@ def test_merger_cases(B, hip_ctx, oracle):
         n = int(maps.n_points[0].item())
         rm.check_merge_result(case, n0, before, n, maps.coords[0, :n].cpu().numpy(), len(case["fixed"]))
         _assert_map_equal(maps, 0, om_, poses, 2)
+
+
+def test_merger_cases_through_the_host_handle(B, hip_ctx, oracle):
+    """the same gtest scenarios through prs_map_* (the stateful object an adapter's merger owns): setScene, compute, read back"""
+    from oracle import binding_mapping as om
+    for case in rm.merger_cases(B):
+        m0 = case["map"]
+        n0 = m0.n_points
+        before = m0.coords[:n0, :3].astype(np.float64).copy()
+        om_, poses, res = run_oracle_case(case)
+        h = ops.MapHandle(hip_ctx, m0.capacity, m0.max_measurements, max_frames=case["n_frames"], max_measured=1024)
+        first = None
+        if m0.max_measurements > 0:
+            first = np.ascontiguousarray(m0.meas[:n0, 0])
+            assert first.dtype.itemsize == 28
+        h.set_scene(m0.coords[:n0, :3], m0.desc[:n0], state=m0.state[:n0, :3], covariance=m0.covariance[:n0], n_opt=m0.n_opt[:n0], first_measurement=first)
+        h.set_frame_pose(0, rm.I4)
+        assert h.size() == (n0, 1)
+        got = h.merge(_gpu_params(case["params"]), case["T"], case["T"], case["fixed"], case["desc"], case["corr"])
+        assert got == (res.n_merged, res.n_added, res.flags), (case["name"], got)
+        sc = h.scene()
+        n = len(sc["coords"])
+        assert h.size() == (n, 2) and n == om_.n_points
+        rm.check_merge_result(case, n0, before, n, sc["coords"], len(case["fixed"]))
+        bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)  # noqa: E731
+        assert np.array_equal(bits(sc["coords"]), bits(om_.coords[:n, :3])) and np.array_equal(bits(sc["state"]), bits(om_.state[:n, :3])), case["name"]
+        assert np.array_equal(sc["desc"], om_.desc[:n]) and np.array_equal(sc["n_opt"], om_.n_opt[:n]) and np.array_equal(sc["inlier"], om_.inlier[:n])
+        h.close()
+    # loud errors: more measurements than the handle holds, a full pose table
+    h = ops.MapHandle(hip_ctx, 64, 0, max_frames=1, max_measured=8)
+    case = rm.merger_cases(B)[0]
+    with pytest.raises(ops.ProslamHipError) as ei:
+        h.merge(_gpu_params(case["params"]), rm.I4, rm.I4, case["fixed"], case["desc"], case["corr"][:4])
+    assert ei.value.status == ops._lib.ERR_CAPACITY
+    h.close()
