@@ -395,6 +395,7 @@ def main():
             "bound": "hbm", "achieved": gbps_search, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps_search / HBM_PEAK_GBPS,
             "traffic": evidence["search"] if evidence else None, "traffic_source": evidence["source"] if evidence else None,
             "ms_per_step": ms_search, "launches_per_step": searches, "algorithmic_bytes_per_frame_and_launch": bytes_search, "frames_per_launch": B,
+            "traffic_over_algorithmic": (evidence["search"] / (B * bytes_search * searches)) if evidence and searches > 0 else None,
         },
         "roofline_matcher": {
             "kernel": "stereo_match5_kernel<%d> (the kernel BASELINE.json north_star prices; matcher + fused adaptor / triangulator epilogue)" % (1 if N <= 1024 else 2),
@@ -409,6 +410,7 @@ def main():
             "ms_per_launch": ms_match,
             "algorithmic_bytes_per_frame": bytes_match,
             "frames_per_launch": B,
+            "traffic_over_algorithmic": (evidence["matcher"] / (B * bytes_match)) if evidence else None,
         },
         "kernel_time_share": {"stereo_match5_kernel": ms_match / (ms_match + ms_align), "align_kernel (search)": ms_search / (ms_match + ms_align),
                               "gn_kernel": ms_gn / (ms_match + ms_align)},
