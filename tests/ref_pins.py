@@ -109,6 +109,30 @@ def kitti_fixture(B):
     return _cache[key]
 
 
+def highway_relative():
+    """camera_275_in_274 of sequence 01 (fixtures.hpp:914-924)"""
+    P = load("ref_kitti_gt")["highway_274_f64"]
+    T = [np.eye(4), np.eye(4)]
+    for i in range(2):
+        T[i][:3, :4] = P[i].reshape(3, 4)
+    return np.linalg.inv(T[0]) @ T[1]
+
+
+def highway_fixture(B):
+    """KITTI::SetUp, highway part (fixtures.hpp:863-876, :1037-1053): frames 274 / 275 of sequence 01 through the same adaptor and
+    triangulator as the city frames"""
+    key = ("highway_fixture", B.name)
+    if key not in _cache:
+        z = load("ref_kitti")
+        meas, desc = {}, {}
+        for i in (0, 1):
+            meas[i], desc[i], _ = stereo_adaptor(B, z["highway_left"][i], z["highway_right"][i], 15, "epipolar", 50.0, 0.8)
+        xyz, valid = B.triangulate(meas[0], KITTI_K, KITTI_BX, 0.0)
+        assert valid.all()  # fixtures.hpp:1044
+        _cache[key] = dict(meas=meas, desc=desc, points_in_camera_00=xyz)
+    return _cache[key]
+
+
 def icl_measurements(B, k):
     """ICL::SetUp (fixtures.hpp:565-650): RawDataPreprocessorMonocularDepth with FAST 5 / 500 keypoints, depth scale 1
     on the metre image (raw_data_preprocessor_monocular_depth.cpp:156-180), unprojected with K"""

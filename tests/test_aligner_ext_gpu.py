@@ -172,3 +172,41 @@ def test_reference_aligner_tests_on_the_reference_images(oracle, hip_ctx):
     got, ref = rp.icl_aligner_depth(B), rp.icl_aligner_depth(O)
     assert got["status"] == 1 and np.all(np.abs(got["error"]) < 0.01), got["error"]  # :1089, :1098-1103
     assert np.array_equal(_bits(got["X"]), _bits(ref["X"])) and got["n_corr"] == ref["n_corr"]
+
+
+@pytest.mark.parametrize("sequence", ["city", "highway"])
+@pytest.mark.parametrize("weighting", [0, 1])
+def test_kitti_factor_level_gn_on_the_reference_images(oracle, hip_ctx, weighting, sequence):
+    """tests/test_aligners.cpp:640-759 (city 00 -> 01) and :762-880 (highway 274 -> 275) on the device: circle finder at the perfect
+    estimate, then 100 prs_pcf_linearize + prs_gn_step iterations from identity; the reference's bounds on the result and every
+    iterate equal to the CPU checker's"""
+    from test_ref_pins import OracleBackend
+    B, O = _Hip(hip_ctx), OracleBackend()
+    fix = rp.kitti_fixture(B) if sequence == "city" else rp.highway_fixture(B)
+    ofix = rp.kitti_fixture(O) if sequence == "city" else rp.highway_fixture(O)
+    relative = rp.kitti_relative(1, 0) if sequence == "city" else rp.highway_relative()
+    m1, d1, p0 = fix["meas"][1], fix["desc"][1], fix["points_in_camera_00"]
+    assert np.array_equal(m1, ofix["meas"][1]) and np.array_equal(_bits(p0), _bits(ofix["points_in_camera_00"]))
+    fp = rp.finder_params(rp.KITTI_K, rp.CIRCLE, 0.1, 1000.0, max_dist=100.0, min_dist=100.0, ratio=0.5, min_ratio=0.1, max_radius=5, min_radius=5)
+    gf, of = B.finder(fp), O.finder(fp)
+    for f in (gf, of):
+        f.set_fixed(m1, d1)
+        f.set_moving(p0, fix["desc"][0])
+        f.set_local_map_in_sensor(np.linalg.inv(relative))
+    for _ in range(100):
+        corr, _ = gf.compute()
+        ocorr, _ = of.compute()
+    assert corr_equal(corr, ocorr) and len(corr) > 15
+    md = float(np.mean(m1[corr["fixed_idx"], 0] - m1[corr["fixed_idx"], 2]))
+    cfg = configs.get("kitti")
+    gap = ops.aligner_params(cfg, mean_disparity=md, stop_at_fixed_point=0, chi_threshold=1000.0, enable_inverse_depth_weighting=weighting, damping=0.0)
+    oap = oracle_aligner_params(oracle, cfg, mean_disparity=md, chi_threshold=1000.0, enable_inverse_depth_weighting=weighting, damping=0.0)
+    Xg, Xo = np.eye(4, dtype=np.float32), np.eye(4, dtype=np.float32)
+    for _ in range(100):
+        res = gf.linearize(gap, Xg, corr)
+        Xg, _ = ops.gn_step(hip_ctx, np.array(res.H, np.float32), np.array(res.b, np.float32), 0.0, Xg)
+        s = oracle.linearize(oap, Xo, ocorr, m1, p0, None)
+        Xo, _ = oracle.gn_step(s, 0.0, Xo)
+        assert np.array_equal(_bits(Xg), _bits(Xo))
+    err = rp.t2tnq(Xg.astype(np.float64) @ relative)
+    assert np.all(np.abs(err[:3]) < 0.1) and np.all(np.abs(err[3:]) < 0.005), err
