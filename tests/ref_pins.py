@@ -362,3 +362,33 @@ def icl_aligner_depth(B):
     X, corr, status, inliers = B.align(cfg, dict(cfg["projective_finder"]), dict(cfg["aligner"]), fixed3, fx["desc"], mv["xyz"], mv["desc"],
                                        icl_relative(50, 0).astype(np.float32))
     return dict(status=status, inliers=inliers, n_corr=len(corr), X=X, error=t2tnq(np.asarray(X, np.float64) @ icl_relative(50, 0)))
+
+
+def aligner_bruteforce_cases(B):
+    """the aligner tests of the reference that plug a descriptor-based brute-force finder into the slice (its correspondences do
+    not depend on the estimate, so the loop is 100 GN iterations on one correspondence vector, from identity):
+    ICL 00To50_AlignerProjective_Bruteforce (tests/test_aligners.cpp:883-962, mono factor, cf_bruteforce_2d 30 / 0.7),
+    ICL 00To50_AlignerProjectiveDepth_Bruteforce (:964-1033, depth factor, cf_bruteforce_3d 35 / 0.7),
+    KITTI 00To01_Aligner_Bruteforce (:1106-1180) and 00To02_Aligner_Bruteforce (:1263-1340): stereo factor, chi 1000, 100 / 0.5.
+    -> dicts(name, cfg, fixed, fixed_desc, moving, moving_desc, corr, truth, bound[6])"""
+    from srrg2_proslam_amd import configs
+    import ref_tracker as rt
+    icl, kit = dict(configs.get("icl")), dict(configs.get("kitti"))
+    m0, m50 = icl_measurements(B, 0), icl_measurements(B, 50)
+    fix = kitti_fixture(B)
+    m2, d2 = rt.kitti_measurements(B, 2)
+    mono = dict(icl)
+    mono["aligner"] = dict(icl["aligner"], factor_type=2, diagonal_info=(1.0, 1.0, 0.0))  # :906 Vector2f(1, 1)
+    kit["aligner"] = dict(kit["aligner"], chi_threshold=1000.0)
+    f3 = np.concatenate([m50["uv"], m50["depth"][:, None]], axis=1).astype(np.float32)
+    raw = [("icl_mono_00_to_50", mono, m50["uv"], m50["desc"], m0["xyz"], m0["desc"], (30.0, 0.7), icl_relative(50, 0), (0.01,) * 6),
+           ("icl_depth_00_to_50", icl, f3, m50["desc"], m0["xyz"], m0["desc"], (35.0, 0.7), icl_relative(50, 0), (0.01,) * 6),
+           ("kitti_00_to_01", kit, fix["meas"][1], fix["desc"][1], fix["points_in_camera_00"], fix["desc"][0], (100.0, 0.5), kitti_relative(1, 0),
+            (0.1, 0.1, 0.2, 0.01, 0.01, 0.01)),
+           ("kitti_00_to_02", kit, m2, d2, fix["points_in_camera_00"], fix["desc"][0], (100.0, 0.5), kitti_relative(2, 0),
+            (0.1, 0.1, 0.35, 0.01, 0.01, 0.01))]
+    out = []
+    for name, cfg, fixed, dfix, moving, dmov, bf, truth, bound in raw:
+        corr = B.bruteforce(dfix, dmov, bf[0], bf[1])
+        out.append(dict(name=name, cfg=cfg, fixed=fixed, fixed_desc=dfix, moving=moving, moving_desc=dmov, corr=corr, truth=truth, bound=np.array(bound)))
+    return out

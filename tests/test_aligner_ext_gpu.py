@@ -210,3 +210,30 @@ def test_kitti_factor_level_gn_on_the_reference_images(oracle, hip_ctx, weightin
         assert np.array_equal(_bits(Xg), _bits(Xo))
     err = rp.t2tnq(Xg.astype(np.float64) @ relative)
     assert np.all(np.abs(err[:3]) < 0.1) and np.all(np.abs(err[3:]) < 0.005), err
+
+
+def test_aligner_with_bruteforce_finder_on_the_reference_images(oracle, hip_ctx):
+    """the brute-force-finder aligner tests of the reference on the device: brute-force matcher kernel for the correspondences, then
+    100 x (prs_pcf_linearize, prs_gn_step); the reference's bounds, and every iterate equal to the CPU checker's"""
+    from test_ref_pins import OracleBackend
+    B, O = _Hip(hip_ctx), OracleBackend()
+    for case, ocase in zip(rp.aligner_bruteforce_cases(B), rp.aligner_bruteforce_cases(O)):
+        assert corr_equal(case["corr"], ocase["corr"]) and np.array_equal(_bits(case["moving"]), _bits(ocase["moving"]))
+        cfg, al = case["cfg"], case["cfg"]["aligner"]
+        md = oracle.mean_disparity(case["fixed"]) if al["factor_type"] == 4 else 0.0
+        gap = ops.aligner_params(cfg, mean_disparity=md, stop_at_fixed_point=0)
+        oap = oracle_aligner_params(oracle, cfg, mean_disparity=md)
+        gf = ops.ProjectiveFinder(hip_ctx, ops.pcf_params(cfg))
+        gf.set_fixed(case["fixed"], case["fixed_desc"])
+        gf.set_moving(case["moving"], case["moving_desc"])
+        Xg, Xo = np.eye(4, dtype=np.float32), np.eye(4, dtype=np.float32)
+        for _ in range(al["max_iterations"]):
+            res = gf.linearize(gap, Xg, case["corr"])
+            Xg, _ = ops.gn_step(hip_ctx, np.array(res.H, np.float32), np.array(res.b, np.float32), al["damping"], Xg)
+            s = oracle.linearize(oap, Xo, ocase["corr"], case["fixed"], case["moving"], None)
+            Xo, _ = oracle.gn_step(s, al["damping"], Xo)
+            assert np.array_equal(_bits(Xg), _bits(Xo)), case["name"]
+        assert res.num_inliers == s.num_inliers >= al["min_num_inliers"]
+        err = rp.t2tnq(Xg.astype(np.float64) @ case["truth"])
+        assert np.all(np.abs(err) < case["bound"]), (case["name"], err)
+        gf.close()

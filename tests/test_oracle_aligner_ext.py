@@ -247,3 +247,18 @@ def test_icl_aligner_projective_depth_on_the_reference_images(oracle):
     got = rp.icl_aligner_depth(OracleBackend())
     assert got["status"] == 1  # tests/test_aligners.cpp:1089
     assert np.all(np.abs(got["error"]) < 0.01), got["error"]  # :1098-1103
+
+
+def test_aligner_with_bruteforce_finder_on_the_reference_images(oracle):
+    """tests/test_aligners.cpp:883-1033, :1106-1180, :1263-1340 (scenarios: ref_pins.aligner_bruteforce_cases)"""
+    for case in rp.aligner_bruteforce_cases(OracleBackend()):
+        cfg, al = case["cfg"], case["cfg"]["aligner"]
+        md = oracle.mean_disparity(case["fixed"]) if al["factor_type"] == 4 else 0.0
+        ap = aligner_params(oracle, cfg, mean_disparity=md)
+        X = np.eye(4, dtype=np.float32)
+        for _ in range(al["max_iterations"]):
+            s = oracle.linearize(ap, X, case["corr"], case["fixed"], case["moving"], None)
+            X, _ = oracle.gn_step(s, al["damping"], X)
+        assert s.num_inliers >= al["min_num_inliers"]  # Status::Success
+        err = rp.t2tnq(X.astype(np.float64) @ case["truth"])
+        assert np.all(np.abs(err) < case["bound"]), (case["name"], err)
