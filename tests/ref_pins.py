@@ -392,3 +392,34 @@ def aligner_bruteforce_cases(B):
         corr = B.bruteforce(dfix, dmov, bf[0], bf[1])
         out.append(dict(name=name, cfg=cfg, fixed=fixed, fixed_desc=dfix, moving=moving, moving_desc=dmov, corr=corr, truth=truth, bound=np.array(bound)))
     return out
+
+
+def kitti_gt_correspondences(B):
+    """correspondences_camera_01_from_00 of the KITTI fixture (fixtures.hpp:988-1035): fixed -> measurement of frame 01, moving -> point of
+    frame 00, from projecting the points of 00 into image 01 with the known motion"""
+    import ref_mapping as rm
+    c = rm.kitti_ideal_correspondences(kitti_fixture(B))  # (00 index, 01 index)
+    out = c.copy()
+    out["fixed_idx"], out["moving_idx"] = c["moving_idx"], c["fixed_idx"]
+    return out
+
+
+def kitti_bruteforce_versus_projective(B):
+    """tests/test_correspondence_finders.cpp:615-688: circle finder at the perfect estimate with radius 5, 25, 125, 625 against the
+    brute-force matcher (50, Lowe 0.5) and the ground-truth correspondences -> [(radius, n_projective, overlap_bf, overlap_gt)]"""
+    fix = kitti_fixture(B)
+    m1, d1, p0, d0 = fix["meas"][1], fix["desc"][1], fix["points_in_camera_00"], fix["desc"][0]
+    bf = B.bruteforce(d1, d0, 50.0, 0.5)
+    gt = kitti_gt_correspondences(B)
+    pairs_bf = set(zip(bf["fixed_idx"].tolist(), bf["moving_idx"].tolist()))
+    pairs_gt = set(zip(gt["fixed_idx"].tolist(), gt["moving_idx"].tolist()))
+    out = []
+    for radius in (5, 25, 125, 625):
+        f = B.finder(finder_params(KITTI_K, CIRCLE, 0.1, 1000.0, max_dist=50.0, min_dist=50.0, ratio=0.5, max_radius=radius, min_radius=radius))
+        f.set_fixed(m1, d1)
+        f.set_moving(p0, d0)
+        f.set_local_map_in_sensor(np.linalg.inv(kitti_relative(1, 0)))
+        corr, _ = f.compute()
+        pr = list(zip(corr["fixed_idx"].tolist(), corr["moving_idx"].tolist()))
+        out.append((radius, len(pr), sum(p in pairs_bf for p in pr) / max(len(pr), 1), sum(p in pairs_gt for p in pr) / max(len(pr), 1), corr))
+    return out, len(bf), len(gt)

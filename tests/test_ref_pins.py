@@ -166,3 +166,12 @@ def test_kitti_projective_kdtree_bounds(B):
     _, c10 = rp.kitti_projective(B, rp.KDTREE, 1, 10, np.eye(4))
     _, c100 = rp.kitti_projective(B, rp.KDTREE, 1, 100, np.eye(4))
     assert len(c10) >= 36 and len(c100) >= 104
+
+
+def test_kitti_bruteforce_versus_projective(B):
+    """tests/test_correspondence_finders.cpp:615-688: at every search radius more than 70 % of the projective matches are brute-force
+    matches too and more than 60 % are ground-truth correspondences"""
+    out, n_bf, n_gt = rp.kitti_bruteforce_versus_projective(B)
+    assert n_bf > 30 and n_gt > 30
+    for radius, n, overlap_bf, overlap_gt, _ in out:
+        assert n > 30 and overlap_gt > 0.6 and overlap_bf > 0.7, (radius, n, overlap_bf, overlap_gt)  # :685-686

@@ -133,3 +133,13 @@ def test_hip_outputs_equal_the_oracle_on_the_reference_images(B, oracle):
         ro = oracle.stereo_match(uvl, dl, uvr, dr, oracle.StereoParams(50.0, 0.9, 0.0, 100, th))[0]
         assert np.array_equal(r[key]["fixed_idx"], ro["fixed_idx"]) and np.array_equal(r[key]["moving_idx"], ro["moving_idx"])
         assert np.array_equal(r[key]["response"], ro["response"])
+
+
+def test_kitti_bruteforce_versus_projective(B, oracle):
+    from test_ref_pins import OracleBackend
+    out, n_bf, n_gt = rp.kitti_bruteforce_versus_projective(B)
+    ref, r_bf, r_gt = rp.kitti_bruteforce_versus_projective(OracleBackend())
+    assert (n_bf, n_gt) == (r_bf, r_gt)
+    for (radius, n, overlap_bf, overlap_gt, corr), (_, rn, _, _, rcorr) in zip(out, ref):
+        assert n > 30 and overlap_gt > 0.6 and overlap_bf > 0.7, (radius, n, overlap_bf, overlap_gt)  # test_correspondence_finders.cpp:685-686
+        assert n == rn and np.array_equal(corr["fixed_idx"], rcorr["fixed_idx"]) and np.array_equal(corr["moving_idx"], rcorr["moving_idx"])
