@@ -265,6 +265,14 @@ typedef struct {
   float motion_prior_info[6];
 } prs_aligner_params;
 
+/* The normal equations of one linearisation.  Every one of the 29 sums (21 entries of the upper triangle of H, 6 of b,
+ * the two chi) is a FIXED-SHAPE float reduction over the correspondence vector (BUILD-DEFINED: the upstream factor loop
+ * and its summation order live in srrg2_solver and are not pinned by anything in the reference tree; the shape is the
+ * "LDS tree-reduced" one the hot path is specified with, chosen so that gfx950 evaluates it with register exchanges):
+ *   leaf l (0..127)  = ((+0 + t_l) + t_{l+128}) + t_{l+256} + ...   terms of the correspondences l, l + 128, ... in order
+ *   seven levels      v[l] <- v[l] + v[l ^ m]  for m = 32, 16, 8, 7, 2, 1, 64 (a balanced binary tree over the 128 leaves)
+ *   sum               = v[0] + 0.0f
+ * Same inputs give the same bits on every launch, batch size and entry point (fused, split, prs_pcf_linearize). */
 typedef struct {
   float H[36];          /* last linearisation, row-major, without prior */
   float b[6];           /* sum J^T Omega e */

@@ -1045,7 +1045,54 @@ float orc_mean_disparity(const float* fixed_uvuv, int n) {
  * mapping/landmarks/filters/stereo_projective_point_ekf_impl.cpp:21-46 (pinhole/stereo Jacobian),
  * mapping/landmarks/landmark_estimator_pose_based_smoother_impl.cpp:77-106 (saturated kernel,
  * H += J^T Omega J, b += J^T Omega e), tests/fixtures.hpp:360-366 ((K p - b)/z).
- * Accumulation is sequential over the correspondence vector in float, like the upstream factor loop. */
+ * Accumulation (BUILD-DEFINED: the upstream factor loop and its sum order are external and unpinned,
+ * SURVEY.md Appendix A "Accumulation & step"; north_star prescribes a tree reduction): every one of the
+ * 29 normal-equation sums (21 H upper + 6 b + 2 chi) is a FIXED-SHAPE float reduction over the
+ * correspondence vector, see orc_sum128_* below. */
+
+/* Fixed-shape sum of a sequence t_0, t_1, ... (float, round to nearest):
+ *   leaf[l] (l = 0..127)  = ((+0 + t_l) + t_{l+128}) + t_{l+256} ...        (terms of index = l mod 128, in order)
+ *   seven pairwise levels  v[l] <- v[l] + v[l ^ m]  for m = 32, 16, 8, 7, 2, 1, 64 (in this order)
+ *   result                 = v[0] + 0.0f                                     (the sign of a zero sum is +)
+ * i.e. 128 interleaved partial sums followed by a balanced binary tree (every level pairs clusters of equal
+ * size: {l, l^7} then {.., l^2, l^5} then all eight of an aligned group of 8, ...); float addition is
+ * commutative, so after a level both partners hold the same value.  The device evaluates the same tree with
+ * one lane per leaf (two wavefronts): the masks are the lane exchanges gfx950 has as single instructions
+ * (v_permlane32_swap, v_permlane16_swap, DPP row_ror:8, row_half_mirror, quad_perm; the two waves meet in
+ * LDS) -- srrg2_proslam_amd/csrc/align.hip, wave_sum_slots. */
+#define ORC_SUM_LEAVES 128
+typedef struct {
+  float leaf[ORC_SUM_LEAVES];
+} orc_sum128;
+
+static void orc_sum128_init(orc_sum128* s) {
+  for (int l = 0; l < ORC_SUM_LEAVES; ++l) {
+    s->leaf[l] = 0.0f;
+  }
+}
+
+static inline void orc_sum128_add(orc_sum128* s, int index, float term) {
+  s->leaf[index & (ORC_SUM_LEAVES - 1)] += term;
+}
+
+static float orc_sum128_result(const orc_sum128* s) {
+  static const int level_mask[7] = {32, 16, 8, 7, 2, 1, 64};
+  float v[ORC_SUM_LEAVES];
+  memcpy(v, s->leaf, sizeof(v));
+  for (int k = 0; k < 7; ++k) {
+    const int m = level_mask[k];
+    for (int l = 0; l < ORC_SUM_LEAVES; ++l) {
+      const int p = l ^ m;
+      if (l < p) {
+        const float sum = v[l] + v[p];
+        v[l]            = sum;
+        v[p]            = sum;
+      }
+    }
+  }
+  return v[0] + 0.0f;
+}
+
 void orc_linearize(const orc_aligner_params* P,
                    const float* X,
                    const orc_corr* corr,
@@ -1087,10 +1134,11 @@ void orc_linearize_ex(const orc_aligner_params* P,
   const float R10 = X[4], R11 = X[5], R12 = X[6], t1 = X[7];
   const float R20 = X[8], R21 = X[9], R22 = X[10], t2 = X[11];
   const float fx = P->fx, fy = P->fy, cx = P->cx, cy = P->cy;
-  float H[6][6];
-  float b[6];
-  memset(H, 0, sizeof(H));
-  memset(b, 0, sizeof(b));
+  /* 21 H (upper triangle, row-major) + 6 b + chi_inliers + chi_total */
+  orc_sum128 sums[29];
+  for (int t = 0; t < 29; ++t) {
+    orc_sum128_init(&sums[t]);
+  }
 
   for (int ic = 0; ic < n_corr; ++ic) {
     const int f     = corr[ic].fixed_idx;
@@ -1200,30 +1248,36 @@ void orc_linearize_ex(const orc_aligner_params* P,
       }
     } else {
       ++out->num_inliers;
-      out->chi_inliers += chi;
+      orc_sum128_add(&sums[27], ic, chi);
       if (cls_out) {
         cls_out[ic] = 0;
       }
     }
-    out->chi_total += chi;
+    orc_sum128_add(&sums[28], ic, chi);
 
     /* H += J^T Omega J (upper), b += J^T Omega e */
+    int t = 0;
     for (int r = 0; r < 6; ++r) {
       const float j0 = J[0][r] * o[0];
       const float j1 = J[1][r] * o[1];
       const float j2 = J[2][r] * o[2];
       for (int c = r; c < 6; ++c) {
-        H[r][c] += fmaf(j2, J[2][c], fmaf(j1, J[1][c], j0 * J[0][c]));
+        orc_sum128_add(&sums[t++], ic, fmaf(j2, J[2][c], fmaf(j1, J[1][c], j0 * J[0][c])));
       }
-      b[r] += fmaf(j2, e[2], fmaf(j1, e[1], j0 * e[0]));
+      orc_sum128_add(&sums[21 + r], ic, fmaf(j2, e[2], fmaf(j1, e[1], j0 * e[0])));
     }
   }
+  int t = 0;
   for (int r = 0; r < 6; ++r) {
-    for (int c = 0; c < 6; ++c) {
-      out->H[6 * r + c] = c >= r ? H[r][c] : H[c][r];
+    for (int c = r; c < 6; ++c) {
+      const float h     = orc_sum128_result(&sums[t++]);
+      out->H[6 * r + c] = h;
+      out->H[6 * c + r] = h;
     }
-    out->b[r] = b[r];
+    out->b[r] = orc_sum128_result(&sums[21 + r]);
   }
+  out->chi_inliers = orc_sum128_result(&sums[27]);
+  out->chi_total   = orc_sum128_result(&sums[28]);
 }
 
 /* IterationAlgorithmGN with damping + dense Cholesky (configurations/kitti.conf:20-22,310-315)

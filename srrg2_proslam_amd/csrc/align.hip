@@ -194,15 +194,29 @@ __device__ __forceinline__ float inverse_depth_weight(const float4 z, const floa
   }
   return wt;
 }
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int kPairs = 16;  // the 29 sums + 3 class counts of one linearisation travel as 16 float pairs (32 "slots")
+// slot (= 2 * pair + component) -> meaning.  The upper triangle of J^T Omega J is produced row by row as float pairs
+// (v_pk_fma_f32); where a row starts on the second element of a pair, the first element would be the mirrored entry:
+// those three places carry the class indicators (1.0f / 0.0f: inlier, kernelised, invalid), so that the class counts
+// come out of the same reduction as exact small integers.
+//    0..5   H00 H01 H02 H03 H04 H05      6  #inliers     7..11  H11 H12 H13 H14 H15
+//   12..15  H22 H23 H24 H25             16  #kernelised 17..19  H33 H34 H35
+//   20..21  H44 H45                     22  #invalid    23      H55
+//   24..29  b0..b5                      30  chi (inliers only)   31  chi (all, kernelised ones saturated)
+constexpr int kSlotInl = 6, kSlotOut = 16, kSlotInv = 22;
+
+// One correspondence of SE3{,Depth,RectifiedStereo}ProjectiveErrorFactor::errorAndJacobian + saturated robustifier,
+// as the 16 pairs above.  cls: 0 inlier, 1 kernelised, 2 invalid (behind the camera / outside the image), 3 inactive.
 template <int DIM = 0, bool PRE_WT = false>
-__device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const PoseRegs& X, const float4 z, const float4 p_in,
-                                             const float mean_dsp, const bool active, float* tv, int& cls, const bool inlier_only = false) {
-  // Straight-line on purpose: with `tv` live out of nested divergent branches the compiler re-materialises
-  // all 29 zeros at every nesting level (~150 v_mov per call, as many as the arithmetic).  A correspondence
-  // that is inactive (slot past the end) or invalid (behind the camera / outside the image) runs the same
-  // arithmetic on a harmless point with zero information: every term is then +-0, which leaves the ordered
-  // sums bit-identical to adding +0 (they start at +0 and x + (-0) = x).  Valid correspondences execute
-  // exactly the operations of the sequential evaluation.
+__device__ __forceinline__ void factor_pairs(const prs_aligner_params& a, const PoseRegs& X, const float4 z, const float4 p_in,
+                                             const float mean_dsp, const bool active, f2* P, int& cls, const bool inlier_only = false) {
+  // Straight-line on purpose: with the terms live out of nested divergent branches the compiler re-materialises
+  // all zeros at every nesting level.  A correspondence that is inactive (slot past the end) or invalid (behind the
+  // camera / outside the image) runs the same arithmetic on harmless stand-in values (point 0, image point 0,
+  // inverse depth 0) with zero information and zero error: every term is then +-0, and a fixed-shape sum that is
+  // normalised with + 0.0f at its root does not see the sign of a zero term.  Valid correspondences execute exactly
+  // the operations of the sequential evaluation.
   const float R00 = X.R00, R01 = X.R01, R02 = X.R02, t0 = X.t0;
   const float R10 = X.R10, R11 = X.R11, R12 = X.R12, t1 = X.t1;
   const float R20 = X.R20, R21 = X.R21, R22 = X.R22, t2 = X.t2;
@@ -210,38 +224,25 @@ __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const 
   const int dim = DIM ? DIM : a.factor_type;
   // explicit fused multiply-adds (one rounding each): the factor arithmetic is defined this way on
   // both sides of the parity test
-  bool valid;
-  float iz_valid;  // 1 / depth of the real point (the stand-in below reuses it: for a valid point both are the same value)
-  {
-    const float px = p_in.x, py = p_in.y, pz = p_in.z;
-    const float pcx = fmaf(R02, pz, fmaf(R01, py, fmaf(R00, px, t0)));
-    const float pcy = fmaf(R12, pz, fmaf(R11, py, fmaf(R10, px, t1)));
-    const float pcz = fmaf(R22, pz, fmaf(R21, py, fmaf(R20, px, t2)));
-    const float hx  = fmaf(fx, pcx, cx * pcz);
-    const float hy  = fmaf(fy, pcy, cy * pcz);
-    const float iz  = 1.0f / pcz;
-    const float u_pred = hx * iz, v_pred = hy * iz;
-    valid    = active && pcz > 0.0f && !(u_pred < 0.0f || u_pred > a.image_cols || v_pred < 0.0f || v_pred > a.image_rows);
-    iz_valid = iz;
-  }
-  // the harmless stand-in: the point (0, 0, 1) seen with zero information and zero error
-  const float px = valid ? p_in.x : 0.0f, py = valid ? p_in.y : 0.0f, pz = valid ? p_in.z : 1.0f;
-  const float pcx = fmaf(R02, pz, fmaf(R01, py, fmaf(R00, px, t0)));
-  const float pcy = fmaf(R12, pz, fmaf(R11, py, fmaf(R10, px, t1)));
-  const float pcz = fmaf(R22, pz, fmaf(R21, py, fmaf(R20, px, t2)));
-  const float hx  = fmaf(fx, pcx, cx * pcz);
-  const float hy  = fmaf(fy, pcy, cy * pcz);
-  const float hz  = pcz;
-  const float iz     = valid ? iz_valid : 0.0f;
-  const float u_pred = hx * iz;
-  const float v_pred = hy * iz;
+  const float pcx = fmaf(R02, p_in.z, fmaf(R01, p_in.y, fmaf(R00, p_in.x, t0)));
+  const float pcy = fmaf(R12, p_in.z, fmaf(R11, p_in.y, fmaf(R10, p_in.x, t1)));
+  const float pcz = fmaf(R22, p_in.z, fmaf(R21, p_in.y, fmaf(R20, p_in.x, t2)));
+  const float hx_r = fmaf(fx, pcx, cx * pcz);
+  const float hy_r = fmaf(fy, pcy, cy * pcz);
+  const float iz_r = 1.0f / pcz;
+  const float u_pred = hx_r * iz_r, v_pred = hy_r * iz_r;
+  const bool valid   = active && pcz > 0.0f && !(u_pred < 0.0f || u_pred > a.image_cols || v_pred < 0.0f || v_pred > a.image_rows);
+  // the stand-in of an invalid / inactive correspondence (any finite values do: its information is zero)
+  const float px = valid ? p_in.x : 0.0f, py = valid ? p_in.y : 0.0f, pz = valid ? p_in.z : 0.0f;
+  const float hx = valid ? hx_r : 0.0f, hy = valid ? hy_r : 0.0f;
+  const float iz = valid ? iz_r : 0.0f;
   float e0 = u_pred - z.x, e1 = v_pred - z.y, e2 = 0.0f;
   float hrx = hx;
   if (dim == PRS_FACTOR_STEREO) {
     hrx = hx + a.baseline_left_in_right_px[0];
     e2  = fmaf(hrx, iz, -z.z);
   } else if (dim == PRS_FACTOR_DEPTH) {
-    e2 = hz - z.z;
+    e2 = pcz - z.z;
   }
   e0 = valid ? e0 : 0.0f;
   e1 = valid ? e1 : 0.0f;
@@ -255,7 +256,6 @@ __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const 
   const float Rm[3][3] = {{R00, R01, R02}, {R10, R11, R12}, {R20, R21, R22}};
   // From here on the six columns of the Jacobian rows travel as three float pairs: the element-wise
   // steps map onto v_pk_mul_f32 / v_pk_fma_f32 (IEEE per lane, same results as the scalar forms).
-  typedef float f2 __attribute__((ext_vector_type(2)));
   auto fma2 = [](f2 x, f2 y, f2 z2) -> f2 { return __builtin_elementwise_fma(x, y, z2); };
   f2 Jp[3][3];
 #pragma unroll
@@ -294,21 +294,17 @@ __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const 
   o2 *= scale;
   chi    = saturated ? a.chi_threshold : chi;
   cls    = !active ? 3 : (!valid ? 2 : (saturated ? 1 : 0));
-  tv[27] = saturated ? 0.0f : chi;
-  tv[28] = chi;
+  P[15]  = f2{saturated ? 0.0f : chi, chi};
   const f2 o02 = {o0, o0}, o12 = {o1, o1}, o22 = {o2, o2}, e02 = {e0, e0}, e12 = {e1, e1}, e22 = {e2, e2};
   f2 j0[3], j1[3], j2[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    j0[k] = J0[k] * o02;
-    j1[k] = J1[k] * o12;
-    j2[k] = J2[k] * o22;
-    const f2 bk    = fma2(j2[k], e22, fma2(j1[k], e12, j0[k] * e02));
-    tv[21 + 2 * k] = bk.x;
-    tv[22 + 2 * k] = bk.y;
+    j0[k]     = J0[k] * o02;
+    j1[k]     = J1[k] * o12;
+    j2[k]     = J2[k] * o22;
+    P[12 + k] = fma2(j2[k], e22, fma2(j1[k], e12, j0[k] * e02));
   }
-  // the upper triangle of J^T Omega J row by row; the full pair is computed where the triangle starts on
-  // the second element of a pair (its first element is the mirrored entry and is dropped)
+  // the upper triangle of J^T Omega J row by row
   int t = 0;
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
@@ -318,13 +314,90 @@ __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const 
     const f2 r0 = {a0, a0}, r1 = {a1, a1}, r2 = {a2, a2};
 #pragma unroll
     for (int k = r >> 1; k < 3; ++k) {
-      const f2 h = fma2(r2, J2[k], fma2(r1, J1[k], r0 * J0[k]));
-      if (2 * k >= r) {
-        tv[t++] = h.x;
-      }
-      tv[t++] = h.y;
+      P[t++] = fma2(r2, J2[k], fma2(r1, J1[k], r0 * J0[k]));
     }
   }
+  // class indicators in the places of the three mirrored entries
+  P[kSlotInl >> 1].x = (valid && !saturated) ? 1.0f : 0.0f;
+  P[kSlotOut >> 1].x = saturated ? 1.0f : 0.0f;
+  P[kSlotInv >> 1].x = (active && !valid) ? 1.0f : 0.0f;
+}
+
+// the 29 terms of one correspondence in the order of the normal-equation sums (21 H upper triangle row-major, 6 b,
+// chi of the inliers, chi of all): the fused kernel's form of factor_pairs
+template <int DIM = 0, bool PRE_WT = false>
+__device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const PoseRegs& X, const float4 z, const float4 p_in,
+                                             const float mean_dsp, const bool active, float* tv, int& cls, const bool inlier_only = false) {
+  f2 P[kPairs];
+  factor_pairs<DIM, PRE_WT>(a, X, z, p_in, mean_dsp, active, P, cls, inlier_only);
+  int t = 0;
+#pragma unroll
+  for (int slot = 0; slot < 24; ++slot) {
+    if (slot != kSlotInl && slot != kSlotOut && slot != kSlotInv) {
+      tv[t++] = (slot & 1) ? P[slot >> 1].y : P[slot >> 1].x;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    tv[21 + 2 * k] = P[12 + k].x;
+    tv[22 + 2 * k] = P[12 + k].y;
+  }
+  tv[27] = P[15].x;
+  tv[28] = P[15].y;
+}
+
+// ---- the fixed-shape sum of the normal equations (defined in include/proslam_hip.h, prs_align_result) --------------
+//   leaf l (0..127) = terms of index l, l + 128, l + 256, ... added in that order;
+//   seven pairwise levels v[l] <- v[l] + v[l ^ m], m = 32, 16, 8, 7, 2, 1, 64; result = v[0] + 0.0f.
+// On the device leaf l is lane (l & 63) of wave (l >> 6) of a 128-thread workgroup: the levels 32 and 16 are
+// v_permlane32_swap / v_permlane16_swap exchanges, 8 / 7 / 2 / 1 are DPP reads inside a row of 16 lanes (row_ror:8,
+// row_half_mirror, two quad_perm), 64 is the add across the two waves.  The reduction is "transposed": a lane gives
+// away half of its slots at every level, so 32 slots cost 16 + 8 + 4 + 2 + 1 + 1 adds per lane instead of 32 * 6.
+constexpr int kSumLevelMasks[7] = {32, 16, 8, 7, 2, 1, 64};
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_read(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void swap_halves32(f2& a, f2& b) {  // lanes 32..63 of a <-> lanes 0..31 of b (both components)
+  const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+  const auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+  a             = f2{__uint_as_float(rx[0]), __uint_as_float(ry[0])};
+  b             = f2{__uint_as_float(rx[1]), __uint_as_float(ry[1])};
+}
+__device__ __forceinline__ void swap_rows16(f2& a, f2& b) {  // odd rows (of 16 lanes) of a <-> even rows of b
+  const auto rx = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+  const auto ry = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+  a             = f2{__uint_as_float(rx[0]), __uint_as_float(ry[0])};
+  b             = f2{__uint_as_float(rx[1]), __uint_as_float(ry[1])};
+}
+// sums the 32 slots of `acc` over the 64 lanes of the wave (levels 32, 16, 8, 7, 2, 1); lane L returns slot (L >> 1) & 31
+__device__ __forceinline__ float wave_sum_slots(f2* acc, const int lane) {
+  f2 w[8], x[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    swap_halves32(acc[i], acc[i + 8]);
+    w[i] = acc[i] + acc[i + 8];  // lanes < 32: pairs 0..7, lanes >= 32: pairs 8..15
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    swap_rows16(w[i], w[i + 4]);
+    x[i] = w[i] + w[i + 4];  // even rows: pairs i, odd rows: pairs i + 4 (of this half's eight)
+  }
+  const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
+  float y[4], zz[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {  // float slots j and j + 4 of this row's eight
+    const float lo = (j & 1) ? x[j >> 1].y : x[j >> 1].x;
+    const float hi = (j & 1) ? x[(j >> 1) + 2].y : x[(j >> 1) + 2].x;
+    y[j]           = (b3 ? hi : lo) + dpp_read<0x128>(b3 ? lo : hi);  // row_ror:8 = lane ^ 8
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    zz[j] = (b2 ? y[j + 2] : y[j]) + dpp_read<0x141>(b2 ? y[j] : y[j + 2]);  // row_half_mirror = lane ^ 7
+  }
+  const float q = (b1 ? zz[1] : zz[0]) + dpp_read<0x4E>(b1 ? zz[0] : zz[1]);  // quad_perm [2,3,0,1] = lane ^ 2
+  return q + dpp_read<0xB1>(q);                                                // quad_perm [1,0,3,2] = lane ^ 1
 }
 
 // SPLIT = the search half of the split pipeline (mode kModeSplitSearch): a compile-time flag, so the
@@ -1109,7 +1182,11 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
           clsbuf[c] = 2;
         }
       }
-      float run = 0.0f;  // lanes 0..28 of wave 0: running sum of their term in correspondence order
+      // the fixed-shape sum of the 29 normal-equation terms (include/proslam_hip.h, prs_align_result): 128 leaves per term in LDS, leaf l = the
+      // terms of the correspondences l, l + 128, l + 256, ... added in that order
+      for (int i = tid; i < kTerms * 128; i += T) {
+        terms[i] = 0.0f;
+      }
       __syncthreads();
       for (int c0 = 0; c0 < nc && pose_ok; c0 += T) {
         ALIGN_MARK();
@@ -1122,40 +1199,39 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
           atomicAdd(cls == 0 ? &sh.n_inl : (cls == 1 ? &sh.n_out : &sh.n_inv), 1);
           clsbuf[c] = (uint8_t) cls;
         }
-#pragma unroll
-        for (int t = 0; t < kTerms; ++t) {
-          terms[t * T + tid] = tv[t];
-        }
-        __syncthreads();
         ALIGN_ACC(acc_lin);
         ALIGN_MARK();
-        // sequential accumulation in correspondence order, one lane per normal-equation entry
-        if (tid < kTerms) {
-          // entries past the last correspondence hold +0.0f and x + 0.0f == x bit-for-bit (the running
-          // sums are never -0.0f), so whole 16-entry groups are added: 4 x 16-byte LDS reads in
-          // flight, then 16 dependent adds in correspondence order
-          const int cnt      = nc - c0 < T ? nc - c0 : T;
-          const float4* row4 = reinterpret_cast<const float4*>(terms + tid * T);
-          float4 n0 = row4[0], n1 = row4[1], n2 = row4[2], n3 = row4[3];
-          for (int j = 0; j < cnt; j += 16) {
-            const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
-            if (j + 16 < cnt) {  // next group's reads fly while this group's dependent adds retire
-              const int k = (j >> 2) + 4;
-              n0 = row4[k];
-              n1 = row4[k + 1];
-              n2 = row4[k + 2];
-              n3 = row4[k + 3];
+        // thread tid holds correspondence c0 + tid: the T / 128 groups of 128 threads add to the leaves one after the other
+#pragma unroll 1
+        for (int grp = 0; grp < T / 128; ++grp) {
+          if ((tid >> 7) == grp) {
+#pragma unroll
+            for (int t = 0; t < kTerms; ++t) {
+              terms[t * 128 + (tid & 127)] += tv[t];
             }
-            run += q0.x; run += q0.y; run += q0.z; run += q0.w;
-            run += q1.x; run += q1.y; run += q1.z; run += q1.w;
-            run += q2.x; run += q2.y; run += q2.z; run += q2.w;
-            run += q3.x; run += q3.y; run += q3.z; run += q3.w;
           }
+          __syncthreads();
         }
-        __syncthreads();
         ALIGN_ACC(acc_sum);
       }
+      ALIGN_MARK();
+      // seven pairwise levels v[l] <- v[l] + v[l ^ m]; a pair is handled by the partner whose bit (highest bit of m) is clear
+#pragma unroll 1
+      for (int lev = 0; lev < 7; ++lev) {
+        const int m  = kSumLevelMasks[lev];
+        const int hb = 31 - __clz(m);
+        for (int i = tid; i < kTerms * 64; i += T) {
+          const int t   = i >> 6, q = i & 63;
+          const int l   = ((q >> hb) << (hb + 1)) | (q & ((1 << hb) - 1));
+          float* row    = terms + t * 128;
+          const float v = row[l] + row[l ^ m];
+          row[l]        = v;
+          row[l ^ m]    = v;
+        }
+        __syncthreads();
+      }
       if (tid < kTerms) {
+        const float run = terms[tid * 128] + 0.0f;  // the root: a zero sum is +0
         if (tid < 21) {
           // upper-triangle index -> (r, k)
           int r = 0, first = 0;
@@ -1175,6 +1251,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
         }
       }
       __syncthreads();
+      ALIGN_ACC(acc_sum);
     }
     if (g.mode == PRS_MODE_LINEARIZE) {
       break;
@@ -1339,32 +1416,86 @@ constexpr int kGnThreads = 128;  // two waves per frame
 constexpr int kGnSlots   = 8;    // the split pipeline serves max_fixed <= 1024
 
 struct GnShared {
-  float X[16], T[16], Tprev[16], H[36], b[6];
+  float X[16], T[16], Tprev[16];
+  // destinations of the 32 summed slots, consecutive: H (both triangles), b, chi (inliers), chi (all), the three class counts
+  float H[36], b[6];
   float chi_in, chi_tot;
+  float fcnt[3];   // #inliers, #kernelised, #invalid of the last linearisation (exact small integers)
+  float pad0;
   float A[16];     // points -> camera: X, or sensor_in_robot^-1 * X
   float Sinv[16];
+  float wsum[32];  // the 32 slot sums of the wave that does not solve
   unsigned long long it;
   int converged, need_search, n_inl, n_out, n_inv, stop, flags;
   int pose_ok;  // every entry of A is finite (kept by whoever writes X)
   int wave_tot[4];
 };
+static_assert(offsetof(GnShared, b) == offsetof(GnShared, H) + 36 * sizeof(float) && offsetof(GnShared, chi_in) == offsetof(GnShared, b) + 6 * sizeof(float) &&
+                offsetof(GnShared, chi_tot) == offsetof(GnShared, chi_in) + sizeof(float) && offsetof(GnShared, fcnt) == offsetof(GnShared, chi_tot) + sizeof(float),
+              "the summed slots are written through GnShared::H");
 
-// THREADS per frame; SLOTS = correspondences per thread the instantiation keeps in registers (ceil(max_fixed / THREADS))
-template <int THREADS, int SLOTS, int DIM = 0>
-__global__ __launch_bounds__(THREADS, 4) void gn_kernel(const AlignArgs g) {
-  constexpr int kRow = THREADS + 4;  // row stride of the term matrix (see kGnRow)
+// where the lane that ends up with summed slot `slot` puts it, as a float index from GnShared::H (`mirror`: the lower-triangle twin)
+__device__ __forceinline__ int gn_slot_destination(const int slot, const bool mirror) {
+  if (slot >= 24) {
+    return 36 + (slot - 24);  // b0..b5, chi_in, chi_tot
+  }
+  if (slot == kSlotInl) {
+    return 44;
+  }
+  if (slot == kSlotOut) {
+    return 45;
+  }
+  if (slot == kSlotInv) {
+    return 46;
+  }
+  // rows of the upper triangle start at slots 0, 6 (+1), 12, 16 (+1), 20, 22 (+1): row r holds columns (r & ~1) .. 5
+  const int r     = slot < 6 ? 0 : (slot < 12 ? 1 : (slot < 16 ? 2 : (slot < 20 ? 3 : (slot < 22 ? 4 : 5))));
+  const int first = r == 0 ? 0 : (r == 1 ? 6 : (r == 2 ? 12 : (r == 3 ? 16 : (r == 4 ? 20 : 22))));
+  const int c     = (r & ~1) + (slot - first);
+  return mirror ? 6 * c + r : 6 * r + c;
+}
+
+// the aligner loop after iteration `it_align` has been executed: the next iteration's index, and whether the frame is
+// finished (MultiAligner3DQR stand-in: max_iterations, then the inlier-only run if there are enough inliers)
+__device__ __forceinline__ bool gn_advance(const prs_aligner_params& a, const int extra, int& it_align, bool fixed_point, const int n_inl) {
+  const bool was_inlier_run = it_align >= a.max_iterations;
+  ++it_align;
+  if (fixed_point && !was_inlier_run && extra > 0) {
+    it_align    = a.max_iterations;  // the rest of the first phase repeats this iteration
+    fixed_point = false;
+  }
+  if (fixed_point) {
+    return true;
+  }
+  if (it_align == a.max_iterations && extra > 0) {
+    return n_inl < a.min_num_inliers;  // not enough inliers for an inlier-only run
+  }
+  return it_align >= a.max_iterations + extra;
+}
+
+// SLOTS = correspondences per thread the instantiation can hold (ceil(max_fixed / 128)).  The operand rows of the first
+// kGnLdsSlots * 128 correspondences (measurement + inverse-depth weight, moving point + information scale: 32 B each) are
+// parked in LDS for the whole launch (16 KB per frame; registers are needed for the 32 running sums), later ones (rare: more
+// than 512 correspondences) are fetched from global memory at every iteration.  KEEP_CLS: the factor classes are remembered
+// (keep_only_inlier_correspondences).
+constexpr int kGnLdsSlots = 4;
+template <int SLOTS, int DIM, bool KEEP_CLS>
+__global__ __launch_bounds__(128, 4) void gn_kernel(const AlignArgs g) {
+  constexpr int THREADS = 128;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid   = threadIdx.x;
+  const int lane  = tid & 63;
+  const int wave  = tid >> 6;
   const int frame = blockIdx.x;
-  // the single-wave phases (ordered sums, 6x6 solve) run on a different wave -- hence a different
-  // SIMD -- from frame to frame, so that the workgroups sharing a CU do not queue them on one SIMD
-  const int stid  = tid - 64 * (frame & (THREADS / 64 - 1));
-  FrameCtl* ctl   = g.ctl + frame;
+  // the single-wave phase (cross-wave add, 6x6 solve, finder bookkeeping) runs on a different wave -- hence a different
+  // SIMD -- from frame to frame, so that the workgroups sharing a CU do not queue it on one SIMD
+  const int solver = frame & 1;
+  const int stid   = tid - 64 * solver;  // 0..63 on the solving wave
+  FrameCtl* ctl    = g.ctl + frame;
   if (ctl->done || ctl->need_search) {
     return;  // finished, or waiting for the search kernel (block-uniform)
   }
-  float* terms             = reinterpret_cast<float*>(smem);
-  GnShared& sh             = *reinterpret_cast<GnShared*>(smem + kTerms * kRow * sizeof(float));
+  GnShared& sh             = *reinterpret_cast<GnShared*>(smem);
   prs_pcf_state* gstate    = g.b.state + frame;
   prs_align_result* gres   = g.b.result + frame;
   const float4* gops       = g.ops + (size_t) frame * (size_t) g.max_fixed * 2;
@@ -1409,96 +1540,74 @@ __global__ __launch_bounds__(THREADS, 4) void gn_kernel(const AlignArgs g) {
   if (tid < 6) {
     sh.b[tid] = gres->b[tid];
   }
-  // operands of this thread's correspondences stay in registers for the whole launch
-  float4 zf[SLOTS], pm[SLOTS];
+  // operand rows of this thread's first correspondences: parked in LDS ([slot][thread]: consecutive lanes, consecutive 16 B)
+  constexpr int LS = SLOTS < kGnLdsSlots ? SLOTS : kGnLdsSlots;
+  float4* lz = reinterpret_cast<float4*>(smem + ((sizeof(GnShared) + 15) / 16) * 16);
+  float4* lp = lz + LS * THREADS;
 #pragma unroll
-  for (int k = 0; k < SLOTS; ++k) {
+  for (int k = 0; k < LS; ++k) {
     const int c = k * THREADS + tid;
-    zf[k]       = c < nc ? gops[2 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
-    pm[k]       = c < nc ? gops[2 * c + 1] : make_float4(0.f, 0.f, 1.f, 1.f);
-    zf[k].w     = inverse_depth_weight(zf[k], mean_dsp);  // (the factors read x, y, z of the measurement only)
-  }
-  __syncthreads();
-
-  // where the lane that sums term `stid` puts its result: H (both triangles), b, chi_inliers, chi_total are
-  // consecutive floats of GnShared
-  int sum_dst0 = 0, sum_dst1 = 0;
-  if (stid >= 0 && stid < kTerms) {
-    if (stid < 21) {
-      int r = 0, firstk = 0;
-      while (stid >= firstk + (6 - r)) {
-        firstk += 6 - r;
-        ++r;
-      }
-      const int kk = r + (stid - firstk);
-      sum_dst0     = 6 * r + kk;
-      sum_dst1     = 6 * kk + r;
-    } else {
-      sum_dst0 = sum_dst1 = 36 + (stid - 21);  // b[0..5], chi_in, chi_tot
+    if (k * THREADS < nc) {
+      float4 z = c < nc ? gops[2 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      z.w      = inverse_depth_weight(z, mean_dsp);  // (the factors read x, y, z of the measurement only)
+      lz[c]    = z;
+      lp[c]    = c < nc ? gops[2 * c + 1] : make_float4(0.f, 0.f, 1.f, 1.f);
     }
   }
-  static_assert(offsetof(GnShared, b) == offsetof(GnShared, H) + 36 * sizeof(float) &&
-                  offsetof(GnShared, chi_in) == offsetof(GnShared, b) + 6 * sizeof(float) &&
-                  offsetof(GnShared, chi_tot) == offsetof(GnShared, chi_in) + sizeof(float),
-                "the ordered sums are written through sh.H");
+  // the summed slot this lane ends up with, and where it goes
+  const int my_slot = (lane >> 1) & 31;
+  const int sum_dst = gn_slot_destination(my_slot, (lane & 1) != 0);
+  __syncthreads();
+
   int it_align = ctl->it_align;
   int executed = ctl->executed;
-  bool first   = true;
   bool done    = false;
   const int extra = inlier_run_length(g.a);  // iterations of the inlier-only run after the max_iterations loop
   uint32_t cls_bits = 0;                     // factor classes of this thread's correspondences in the last linearisation (2 bits each)
   bool have_cls     = false;                 // (block-uniform) the last executed iteration linearised
-  // one aligner iteration is over: advance, change phase, report whether the frame is finished (block-uniform)
-  auto advance = [&](bool fixed_point) -> bool {
-    const bool was_inlier_run = it_align >= g.a.max_iterations;
-    ++it_align;
-    if (fixed_point && !was_inlier_run && extra > 0) {
-      it_align    = g.a.max_iterations;  // the rest of the first phase repeats this iteration
-      fixed_point = false;
-    }
-    if (fixed_point) {
-      return true;
-    }
-    if (it_align == g.a.max_iterations && extra > 0) {
-      return sh.n_inl < g.a.min_num_inliers;  // not enough inliers for an inlier-only run
-    }
-    return it_align >= g.a.max_iterations + extra;
-  };
-  while (true) {
-    if (!first && it_align < g.a.max_iterations) {
-      // finder.setLocalMapInSensor(X); finder.compute() for aligner iteration it_align, as long as it
-      // needs no projective search (CF/correspondence_finder_projective_base_impl.cpp:138-178)
-      if (stid == 0) {
-        for (int i = 0; i < 16; ++i) {
-          sh.T[i] = sh.A[i];
-        }
-        if (!sh.converged) {
-          const unsigned long long k = g.f.number_of_solver_iterations_per_projection;
-          if (k == 0 || sh.it % k == 0 || sh.it == 1) {
+
+  // What the solving wave does once an iteration's pose is final (uniform control flow inside the wave): decide whether the
+  // loop goes on and, if the next iteration belongs to the first phase, perform its finder.setLocalMapInSensor(X);
+  // finder.compute() as long as that needs no projective search (CF/correspondence_finder_projective_base_impl.cpp:138-178)
+  auto finder_bookkeeping = [&](const bool fixed_point) {
+    int next        = it_align;
+    const bool over = gn_advance(g.a, extra, next, fixed_point, sh.n_inl);
+    if (!over && next < g.a.max_iterations) {
+      if (stid < 16) {
+        sh.T[stid] = sh.A[stid];
+      }
+      if (!sh.converged) {
+        const unsigned long long k  = g.f.number_of_solver_iterations_per_projection;
+        const unsigned long long it = sh.it;
+        if (k == 0 || it % k == 0 || it == 1) {
+          if (stid == 0) {
             sh.need_search = 1;
-          } else {
-            for (int i = 0; i < 16; ++i) {
-              sh.Tprev[i] = sh.T[i];
+          }
+        } else {
+          if (stid < 16) {
+            sh.Tprev[stid] = sh.A[stid];
+          }
+          if (stid == 0) {
+            sh.it = it + 1;
+            if (nc == 0) {
+              sh.flags |= PRS_WARN_NO_MATCHES;  // _postCompute (bruteforce_impl.cpp:237-242)
             }
-            ++sh.it;
           }
         }
-        if (!sh.need_search && nc == 0) {
-          sh.flags |= PRS_WARN_NO_MATCHES;  // _postCompute (bruteforce_impl.cpp:237-242)
-        }
-      }
-      __syncthreads();
-      if (sh.need_search) {
-        break;
+      } else if (stid == 0 && nc == 0) {
+        sh.flags |= PRS_WARN_NO_MATCHES;
       }
     }
-    first = false;
+  };
+
+  while (true) {
     ++executed;
     if (nc < g.a.min_num_correspondences) {
       // slice has too few correspondences: no update this iteration
       if (tid == 0) {
         sh.n_inl = sh.n_out = sh.n_inv = 0;
         sh.chi_in = sh.chi_tot = 0.0f;
+        sh.stop = (g.a.stop_at_fixed_point && (sh.converged || it_align >= g.a.max_iterations)) ? 1 : 0;
       }
       for (int i = tid; i < 36; i += THREADS) {
         sh.H[i] = 0.0f;
@@ -1506,121 +1615,135 @@ __global__ __launch_bounds__(THREADS, 4) void gn_kernel(const AlignArgs g) {
       if (tid < 6) {
         sh.b[tid] = 0.0f;
       }
-      __syncthreads();
       have_cls = false;
-      if (advance(g.a.stop_at_fixed_point && (sh.converged || it_align >= g.a.max_iterations))) {
-        done = true;
-        break;
+      __syncthreads();
+      if (wave == solver) {
+        finder_bookkeeping(sh.stop != 0);
       }
-      continue;
-    }
-    const bool inlier_run = it_align >= g.a.max_iterations;
-    have_cls              = true;
-    cls_bits              = 0;
-    const PoseRegs pose = {sh.A[0], sh.A[1], sh.A[2], sh.A[3], sh.A[4], sh.A[5], sh.A[6], sh.A[7], sh.A[8], sh.A[9], sh.A[10], sh.A[11]};
-    // a pose with a NaN / inf entry: every correspondence is invalid, all sums stay zero
-    const bool pose_ok  = __builtin_amdgcn_readfirstlane(sh.pose_ok) != 0;
-    if (tid == 0) {
-      sh.n_inl = sh.n_out = 0;
-      sh.n_inv = pose_ok ? 0 : nc;
-    }
-    float run = 0.0f;
-    int wave_inl = 0, wave_out = 0, wave_inv = 0;
-    __syncthreads();
+      __syncthreads();
+    } else {
+      const bool inlier_run = it_align >= g.a.max_iterations;
+      have_cls              = true;
+      cls_bits              = 0;
+      const PoseRegs pose = {sh.A[0], sh.A[1], sh.A[2], sh.A[3], sh.A[4], sh.A[5], sh.A[6], sh.A[7], sh.A[8], sh.A[9], sh.A[10], sh.A[11]};
+      // a pose with a NaN / inf entry: every correspondence is invalid, all sums stay zero
+      const bool pose_ok  = __builtin_amdgcn_readfirstlane(sh.pose_ok) != 0;
+      f2 acc[kPairs];
+      if (pose_ok) {
 #pragma unroll
-    for (int k = 0; k < SLOTS; ++k) {
-      const int c0 = k * THREADS;
-      if (c0 < nc && pose_ok) {
-        float tv[kTerms];
-        int cls;
-        factor_terms<DIM, true>(g.a, pose, zf[k], pm[k], mean_dsp, c0 + tid < nc, tv, cls, inlier_run);
-        cls_bits |= (uint32_t) (cls & 3) << (2 * k);
-        // inlier / outlier / invalid counts of the wave (scalar), added to the frame's counters once per iteration
-        wave_inl += (int) __popcll(__ballot(cls == 0));
-        wave_out += (int) __popcll(__ballot(cls == 1));
-        wave_inv += (int) __popcll(__ballot(cls == 2));
+        for (int k = 0; k < SLOTS; ++k) {
+          const int c0 = k * THREADS;
+          if (k == 0 || c0 < nc) {
+            const int c = c0 + tid;
+            float4 z, p;
+            if (k < LS) {
+              z = lz[c];
+              p = lp[c];
+            } else {
+              z   = c < nc ? gops[2 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
+              p   = c < nc ? gops[2 * c + 1] : make_float4(0.f, 0.f, 1.f, 1.f);
+              z.w = inverse_depth_weight(z, mean_dsp);
+            }
+            f2 P[kPairs];
+            int cls;
+            factor_pairs<DIM, true>(g.a, pose, z, p, mean_dsp, c < nc, P, cls, inlier_run);
+            if (KEEP_CLS) {
+              cls_bits |= (uint32_t) (cls & 3) << (2 * k);
+            }
 #pragma unroll
-        for (int t = 0; t < kTerms; ++t) {
-          terms[t * kRow + tid] = tv[t];
-        }
-        __syncthreads();
-        if (stid >= 0 && stid < kTerms) {
-          const int cnt      = nc - c0 < THREADS ? nc - c0 : THREADS;
-          const float4* row4 = reinterpret_cast<const float4*>(terms + stid * kRow);
-          // (no software prefetch: the kernel is bound by instruction issue and eight frames per CU cover the LDS
-          // latency; a second register set costs eight copies per sixteen terms)
-          for (int j = 0; j < cnt; j += 16) {
-            const int kk    = j >> 2;
-            const float4 q0 = row4[kk], q1 = row4[kk + 1], q2 = row4[kk + 2], q3 = row4[kk + 3];
-            run += q0.x; run += q0.y; run += q0.z; run += q0.w;
-            run += q1.x; run += q1.y; run += q1.z; run += q1.w;
-            run += q2.x; run += q2.y; run += q2.z; run += q2.w;
-            run += q3.x; run += q3.y; run += q3.z; run += q3.w;
+            for (int i = 0; i < kPairs; ++i) {
+              acc[i] = k == 0 ? P[i] : acc[i] + P[i];
+            }
           }
         }
-        __syncthreads();
-      } else if (c0 < nc) {
-        cls_bits |= 2u << (2 * k);  // non-finite pose: every correspondence is invalid
-      }
-    }
-    if (stid >= 0 && stid < kTerms) {
-      sh.H[sum_dst0] = run;
-      sh.H[sum_dst1] = run;
-    }
-    if ((tid & 63) == 0) {
-      atomicAdd(&sh.n_inl, wave_inl);
-      atomicAdd(&sh.n_out, wave_out);
-      atomicAdd(&sh.n_inv, wave_inv);
-    }
-    __syncthreads();
-    if (stid == 0) {
-      float H[36], b[6], X[16];
+      } else {
 #pragma unroll
-      for (int i = 0; i < 36; ++i) {
-        H[i] = sh.H[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        b[i] = sh.b[i];
-      }
-      if (g.b.prior) {
-        const float* pr = g.b.prior + (size_t) frame * 42;
-#pragma unroll
-        for (int i = 0; i < 36; ++i) {
-          H[i] += pr[i];
+        for (int i = 0; i < kPairs; ++i) {
+          acc[i] = f2{0.0f, 0.0f};
         }
+        int mine = 0;  // this lane's correspondences: all invalid
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          b[i] += pr[36 + i];
+        for (int k = 0; k < SLOTS; ++k) {
+          if (k * THREADS + tid < nc) {
+            ++mine;
+            cls_bits |= 2u << (2 * k);
+          }
         }
+        acc[kSlotInv >> 1].x = (float) mine;
       }
+      // levels 32, 16, 8, 7, 2, 1 of the fixed-shape sum inside the wave; level 64 across the two waves through LDS
+      float tot = wave_sum_slots(acc, lane);
+      if (wave != solver) {
+        sh.wsum[my_slot] = tot;
+      }
+      __syncthreads();
+      if (wave == solver) {
+        tot = tot + sh.wsum[my_slot];
+        tot = tot + 0.0f;  // the root: a zero sum is +0
+        (&sh.H[0])[sum_dst] = tot;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (stid == 0) {
+          sh.n_inl = (int) sh.fcnt[0];
+          sh.n_out = (int) sh.fcnt[1];
+          sh.n_inv = (int) sh.fcnt[2];
+          float H[36], b[6], X[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        X[i] = sh.X[i];
-      }
-      if (g.a.enable_motion_prior) {
-        add_motion_prior(g.a, g.prior_mean ? g.prior_mean + (size_t) frame * 16 : nullptr, X, H, b);
-      }
-      gn_step(H, b, g.a.damping, X);
-      uint32_t changed_bits = 0;  // (bitwise, no short-circuit: sixteen compares would be sixteen branches)
+          for (int i = 0; i < 36; ++i) {
+            H[i] = sh.H[i];
+          }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        changed_bits |= __float_as_uint(X[i]) ^ __float_as_uint(sh.X[i]);
-        sh.X[i] = X[i];
-      }
-      sh.stop = (g.a.stop_at_fixed_point && changed_bits == 0u && (sh.converged || inlier_run)) ? 1 : 0;
-      float a16[16];
-      pose_to_camera(g.a, sh.Sinv, X, a16);
+          for (int i = 0; i < 6; ++i) {
+            b[i] = sh.b[i];
+          }
+          if (g.b.prior) {
+            const float* pr = g.b.prior + (size_t) frame * 42;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        sh.A[i] = a16[i];
+            for (int i = 0; i < 36; ++i) {
+              H[i] += pr[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+              b[i] += pr[36 + i];
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            X[i] = sh.X[i];
+          }
+          if (g.a.enable_motion_prior) {
+            add_motion_prior(g.a, g.prior_mean ? g.prior_mean + (size_t) frame * 16 : nullptr, X, H, b);
+          }
+          gn_step(H, b, g.a.damping, X);
+          uint32_t changed_bits = 0;  // (bitwise, no short-circuit: sixteen compares would be sixteen branches)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            changed_bits |= __float_as_uint(X[i]) ^ __float_as_uint(sh.X[i]);
+            sh.X[i] = X[i];
+          }
+          sh.stop = (g.a.stop_at_fixed_point && changed_bits == 0u && (sh.converged || inlier_run)) ? 1 : 0;
+          float a16[16];
+          pose_to_camera(g.a, sh.Sinv, X, a16);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            sh.A[i] = a16[i];
+          }
+          const PoseRegs xn = {a16[0], a16[1], a16[2], a16[3], a16[4], a16[5], a16[6], a16[7], a16[8], a16[9], a16[10], a16[11]};
+          sh.pose_ok        = pose_is_finite(xn) ? 1 : 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        finder_bookkeeping(sh.stop != 0);
       }
-      const PoseRegs xn = {a16[0], a16[1], a16[2], a16[3], a16[4], a16[5], a16[6], a16[7], a16[8], a16[9], a16[10], a16[11]};
-      sh.pose_ok        = pose_is_finite(xn) ? 1 : 0;
+      __syncthreads();
     }
-    __syncthreads();
-    if (advance(sh.stop != 0)) {
+    if (gn_advance(g.a, extra, it_align, sh.stop != 0, sh.n_inl)) {
       done = true;
+      break;
+    }
+    if (it_align < g.a.max_iterations && sh.need_search) {
       break;
     }
   }
@@ -1628,10 +1751,9 @@ __global__ __launch_bounds__(THREADS, 4) void gn_kernel(const AlignArgs g) {
   // ---- keep_only_inlier_correspondences: the returned vector keeps the inliers of the last linearisation, in order ----
   int nc_out = nc;
   __syncthreads();
-  if (done && g.a.keep_only_inlier_correspondences && have_cls) {
+  if (KEEP_CLS && done && g.a.keep_only_inlier_correspondences && have_cls) {
     prs_corr* __restrict__ gcorr = g.b.corr + (size_t) frame * (size_t) g.b.fixed_stride;
-    const int lane = tid & 63, wave = tid >> 6;
-    int base       = 0;
+    int base                     = 0;
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) {
       const int c0 = k * THREADS;
@@ -1911,7 +2033,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
                                                                      : align_kernel<kSearchThreads, true, PRS_SEARCH_KDTREE>));
   // two waves per frame (eight frames resident per CU: the kernel is bound by its single-wave phases and by
   // instruction issue, more independent frames fill the idle slots)
-  const size_t lds_gn  = (size_t) kTerms * (kGnThreads + 4) * sizeof(float) + sizeof(GnShared) + 16;
+  const size_t lds_gn  = ((sizeof(GnShared) + 15) / 16) * 16 + (size_t) kGnLdsSlots * kGnThreads * 2 * sizeof(float4);  // shared state + parked operand rows
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(skernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_search);
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_align_batch_run attribute");
@@ -1955,25 +2077,12 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
         ctx_report_stamps(ctx, batch->batch, 10, "search launch (split): - | - | - | - || lattice build | projection+search | second-best pass | filter | commit");
       }
       {
-        // (the rectified-stereo factor, the one kitti.conf / euroc.conf use, has its own instantiations: the factor
-        // type as a compile-time constant removes ~10 selects per linearised correspondence)
-        const bool stereo = aligner->factor_type == PRS_FACTOR_STEREO;
-        auto launch_gn    = [&](auto generic, auto for_stereo) {
-          if (stereo) {
-            hipLaunchKernelGGL(for_stereo, dim3(batch->batch), dim3(128), lds_gn, stream, g);
-          } else {
-            hipLaunchKernelGGL(generic, dim3(batch->batch), dim3(128), lds_gn, stream, g);
-          }
-        };
-        if (max_fixed <= 4 * 128) {
-          launch_gn(gn_kernel<128, 4>, gn_kernel<128, 4, PRS_FACTOR_STEREO>);
-        } else if (max_fixed <= 6 * 128) {
-          launch_gn(gn_kernel<128, 6>, gn_kernel<128, 6, PRS_FACTOR_STEREO>);
-        } else if (max_fixed <= 7 * 128) {
-          launch_gn(gn_kernel<128, 7>, gn_kernel<128, 7, PRS_FACTOR_STEREO>);
-        } else {
-          launch_gn(gn_kernel<128, 8>, gn_kernel<128, 8, PRS_FACTOR_STEREO>);
-        }
+        // (the rectified-stereo factor, the one kitti.conf / euroc.conf use, has its own instantiation: the factor type as a
+        // compile-time constant removes ~10 selects per linearised correspondence; so does not remembering the factor classes)
+        const bool fast = aligner->factor_type == PRS_FACTOR_STEREO && !aligner->keep_only_inlier_correspondences;
+        auto gnk        = max_fixed <= 4 * 128 ? (fast ? gn_kernel<4, PRS_FACTOR_STEREO, false> : gn_kernel<4, 0, true>)
+                                               : (fast ? gn_kernel<8, PRS_FACTOR_STEREO, false> : gn_kernel<8, 0, true>);
+        hipLaunchKernelGGL(gnk, dim3(batch->batch), dim3(kGnThreads), lds_gn, stream, g);
       }
       tick();
       ++total;

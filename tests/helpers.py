@@ -101,6 +101,10 @@ def aligner_params(ob, cfg, mean_disparity=0.0, **kw):
     p.enable_inlier_only_runs = int(al.get("enable_inlier_only_runs", 0))
     p.keep_only_inlier_correspondences = int(al.get("keep_only_inlier_correspondences", 0))
     p.inlier_only_iterations = int(al.get("inlier_only_iterations", 0))
+    if al.get("motion_prior_info") is not None:  # AlignerSliceMotionModel3D stand-in (ops.set_motion_prior on the device side)
+        p.enable_motion_prior = 1
+        for i in range(6):
+            p.motion_prior_info[i] = float(al["motion_prior_info"][i])
     return p
 
 
