@@ -1688,49 +1688,130 @@ __global__ __launch_bounds__(128, 4) void gn_kernel(const AlignArgs g) {
           sh.n_inl = (int) sh.fcnt[0];
           sh.n_out = (int) sh.fcnt[1];
           sh.n_inv = (int) sh.fcnt[2];
-          float H[36], b[6], X[16];
-#pragma unroll
-          for (int i = 0; i < 36; ++i) {
-            H[i] = sh.H[i];
-          }
-#pragma unroll
-          for (int i = 0; i < 6; ++i) {
-            b[i] = sh.b[i];
-          }
+        }
+        // ---- (H + damping I) dx = -b, X <- X * exp(dx) by the lanes of this wave: lane i < 6 owns row i of the system and
+        // of the Cholesky factor, lane r < 3 row r of the pose; pivots, substitutions and the perturbation are uniform
+        // (every lane evaluates them from broadcast values).  Every element goes through exactly the operations of
+        // prs_se3.h's gn_step, in the same order, so the pose is bit-identical to the one-lane evaluation.
+        {
+          const int row     = lane < 6 ? lane : 5;  // lanes >= 6 shadow row 5 (results unused)
+          const int prow    = lane < 3 ? lane : 2;
+          const float2* hr2 = reinterpret_cast<const float2*>(&sh.H[6 * row]);
+          const float2 h01 = hr2[0], h23 = hr2[1], h45 = hr2[2];
+          float h[6] = {h01.x, h01.y, h23.x, h23.y, h45.x, h45.y};
+          float hb   = sh.b[row];
+          const float4 xr = *reinterpret_cast<const float4*>(&sh.X[4 * prow]);
           if (g.b.prior) {
             const float* pr = g.b.prior + (size_t) frame * 42;
 #pragma unroll
-            for (int i = 0; i < 36; ++i) {
-              H[i] += pr[i];
+            for (int c = 0; c < 6; ++c) {
+              h[c] += pr[6 * row + c];
             }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-              b[i] += pr[36 + i];
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            X[i] = sh.X[i];
+            hb += pr[36 + row];
           }
           if (g.a.enable_motion_prior) {
-            add_motion_prior(g.a, g.prior_mean ? g.prior_mean + (size_t) frame * 16 : nullptr, X, H, b);
-          }
-          gn_step(H, b, g.a.damping, X);
-          uint32_t changed_bits = 0;  // (bitwise, no short-circuit: sixteen compares would be sixteen branches)
+            // AlignerSliceMotionModel3D stand-in (add_motion_prior): e = t2tnq(Z^-1 X), H[i][i] += info[i], b[i] += info[i] * e[i]
+            float X[16], e[6];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            changed_bits |= __float_as_uint(X[i]) ^ __float_as_uint(sh.X[i]);
-            sh.X[i] = X[i];
-          }
-          sh.stop = (g.a.stop_at_fixed_point && changed_bits == 0u && (sh.converged || inlier_run)) ? 1 : 0;
-          float a16[16];
-          pose_to_camera(g.a, sh.Sinv, X, a16);
+            for (int i = 0; i < 16; ++i) {
+              X[i] = sh.X[i];
+            }
+            if (g.prior_mean) {
+              const float* Z = g.prior_mean + (size_t) frame * 16;
+              float z[16], Zi[16], D[16];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            sh.A[i] = a16[i];
+              for (int i = 0; i < 16; ++i) {
+                z[i] = Z[i];
+              }
+              se3_inverse(z, Zi);
+              se3_mul(Zi, X, D);
+              t2tnq(D, e);
+            } else {
+              t2tnq(X, e);
+            }
+            float er = e[0], ir = g.a.motion_prior_info[0];
+#pragma unroll
+            for (int k = 1; k < 6; ++k) {
+              er = row == k ? e[k] : er;
+              ir = row == k ? g.a.motion_prior_info[k] : ir;
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+              h[c] = row == c ? h[c] + ir : h[c];
+            }
+            hb += ir * er;
           }
-          const PoseRegs xn = {a16[0], a16[1], a16[2], a16[3], a16[4], a16[5], a16[6], a16[7], a16[8], a16[9], a16[10], a16[11]};
-          sh.pose_ok        = pose_is_finite(xn) ? 1 : 0;
+          auto bcast = [](const float v, const int l) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+          float Lr[6], inv[6];
+          bool ok = true;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            float v = row == j ? h[j] + g.a.damping : h[j];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              if (k < j) {
+                v = fmaf(-Lr[k], bcast(Lr[k], j), v);
+              }
+            }
+            const float piv = bcast(v, j);
+            ok              = ok && piv > 0.0f;  // (no early exit: a failed pivot only poisons values that are dropped below)
+            inv[j]          = 1.0f / sqrtf(piv);
+            Lr[j]           = v * inv[j];
+          }
+          float y[6], dx[6];
+          float vy = -hb;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            y[k] = bcast(vy, k) * inv[k];
+            vy   = fmaf(-Lr[k], y[k], vy);
+          }
+#pragma unroll
+          for (int i = 5; i >= 0; --i) {
+            float v = y[i];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              if (k > i) {
+                v = fmaf(-bcast(Lr[i], k), dx[k], v);
+              }
+            }
+            dx[i] = v * inv[i];
+          }
+          float D[16];
+          tnq2t(dx, D);
+          float4 xn;
+          xn.x = (xr.x * D[0] + xr.y * D[4]) + xr.z * D[8];
+          xn.y = (xr.x * D[1] + xr.y * D[5]) + xr.z * D[9];
+          xn.z = (xr.x * D[2] + xr.y * D[6]) + xr.z * D[10];
+          xn.w = ((xr.x * D[3] + xr.y * D[7]) + xr.z * D[11]) + xr.w;
+          xn.x = ok ? xn.x : xr.x;  // (component by component: a select between the two structs goes through scratch)
+          xn.y = ok ? xn.y : xr.y;
+          xn.z = ok ? xn.z : xr.z;
+          xn.w = ok ? xn.w : xr.w;
+          const uint32_t changed = (__float_as_uint(xn.x) ^ __float_as_uint(xr.x)) | (__float_as_uint(xn.y) ^ __float_as_uint(xr.y)) |
+                                   (__float_as_uint(xn.z) ^ __float_as_uint(xr.z)) | (__float_as_uint(xn.w) ^ __float_as_uint(xr.w));
+          const bool any_changed = (__ballot(changed != 0u) & 7ull) != 0ull;
+          // points -> camera: X, or sensor_in_robot^-1 * X
+          float4 an = xn;
+          if (g.a.with_sensor) {
+            const float4 sr = *reinterpret_cast<const float4*>(&sh.Sinv[4 * prow]);
+            const float4 x0 = {bcast(xn.x, 0), bcast(xn.y, 0), bcast(xn.z, 0), bcast(xn.w, 0)};
+            const float4 x1 = {bcast(xn.x, 1), bcast(xn.y, 1), bcast(xn.z, 1), bcast(xn.w, 1)};
+            const float4 x2 = {bcast(xn.x, 2), bcast(xn.y, 2), bcast(xn.z, 2), bcast(xn.w, 2)};
+            an.x = (sr.x * x0.x + sr.y * x1.x) + sr.z * x2.x;
+            an.y = (sr.x * x0.y + sr.y * x1.y) + sr.z * x2.y;
+            an.z = (sr.x * x0.z + sr.y * x1.z) + sr.z * x2.z;
+            an.w = ((sr.x * x0.w + sr.y * x1.w) + sr.z * x2.w) + sr.w;
+          }
+          const float rs = (an.x + an.y) + (an.z + an.w);
+          const float fs = (bcast(rs, 0) + bcast(rs, 1)) + bcast(rs, 2);  // pose_is_finite's sum
+          if (lane < 3) {
+            *reinterpret_cast<float4*>(&sh.X[4 * lane]) = xn;
+            *reinterpret_cast<float4*>(&sh.A[4 * lane]) = an;
+          }
+          if (stid == 0) {
+            sh.stop    = (g.a.stop_at_fixed_point && !any_changed && (sh.converged || inlier_run)) ? 1 : 0;
+            sh.pose_ok = (fs - fs) == 0.0f ? 1 : 0;
+          }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
