@@ -1051,7 +1051,8 @@ float orc_mean_disparity(const float* fixed_uvuv, int n) {
  * correspondence vector, see orc_sum128_* below. */
 
 /* Fixed-shape sum of a sequence t_0, t_1, ... (float, round to nearest):
- *   leaf[l] (l = 0..127)  = ((+0 + t_l) + t_{l+128}) + t_{l+256} ...        (terms of index = l mod 128, in order)
+ *   leaf[l] (l = 0..127)  = ((+0 + t_l) + t_{l+128}) + t_{l+256} ...        (terms of index = l mod 128, in order;
+ *                           a term that is a sum of products enters through fused multiply-adds, orc_sum128_fma3)
  *   seven pairwise levels  v[l] <- v[l] + v[l ^ m]  for m = 32, 16, 8, 7, 2, 1, 64 (in this order)
  *   result                 = v[0] + 0.0f                                     (the sign of a zero sum is +)
  * i.e. 128 interleaved partial sums followed by a balanced binary tree (every level pairs clusters of equal
@@ -1073,6 +1074,12 @@ static void orc_sum128_init(orc_sum128* s) {
 
 static inline void orc_sum128_add(orc_sum128* s, int index, float term) {
   s->leaf[index & (ORC_SUM_LEAVES - 1)] += term;
+}
+
+/* leaf <- a2*b2 + (a1*b1 + (a0*b0 + leaf)), one rounding per product-sum */
+static inline void orc_sum128_fma3(orc_sum128* s, int index, float a0, float b0, float a1, float b1, float a2, float b2) {
+  float* leaf = &s->leaf[index & (ORC_SUM_LEAVES - 1)];
+  *leaf       = fmaf(a2, b2, fmaf(a1, b1, fmaf(a0, b0, *leaf)));
 }
 
 static float orc_sum128_result(const orc_sum128* s) {
@@ -1194,36 +1201,37 @@ void orc_linearize_ex(const orc_aligner_params* P,
       }
     }
 
-    /* Jp = R * [ wt*I | -2 [p]x ]  (3x6) */
+    /* J = D * R * [ wt*I | -2 [p]x ]  (3x6), D = d(image point)/d(point in camera):
+     *   row 0 (u):  (fx/z, 0, (cx - u)/z)     row 1 (v):  (0, fy/z, (cy - v)/z)
+     *   row 2:      stereo (uR): (fx/z, 0, (cx - uR)/z); depth: (0, 0, 1); mono: none.
+     * Evaluated as Q = D * R (three 3-vectors), then J_i = ( wt * Q_i | a x Q_i ) with a = 2 p
+     * (Q_i * (-2 [p]x) = a x Q_i).  BUILD-DEFINED operation order, one rounding per line. */
     const float ax = 2.0f * px, ay = 2.0f * py, az = 2.0f * pz;
-    float Jp[3][6];
     const float Rm[3][3] = {{R00, R01, R02}, {R10, R11, R12}, {R20, R21, R22}};
-    for (int r = 0; r < 3; ++r) {
-      Jp[r][0] = Rm[r][0] * wt;
-      Jp[r][1] = Rm[r][1] * wt;
-      Jp[r][2] = Rm[r][2] * wt;
-      Jp[r][3] = fmaf(Rm[r][2], ay, -(Rm[r][1] * az));
-      Jp[r][4] = fmaf(Rm[r][0], az, -(Rm[r][2] * ax));
-      Jp[r][5] = fmaf(Rm[r][1], ax, -(Rm[r][0] * ay));
-    }
-    /* A = K * Jp; J = J_div(h) * A */
-    const float hx_iz2 = (hx * iz) * iz;
-    const float hy_iz2 = (hy * iz) * iz;
-    const float hr_iz2 = (hrx * iz) * iz;
-    float J[3][6];
-    for (int c = 0; c < 6; ++c) {
-      const float a0 = fmaf(fx, Jp[0][c], cx * Jp[2][c]);
-      const float a1 = fmaf(fy, Jp[1][c], cy * Jp[2][c]);
-      const float a2 = Jp[2][c];
-      J[0][c]        = fmaf(a0, iz, -(hx_iz2 * a2));
-      J[1][c]        = fmaf(a1, iz, -(hy_iz2 * a2));
+    const float alpha = fx * iz, gamma = fy * iz;
+    const float beta0 = (cx - u_pred) * iz;
+    const float beta1 = (cy - v_pred) * iz;
+    const float beta2 = (cx - hrx * iz) * iz; /* stereo only */
+    float Q[3][3];
+    for (int c = 0; c < 3; ++c) {
+      Q[0][c] = fmaf(alpha, Rm[0][c], beta0 * Rm[2][c]);
+      Q[1][c] = fmaf(gamma, Rm[1][c], beta1 * Rm[2][c]);
       if (dim == ORC_FACTOR_STEREO) {
-        J[2][c] = fmaf(a0, iz, -(hr_iz2 * a2));
+        Q[2][c] = fmaf(alpha, Rm[0][c], beta2 * Rm[2][c]);
       } else if (dim == ORC_FACTOR_DEPTH) {
-        J[2][c] = a2;
+        Q[2][c] = Rm[2][c];
       } else {
-        J[2][c] = 0.0f;
+        Q[2][c] = 0.0f;
       }
+    }
+    float J[3][6];
+    for (int i = 0; i < 3; ++i) {
+      J[i][0] = Q[i][0] * wt;
+      J[i][1] = Q[i][1] * wt;
+      J[i][2] = Q[i][2] * wt;
+      J[i][3] = fmaf(ay, Q[i][2], -(az * Q[i][1]));
+      J[i][4] = fmaf(az, Q[i][0], -(ax * Q[i][2]));
+      J[i][5] = fmaf(ax, Q[i][1], -(ay * Q[i][0]));
     }
 
     /* Omega = diag(info) * scale(moving) (aligner_slice_processor_projective.cpp:46-56) */
@@ -1255,16 +1263,17 @@ void orc_linearize_ex(const orc_aligner_params* P,
     }
     orc_sum128_add(&sums[28], ic, chi);
 
-    /* H += J^T Omega J (upper), b += J^T Omega e */
+    /* H += J^T Omega J (upper), b += J^T Omega e: the three products of an entry are accumulated into the
+     * correspondence's leaf with fused multiply-adds (leaf <- j0*J0 + leaf, then j1*J1, then j2*J2) */
     int t = 0;
     for (int r = 0; r < 6; ++r) {
       const float j0 = J[0][r] * o[0];
       const float j1 = J[1][r] * o[1];
       const float j2 = J[2][r] * o[2];
       for (int c = r; c < 6; ++c) {
-        orc_sum128_add(&sums[t++], ic, fmaf(j2, J[2][c], fmaf(j1, J[1][c], j0 * J[0][c])));
+        orc_sum128_fma3(&sums[t++], ic, j0, J[0][c], j1, J[1][c], j2, J[2][c]);
       }
-      orc_sum128_add(&sums[21 + r], ic, fmaf(j2, e[2], fmaf(j1, e[1], j0 * e[0])));
+      orc_sum128_fma3(&sums[21 + r], ic, j0, e[0], j1, e[1], j2, e[2]);
     }
   }
   int t = 0;

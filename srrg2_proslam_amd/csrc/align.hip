@@ -63,6 +63,10 @@ struct AlignShared {
   int wave_tot[16];
 };
 
+static_assert(offsetof(AlignShared, b) == offsetof(AlignShared, H) + 36 * sizeof(float) && offsetof(AlignShared, chi_in) == offsetof(AlignShared, b) + 6 * sizeof(float) &&
+                offsetof(AlignShared, chi_tot) == offsetof(AlignShared, chi_in) + sizeof(float),
+              "the summed slots are written through AlignShared::H");
+
 // split pipeline (search kernel + GN kernel alternate until every frame is done): per-frame control word
 struct FrameCtl {
   int it_align;     // aligner iterations whose GN step has been applied
@@ -84,7 +88,6 @@ struct AlignArgs {
   int rows_table;  // R = projector canvas rows (lattice row table extent)
   int lut_cap;     // entries of the circle width table
   int cell_sy, cell_sx, cell_ncx, cell_ncy, ncells;  // 2-D cell grid over the canvas (cells of 2^sy rows x 2^sx cols)
-  uint2* cand;     // scratch [batch][moving_stride]
   float4* ops;     // split pipeline: [batch][max_fixed][2] per-correspondence operands (fixed measurement, moving point)
   FrameCtl* ctl;   // split pipeline: [batch]
   int* pending;    // split pipeline: number of frames the last GN launch left unfinished
@@ -175,7 +178,7 @@ __host__ __device__ __forceinline__ int inlier_run_length(const prs_aligner_para
 struct PoseRegs {
   float R00, R01, R02, t0, R10, R11, R12, t1, R20, R21, R22, t2;
 };
-// factor_terms runs its arithmetic on every lane; a pose with a NaN / inf entry (every correspondence is then
+// factor_accumulate runs its arithmetic on every lane; a pose with a NaN / inf entry (every correspondence is then
 // invalid: no term, no update) is kept away from it by its callers
 __device__ __forceinline__ bool pose_is_finite(const PoseRegs& X) {
   const float s = ((((X.R00 + X.R01) + (X.R02 + X.t0)) + ((X.R10 + X.R11) + (X.R12 + X.t1))) + ((X.R20 + X.R21) + (X.R22 + X.t2)));
@@ -197,25 +200,30 @@ __device__ __forceinline__ float inverse_depth_weight(const float4 z, const floa
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kPairs = 16;  // the 29 sums + 3 class counts of one linearisation travel as 16 float pairs (32 "slots")
 // slot (= 2 * pair + component) -> meaning.  The upper triangle of J^T Omega J is produced row by row as float pairs
-// (v_pk_fma_f32); where a row starts on the second element of a pair, the first element would be the mirrored entry:
-// those three places carry the class indicators (1.0f / 0.0f: inlier, kernelised, invalid), so that the class counts
-// come out of the same reduction as exact small integers.
-//    0..5   H00 H01 H02 H03 H04 H05      6  #inliers     7..11  H11 H12 H13 H14 H15
-//   12..15  H22 H23 H24 H25             16  #kernelised 17..19  H33 H34 H35
-//   20..21  H44 H45                     22  #invalid    23      H55
+// (v_pk_fma_f32); where a row starts on the second element of a pair, the first element is the mirrored entry and is
+// not used.  The first of those three places carries the class counts into the reduction: #inliers + kClsOutUnit *
+// #kernelised as one float (an exact integer below 2^24, so its sum does not depend on the order).
+//    0..5   H00 H01 H02 H03 H04 H05      6  class counts  7..11  H11 H12 H13 H14 H15
+//   12..15  H22 H23 H24 H25             16  -            17..19  H33 H34 H35
+//   20..21  H44 H45                     22  -            23      H55
 //   24..29  b0..b5                      30  chi (inliers only)   31  chi (all, kernelised ones saturated)
-constexpr int kSlotInl = 6, kSlotOut = 16, kSlotInv = 22;
+constexpr float kClsOutUnit = 2048.0f;  // > the largest number of correspondences of a frame handled here (1024)
+constexpr int kSlotCls = 6, kSlotUnusedA = 16, kSlotUnusedB = 22;
 
 // One correspondence of SE3{,Depth,RectifiedStereo}ProjectiveErrorFactor::errorAndJacobian + saturated robustifier,
-// as the 16 pairs above.  cls: 0 inlier, 1 kernelised, 2 invalid (behind the camera / outside the image), 3 inactive.
+// ACCUMULATED into the 16 pairs above (the running sums of this lane's leaf of the fixed-shape sum): every entry of
+// J^T Omega J and J^T Omega e enters through three fused multiply-adds, acc <- j0 * J0 + acc, then j1 * J1, then j2 * J2.
+// cls: 0 inlier, 1 kernelised, 2 invalid (behind the camera / outside the image), 3 inactive.
+// J = D * R * [ wt I | -2 [p]x ] with D = d(image point) / d(point in camera) is evaluated as Q = D * R (three 3-vectors)
+// and J_i = ( wt Q_i | a x Q_i ), a = 2 p.
 template <int DIM = 0, bool PRE_WT = false>
-__device__ __forceinline__ void factor_pairs(const prs_aligner_params& a, const PoseRegs& X, const float4 z, const float4 p_in,
-                                             const float mean_dsp, const bool active, f2* P, int& cls, const bool inlier_only = false) {
+__device__ __forceinline__ void factor_accumulate(const prs_aligner_params& a, const PoseRegs& X, const float4 z, const float4 p_in,
+                                                  const float mean_dsp, const bool active, f2* acc, float& code, int& cls, const bool inlier_only = false) {
   // Straight-line on purpose: with the terms live out of nested divergent branches the compiler re-materialises
   // all zeros at every nesting level.  A correspondence that is inactive (slot past the end) or invalid (behind the
   // camera / outside the image) runs the same arithmetic on harmless stand-in values (point 0, image point 0,
-  // inverse depth 0) with zero information and zero error: every term is then +-0, and a fixed-shape sum that is
-  // normalised with + 0.0f at its root does not see the sign of a zero term.  Valid correspondences execute exactly
+  // inverse depth 0) with zero information and zero error: every product is then +-0, and a fixed-shape sum that is
+  // normalised with + 0.0f at its root does not see the sign of a zero.  Valid correspondences execute exactly
   // the operations of the sequential evaluation.
   const float R00 = X.R00, R01 = X.R01, R02 = X.R02, t0 = X.t0;
   const float R10 = X.R10, R11 = X.R11, R12 = X.R12, t1 = X.t1;
@@ -230,17 +238,18 @@ __device__ __forceinline__ void factor_pairs(const prs_aligner_params& a, const 
   const float hx_r = fmaf(fx, pcx, cx * pcz);
   const float hy_r = fmaf(fy, pcy, cy * pcz);
   const float iz_r = 1.0f / pcz;
-  const float u_pred = hx_r * iz_r, v_pred = hy_r * iz_r;
-  const bool valid   = active && pcz > 0.0f && !(u_pred < 0.0f || u_pred > a.image_cols || v_pred < 0.0f || v_pred > a.image_rows);
+  const float u_r = hx_r * iz_r, v_r = hy_r * iz_r;
+  const bool valid = active && pcz > 0.0f && !(u_r < 0.0f || u_r > a.image_cols || v_r < 0.0f || v_r > a.image_rows);
   // the stand-in of an invalid / inactive correspondence (any finite values do: its information is zero)
   const float px = valid ? p_in.x : 0.0f, py = valid ? p_in.y : 0.0f, pz = valid ? p_in.z : 0.0f;
-  const float hx = valid ? hx_r : 0.0f, hy = valid ? hy_r : 0.0f;
+  const float u_pred = valid ? u_r : 0.0f, v_pred = valid ? v_r : 0.0f;
   const float iz = valid ? iz_r : 0.0f;
   float e0 = u_pred - z.x, e1 = v_pred - z.y, e2 = 0.0f;
-  float hrx = hx;
+  float ur = 0.0f;  // predicted column in the right image
   if (dim == PRS_FACTOR_STEREO) {
-    hrx = hx + a.baseline_left_in_right_px[0];
-    e2  = fmaf(hrx, iz, -z.z);
+    const float hrx = (valid ? hx_r : 0.0f) + a.baseline_left_in_right_px[0];
+    e2              = fmaf(hrx, iz, -z.z);
+    ur              = hrx * iz;
   } else if (dim == PRS_FACTOR_DEPTH) {
     e2 = pcz - z.z;
   }
@@ -252,32 +261,42 @@ __device__ __forceinline__ void factor_pairs(const prs_aligner_params& a, const 
     wt = PRE_WT ? z.w : inverse_depth_weight(z, mean_dsp);
     wt = valid ? wt : 1.0f;
   }
-  const float ax = 2.0f * px, ay = 2.0f * py, az = 2.0f * pz;
-  const float Rm[3][3] = {{R00, R01, R02}, {R10, R11, R12}, {R20, R21, R22}};
-  // From here on the six columns of the Jacobian rows travel as three float pairs: the element-wise
-  // steps map onto v_pk_mul_f32 / v_pk_fma_f32 (IEEE per lane, same results as the scalar forms).
   auto fma2 = [](f2 x, f2 y, f2 z2) -> f2 { return __builtin_elementwise_fma(x, y, z2); };
-  f2 Jp[3][3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    Jp[r][0] = f2{Rm[r][0] * wt, Rm[r][1] * wt};
-    Jp[r][1] = f2{Rm[r][2] * wt, fmaf(Rm[r][2], ay, -(Rm[r][1] * az))};
-    Jp[r][2] = f2{fmaf(Rm[r][0], az, -(Rm[r][2] * ax)), fmaf(Rm[r][1], ax, -(Rm[r][0] * ay))};
+  // Q = D * R, rows as (pair of columns 0 1, column 2)
+  const float alpha = fx * iz, gamma = fy * iz;
+  const float beta0 = (cx - u_pred) * iz;
+  const float beta1 = (cy - v_pred) * iz;
+  const float beta2 = (cx - ur) * iz;
+  const f2 R0p = {R00, R01}, R1p = {R10, R11}, R2p = {R20, R21};
+  f2 Qp[3];     // (Q_i0, Q_i1)
+  float Qz[3];  // Q_i2
+  Qp[0] = fma2(f2{alpha, alpha}, R0p, f2{beta0, beta0} * R2p);
+  Qz[0] = fmaf(alpha, R02, beta0 * R22);
+  Qp[1] = fma2(f2{gamma, gamma}, R1p, f2{beta1, beta1} * R2p);
+  Qz[1] = fmaf(gamma, R12, beta1 * R22);
+  if (dim == PRS_FACTOR_STEREO) {
+    Qp[2] = fma2(f2{alpha, alpha}, R0p, f2{beta2, beta2} * R2p);
+    Qz[2] = fmaf(alpha, R02, beta2 * R22);
+  } else if (dim == PRS_FACTOR_DEPTH) {
+    Qp[2] = R2p;
+    Qz[2] = R22;
+  } else {
+    Qp[2] = f2{0.0f, 0.0f};
+    Qz[2] = 0.0f;
   }
-  const float hx_iz2 = (hx * iz) * iz;
-  const float hy_iz2 = (hy * iz) * iz;
-  const float hr_iz2 = (hrx * iz) * iz;
-  const f2 fx2 = {fx, fx}, fy2 = {fy, fy}, cx2 = {cx, cx}, cy2 = {cy, cy}, iz2 = {iz, iz};
-  const f2 hx2 = {hx_iz2, hx_iz2}, hy2 = {hy_iz2, hy_iz2}, hr2 = {hr_iz2, hr_iz2};
-  f2 J0[3], J1[3], J2[3];
+  // J_i = ( wt Q_i | a x Q_i ) as three pairs: (J_i0 J_i1) (J_i2 J_i3) (J_i4 J_i5).  The operand pairs are laid out so that
+  // no value has to sit in two register positions (a packed operation reads aligned register pairs; a scalar one any register):
+  //   (J_i2, J_i3) = (wt, ay) * Q_i2 - (0, az) * Q_i1        (wt * Q_i2 - 0 = wt * Q_i2 exactly)
+  //   (J_i4, J_i5) = (az, ax) * (Q_i0, Q_i1) - (ax * Q_i2, ay * Q_i0)
+  const f2 c_wt_ay = {wt, 2.0f * py};
+  const f2 c_0_az  = {0.0f, 2.0f * pz};
+  const f2 c_az_ax = {2.0f * pz, 2.0f * px};
+  f2 J[3][3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const f2 a0 = fma2(fx2, Jp[0][k], cx2 * Jp[2][k]);
-    const f2 a1 = fma2(fy2, Jp[1][k], cy2 * Jp[2][k]);
-    const f2 a2 = Jp[2][k];
-    J0[k]       = fma2(a0, iz2, -(hx2 * a2));
-    J1[k]       = fma2(a1, iz2, -(hy2 * a2));
-    J2[k]       = dim == PRS_FACTOR_STEREO ? fma2(a0, iz2, -(hr2 * a2)) : (dim == PRS_FACTOR_DEPTH ? a2 : f2{0.0f, 0.0f});
+  for (int i = 0; i < 3; ++i) {
+    J[i][0] = Qp[i] * f2{wt, wt};
+    J[i][1] = fma2(c_wt_ay, f2{Qz[i], Qz[i]}, -(c_0_az * f2{Qp[i].y, Qp[i].y}));
+    J[i][2] = fma2(c_az_ax, Qp[i], -f2{c_az_ax.y * Qz[i], c_wt_ay.y * Qp[i].x});
   }
   // Omega = diag(info) * scale(moving point) (aligner_slice_processor_projective.cpp:46-56)
   const float s = valid ? p_in.w : 0.0f;
@@ -292,18 +311,20 @@ __device__ __forceinline__ void factor_pairs(const prs_aligner_params& a, const 
   o0 *= scale;
   o1 *= scale;
   o2 *= scale;
-  chi    = saturated ? a.chi_threshold : chi;
-  cls    = !active ? 3 : (!valid ? 2 : (saturated ? 1 : 0));
-  P[15]  = f2{saturated ? 0.0f : chi, chi};
+  chi = saturated ? a.chi_threshold : chi;
+  cls = !active ? 3 : (!valid ? 2 : (saturated ? 1 : 0));
+  acc[15] += f2{saturated ? 0.0f : chi, chi};
   const f2 o02 = {o0, o0}, o12 = {o1, o1}, o22 = {o2, o2}, e02 = {e0, e0}, e12 = {e1, e1}, e22 = {e2, e2};
   f2 j0[3], j1[3], j2[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    j0[k]     = J0[k] * o02;
-    j1[k]     = J1[k] * o12;
-    j2[k]     = J2[k] * o22;
-    P[12 + k] = fma2(j2[k], e22, fma2(j1[k], e12, j0[k] * e02));
+    j0[k]       = J[0][k] * o02;
+    j1[k]       = J[1][k] * o12;
+    j2[k]       = J[2][k] * o22;
+    acc[12 + k] = fma2(j2[k], e22, fma2(j1[k], e12, fma2(j0[k], e02, acc[12 + k])));
   }
+  // class counts: one exact small-integer code per correspondence, 1 for an inlier, kClsOutUnit for a kernelised one
+  code += valid ? (saturated ? kClsOutUnit : 1.0f) : 0.0f;
   // the upper triangle of J^T Omega J row by row
   int t = 0;
 #pragma unroll
@@ -314,36 +335,10 @@ __device__ __forceinline__ void factor_pairs(const prs_aligner_params& a, const 
     const f2 r0 = {a0, a0}, r1 = {a1, a1}, r2 = {a2, a2};
 #pragma unroll
     for (int k = r >> 1; k < 3; ++k) {
-      P[t++] = fma2(r2, J2[k], fma2(r1, J1[k], r0 * J0[k]));
+      acc[t] = fma2(r2, J[2][k], fma2(r1, J[1][k], fma2(r0, J[0][k], acc[t])));  // (mirrored first elements: not used)
+      ++t;
     }
   }
-  // class indicators in the places of the three mirrored entries
-  P[kSlotInl >> 1].x = (valid && !saturated) ? 1.0f : 0.0f;
-  P[kSlotOut >> 1].x = saturated ? 1.0f : 0.0f;
-  P[kSlotInv >> 1].x = (active && !valid) ? 1.0f : 0.0f;
-}
-
-// the 29 terms of one correspondence in the order of the normal-equation sums (21 H upper triangle row-major, 6 b,
-// chi of the inliers, chi of all): the fused kernel's form of factor_pairs
-template <int DIM = 0, bool PRE_WT = false>
-__device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const PoseRegs& X, const float4 z, const float4 p_in,
-                                             const float mean_dsp, const bool active, float* tv, int& cls, const bool inlier_only = false) {
-  f2 P[kPairs];
-  factor_pairs<DIM, PRE_WT>(a, X, z, p_in, mean_dsp, active, P, cls, inlier_only);
-  int t = 0;
-#pragma unroll
-  for (int slot = 0; slot < 24; ++slot) {
-    if (slot != kSlotInl && slot != kSlotOut && slot != kSlotInv) {
-      tv[t++] = (slot & 1) ? P[slot >> 1].y : P[slot >> 1].x;
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    tv[21 + 2 * k] = P[12 + k].x;
-    tv[22 + 2 * k] = P[12 + k].y;
-  }
-  tv[27] = P[15].x;
-  tv[28] = P[15].y;
 }
 
 // ---- the fixed-shape sum of the normal equations (defined in include/proslam_hip.h, prs_align_result) --------------
@@ -353,7 +348,6 @@ __device__ __forceinline__ void factor_terms(const prs_aligner_params& a, const 
 // v_permlane32_swap / v_permlane16_swap exchanges, 8 / 7 / 2 / 1 are DPP reads inside a row of 16 lanes (row_ror:8,
 // row_half_mirror, two quad_perm), 64 is the add across the two waves.  The reduction is "transposed": a lane gives
 // away half of its slots at every level, so 32 slots cost 16 + 8 + 4 + 2 + 1 + 1 adds per lane instead of 32 * 6.
-constexpr int kSumLevelMasks[7] = {32, 16, 8, 7, 2, 1, 64};
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_read(float x) {
@@ -400,6 +394,27 @@ __device__ __forceinline__ float wave_sum_slots(f2* acc, const int lane) {
   return q + dpp_read<0xB1>(q);                                                // quad_perm [1,0,3,2] = lane ^ 1
 }
 
+// where the lane that ends up with summed slot `slot` puts it, as a float index from the H member of the kernel's shared state (H[36], b[6], chi of the inliers, chi of all, then GnShared's three class counts) (`mirror`: the lower-triangle twin)
+__device__ __forceinline__ int gn_slot_destination(const int slot, const bool mirror) {
+  if (slot >= 24) {
+    return 36 + (slot - 24);  // b0..b5, chi_in, chi_tot
+  }
+  if (slot == kSlotCls) {
+    return 44;  // the class-count code
+  }
+  if (slot == kSlotUnusedA) {
+    return 45;  // (mirrored entries: parked next to it, never read)
+  }
+  if (slot == kSlotUnusedB) {
+    return 46;
+  }
+  // rows of the upper triangle start at slots 0, 6 (+1), 12, 16 (+1), 20, 22 (+1): row r holds columns (r & ~1) .. 5
+  const int r     = slot < 6 ? 0 : (slot < 12 ? 1 : (slot < 16 ? 2 : (slot < 20 ? 3 : (slot < 22 ? 4 : 5))));
+  const int first = r == 0 ? 0 : (r == 1 ? 6 : (r == 2 ? 12 : (r == 3 ? 16 : (r == 4 ? 20 : 22))));
+  const int c     = (r & ~1) + (slot - first);
+  return mirror ? 6 * c + r : 6 * r + c;
+}
+
 // SPLIT = the search half of the split pipeline (mode kModeSplitSearch): a compile-time flag, so the
 // Gauss-Newton code (and its registers) is not part of that instantiation
 // STYPE: the search pattern as a compile-time constant (-1 = read it from the parameters), so that the search
@@ -423,7 +438,6 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
   const au32x4* __restrict__ gfd  = reinterpret_cast<const au32x4*>(g.b.fixed_desc + fbase * PRS_DESC_BYTES);
   const au32x4* __restrict__ gmd  = reinterpret_cast<const au32x4*>(g.b.moving_desc + mbase * PRS_DESC_BYTES);
   prs_corr* __restrict__ gcorr    = g.b.corr + fbase;
-  uint2* __restrict__ cand        = g.cand + mbase;
   prs_pcf_state* gstate           = g.b.state + frame;
   prs_align_result* gres          = g.b.result + frame;
 
@@ -834,6 +848,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
           }
         }
         __syncthreads();
+        SUB_ACC(acc_pass2);  // staging: candidate keys, fixed descriptor rows -> LDS
         {
           const float W0 = sh.W[0], W1 = sh.W[1], W2 = sh.W[2], W3 = sh.W[3];
           const float W4 = sh.W[4], W5 = sh.W[5], W6 = sh.W[6], W7 = sh.W[7];
@@ -981,16 +996,25 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                   cd.y = (uint32_t) inv[seck & 0xffffu] | ((seck >> 16) << 16);
                 }
               }
-              // _addCorrespondenceCandidate (:8-37): order-independent reduction on
-              // (response, insertion order = (moving index, best before second best))
+              // _addCorrespondenceCandidate (:8-37) + the per-fixed best / second-lowest response of _filterCorrespondences
+              // (:57-68), order-independent: keys are (response, insertion order = (moving index, best before second best));
+              // atomicMin returns the value it met, and whichever of the two is not the new minimum has lost for good, so
+              // second[] ends up as the minimum response over everything but the winner without a second pass
+              auto emit = [&](const uint32_t c, const uint32_t tag) {
+                const uint32_t f   = c & 0xffffu;
+                const uint32_t key = ((c >> 16) << 17) | ((uint32_t) m << 1) | tag;
+                const uint32_t old = atomicMin(&bestkey[f], key);
+                if (old != kNoneU32) {
+                  atomicMin(&second[f], (old > key ? old : key) >> 17);
+                }
+              };
               if (cd.x != kNoneU32) {
-                atomicMin(&bestkey[cd.x & 0xffffu], ((cd.x >> 16) << 17) | ((uint32_t) m << 1));
+                emit(cd.x, 0u);
               }
               if (cd.y != kNoneU32) {
-                atomicMin(&bestkey[cd.y & 0xffffu], ((cd.y >> 16) << 17) | ((uint32_t) m << 1) | 1u);
+                emit(cd.y, 1u);
               }
             }
-            cand[m] = cd;
            }
           }
           if (projected) {
@@ -999,24 +1023,6 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
         }
         __syncthreads();
         SUB_ACC(acc_search);
-        // -- second lowest response per fixed index (:57-68): minimum over everything but the winner
-        for (int m = tid; m < nM; m += T) {
-          const uint2 cd = cand[m];
-          if (cd.x != kNoneU32) {
-            const uint32_t key = ((cd.x >> 16) << 17) | ((uint32_t) m << 1);
-            if (key != bestkey[cd.x & 0xffffu]) {
-              atomicMin(&second[cd.x & 0xffffu], cd.x >> 16);
-            }
-          }
-          if (cd.y != kNoneU32) {
-            const uint32_t key = ((cd.y >> 16) << 17) | ((uint32_t) m << 1) | 1u;
-            if (key != bestkey[cd.y & 0xffffu]) {
-              atomicMin(&second[cd.y & 0xffffu], cd.y >> 16);
-            }
-          }
-        }
-        __syncthreads();
-        SUB_ACC(acc_pass2);
         // -- _filterCorrespondences (:41-102) in ascending fixed index; second[] is recycled to hold
         //    the output slot of accepted entries
         {
@@ -1173,8 +1179,6 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
       // a pose with a NaN / inf entry: every correspondence is invalid, all sums stay zero
       const bool pose_ok   = __all(pose_is_finite(pose));  // (uniform by construction; __all makes the branch scalar)
       if (tid == 0) {
-        sh.n_inl = sh.n_out = 0;
-        sh.n_inv = pose_ok ? 0 : nc;
         sh.have_cls = 1;
       }
       if (!pose_ok) {
@@ -1182,72 +1186,51 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
           clsbuf[c] = 2;
         }
       }
-      // the fixed-shape sum of the 29 normal-equation terms (include/proslam_hip.h, prs_align_result): 128 leaves per term in LDS, leaf l = the
-      // terms of the correspondences l, l + 128, l + 256, ... added in that order
-      for (int i = tid; i < kTerms * 128; i += T) {
-        terms[i] = 0.0f;
-      }
-      __syncthreads();
-      for (int c0 = 0; c0 < nc && pose_ok; c0 += T) {
-        ALIGN_MARK();
-        const int c = c0 + tid;
-        float tv[kTerms];
-        int cls;
-        const int cc = c < nc ? c : 0;
-        factor_terms(g.a, pose, cfix[cc], cmov[cc], mean_dsp, c < nc, tv, cls, inlier_run);
-        if (c < nc) {
-          atomicAdd(cls == 0 ? &sh.n_inl : (cls == 1 ? &sh.n_out : &sh.n_inv), 1);
-          clsbuf[c] = (uint8_t) cls;
-        }
-        ALIGN_ACC(acc_lin);
-        ALIGN_MARK();
-        // thread tid holds correspondence c0 + tid: the T / 128 groups of 128 threads add to the leaves one after the other
-#pragma unroll 1
-        for (int grp = 0; grp < T / 128; ++grp) {
-          if ((tid >> 7) == grp) {
+      // the fixed-shape sum of the normal equations (include/proslam_hip.h, prs_align_result), exactly as the split
+      // pipeline's Gauss-Newton kernel evaluates it: the first 128 threads own one leaf each (running sums in registers,
+      // correspondences l, l + 128, ... in order), six exchange levels inside each of the two waves, the seventh through LDS
+      ALIGN_MARK();
+      float tot = 0.0f;
+      if (tid < 128) {
+        f2 acc[kPairs];
 #pragma unroll
-            for (int t = 0; t < kTerms; ++t) {
-              terms[t * 128 + (tid & 127)] += tv[t];
+        for (int i = 0; i < kPairs; ++i) {
+          acc[i] = f2{0.0f, 0.0f};
+        }
+        float code = 0.0f;
+        if (pose_ok) {
+          for (int c0 = 0; c0 < nc; c0 += 128) {
+            const int c  = c0 + tid;
+            const int cc = c < nc ? c : 0;
+            int cls;
+            factor_accumulate(g.a, pose, cfix[cc], cmov[cc], mean_dsp, c < nc, acc, code, cls, inlier_run);
+            if (c < nc) {
+              clsbuf[c] = (uint8_t) cls;
             }
           }
-          __syncthreads();
         }
-        ALIGN_ACC(acc_sum);
+        acc[kSlotCls >> 1].x = code;  // (a pose that is not finite: no inlier, no kernelised factor, everything invalid)
+        tot = wave_sum_slots(acc, lane);
+        if (wave == 1) {
+          terms[(lane >> 1) & 31] = tot;
+        }
       }
+      ALIGN_ACC(acc_lin);
+      __syncthreads();
       ALIGN_MARK();
-      // seven pairwise levels v[l] <- v[l] + v[l ^ m]; a pair is handled by the partner whose bit (highest bit of m) is clear
-#pragma unroll 1
-      for (int lev = 0; lev < 7; ++lev) {
-        const int m  = kSumLevelMasks[lev];
-        const int hb = 31 - __clz(m);
-        for (int i = tid; i < kTerms * 64; i += T) {
-          const int t   = i >> 6, q = i & 63;
-          const int l   = ((q >> hb) << (hb + 1)) | (q & ((1 << hb) - 1));
-          float* row    = terms + t * 128;
-          const float v = row[l] + row[l ^ m];
-          row[l]        = v;
-          row[l ^ m]    = v;
-        }
-        __syncthreads();
-      }
-      if (tid < kTerms) {
-        const float run = terms[tid * 128] + 0.0f;  // the root: a zero sum is +0
-        if (tid < 21) {
-          // upper-triangle index -> (r, k)
-          int r = 0, first = 0;
-          while (tid >= first + (6 - r)) {
-            first += 6 - r;
-            ++r;
+      if (wave == 0) {
+        const int slot = (lane >> 1) & 31;
+        tot            = tot + terms[slot];
+        tot            = tot + 0.0f;  // the root: a zero sum is +0
+        if (slot == kSlotCls) {
+          if ((lane & 1) == 0) {
+            const int cc = (int) tot;  // #inliers + kClsOutUnit * #kernelised
+            sh.n_inl     = cc & ((int) kClsOutUnit - 1);
+            sh.n_out     = cc / (int) kClsOutUnit;
+            sh.n_inv     = nc - sh.n_inl - sh.n_out;
           }
-          const int k       = r + (tid - first);
-          sh.H[6 * r + k]   = run;
-          sh.H[6 * k + r]   = run;
-        } else if (tid < 27) {
-          sh.b[tid - 21] = run;
-        } else if (tid == 27) {
-          sh.chi_in = run;
-        } else {
-          sh.chi_tot = run;
+        } else if (slot != kSlotUnusedA && slot != kSlotUnusedB) {
+          (&sh.H[0])[gn_slot_destination(slot, (lane & 1) != 0)] = tot;  // H (both triangles), b, chi_in, chi_tot
         }
       }
       __syncthreads();
@@ -1420,7 +1403,7 @@ struct GnShared {
   // destinations of the 32 summed slots, consecutive: H (both triangles), b, chi (inliers), chi (all), the three class counts
   float H[36], b[6];
   float chi_in, chi_tot;
-  float fcnt[3];   // #inliers, #kernelised, #invalid of the last linearisation (exact small integers)
+  float fcnt[3];   // [0]: #inliers + kClsOutUnit * #kernelised of the last linearisation (an exact integer); [1], [2]: not used
   float pad0;
   float A[16];     // points -> camera: X, or sensor_in_robot^-1 * X
   float Sinv[16];
@@ -1433,27 +1416,6 @@ struct GnShared {
 static_assert(offsetof(GnShared, b) == offsetof(GnShared, H) + 36 * sizeof(float) && offsetof(GnShared, chi_in) == offsetof(GnShared, b) + 6 * sizeof(float) &&
                 offsetof(GnShared, chi_tot) == offsetof(GnShared, chi_in) + sizeof(float) && offsetof(GnShared, fcnt) == offsetof(GnShared, chi_tot) + sizeof(float),
               "the summed slots are written through GnShared::H");
-
-// where the lane that ends up with summed slot `slot` puts it, as a float index from GnShared::H (`mirror`: the lower-triangle twin)
-__device__ __forceinline__ int gn_slot_destination(const int slot, const bool mirror) {
-  if (slot >= 24) {
-    return 36 + (slot - 24);  // b0..b5, chi_in, chi_tot
-  }
-  if (slot == kSlotInl) {
-    return 44;
-  }
-  if (slot == kSlotOut) {
-    return 45;
-  }
-  if (slot == kSlotInv) {
-    return 46;
-  }
-  // rows of the upper triangle start at slots 0, 6 (+1), 12, 16 (+1), 20, 22 (+1): row r holds columns (r & ~1) .. 5
-  const int r     = slot < 6 ? 0 : (slot < 12 ? 1 : (slot < 16 ? 2 : (slot < 20 ? 3 : (slot < 22 ? 4 : 5))));
-  const int first = r == 0 ? 0 : (r == 1 ? 6 : (r == 2 ? 12 : (r == 3 ? 16 : (r == 4 ? 20 : 22))));
-  const int c     = (r & ~1) + (slot - first);
-  return mirror ? 6 * c + r : 6 * r + c;
-}
 
 // the aligner loop after iteration `it_align` has been executed: the next iteration's index, and whether the frame is
 // finished (MultiAligner3DQR stand-in: max_iterations, then the inlier-only run if there are enough inliers)
@@ -1629,6 +1591,11 @@ __global__ __launch_bounds__(128, 4) void gn_kernel(const AlignArgs g) {
       // a pose with a NaN / inf entry: every correspondence is invalid, all sums stay zero
       const bool pose_ok  = __builtin_amdgcn_readfirstlane(sh.pose_ok) != 0;
       f2 acc[kPairs];
+#pragma unroll
+      for (int i = 0; i < kPairs; ++i) {
+        acc[i] = f2{0.0f, 0.0f};
+      }
+      float code = 0.0f;  // class counts of this lane's correspondences (factor_accumulate)
       if (pose_ok) {
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
@@ -1644,33 +1611,22 @@ __global__ __launch_bounds__(128, 4) void gn_kernel(const AlignArgs g) {
               p   = c < nc ? gops[2 * c + 1] : make_float4(0.f, 0.f, 1.f, 1.f);
               z.w = inverse_depth_weight(z, mean_dsp);
             }
-            f2 P[kPairs];
             int cls;
-            factor_pairs<DIM, true>(g.a, pose, z, p, mean_dsp, c < nc, P, cls, inlier_run);
+            factor_accumulate<DIM, true>(g.a, pose, z, p, mean_dsp, c < nc, acc, code, cls, inlier_run);
             if (KEEP_CLS) {
               cls_bits |= (uint32_t) (cls & 3) << (2 * k);
             }
-#pragma unroll
-            for (int i = 0; i < kPairs; ++i) {
-              acc[i] = k == 0 ? P[i] : acc[i] + P[i];
-            }
           }
         }
-      } else {
-#pragma unroll
-        for (int i = 0; i < kPairs; ++i) {
-          acc[i] = f2{0.0f, 0.0f};
-        }
-        int mine = 0;  // this lane's correspondences: all invalid
+      } else if (KEEP_CLS) {
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
           if (k * THREADS + tid < nc) {
-            ++mine;
-            cls_bits |= 2u << (2 * k);
+            cls_bits |= 2u << (2 * k);  // a pose that is not finite: everything is invalid
           }
         }
-        acc[kSlotInv >> 1].x = (float) mine;
       }
+      acc[kSlotCls >> 1].x = code;
       // levels 32, 16, 8, 7, 2, 1 of the fixed-shape sum inside the wave; level 64 across the two waves through LDS
       float tot = wave_sum_slots(acc, lane);
       if (wave != solver) {
@@ -1685,9 +1641,10 @@ __global__ __launch_bounds__(128, 4) void gn_kernel(const AlignArgs g) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (stid == 0) {
-          sh.n_inl = (int) sh.fcnt[0];
-          sh.n_out = (int) sh.fcnt[1];
-          sh.n_inv = (int) sh.fcnt[2];
+          const int cc = (int) sh.fcnt[0];  // #inliers + kClsOutUnit * #kernelised
+          sh.n_inl     = cc & ((int) kClsOutUnit - 1);
+          sh.n_out     = cc / (int) kClsOutUnit;
+          sh.n_inv     = nc - sh.n_inl - sh.n_out;
         }
         // ---- (H + damping I) dx = -b, X <- X * exp(dx) by the lanes of this wave: lane i < 6 owns row i of the system and
         // of the Cholesky factor, lane r < 3 row r of the pose; pivots, substitutions and the perturbation are uniform
@@ -2055,10 +2012,6 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
     return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_run: fixed cloud does not fit the 160 KiB LDS (lower max_fixed)");
   }
   g.stamps = ctx_stamps(ctx, (size_t) batch->batch * 16 * sizeof(unsigned long long));
-  g.cand = static_cast<uint2*>(ctx_device_scratch_slot(ctx, 1, (size_t) batch->batch * (size_t) batch->moving_stride * sizeof(uint2)));
-  if (!g.cand) {
-    return ctx_fail(ctx, PRS_ERR_HIP, "prs_align_batch_run: candidate scratch allocation failed");
-  }
   g.ops     = nullptr;
   g.ctl     = nullptr;
   g.pending = nullptr;
@@ -2082,7 +2035,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
       return ctx_fail_hip(ctx, e, "prs_align_batch_run launch");
     }
     if (g.stamps) {
-      ctx_report_stamps(ctx, batch->batch, 10, "align (fused, 256 threads): finder | linearize | sequential sums | GN solve || of finder: lattice build | projection+search | second-best pass | filter | commit");
+      ctx_report_stamps(ctx, batch->batch, 10, "align (fused, 256 threads): finder | linearize | sequential sums | GN solve || of finder: lattice build | projection+search | staging (keys, fixed rows -> LDS) | filter | commit");
     }
     return PRS_OK;
   }
@@ -2155,7 +2108,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
       hipLaunchKernelGGL(skernel, dim3(batch->batch), dim3(kSearchThreads), lds_search, stream, gs);
       tick();
       if (stamps_split) {
-        ctx_report_stamps(ctx, batch->batch, 10, "search launch (split): - | - | - | - || lattice build | projection+search | second-best pass | filter | commit");
+        ctx_report_stamps(ctx, batch->batch, 10, "search launch (split): - | - | - | - || lattice build | projection+search | staging (keys, fixed rows -> LDS) | filter | commit");
       }
       {
         // (the rectified-stereo factor, the one kitti.conf / euroc.conf use, has its own instantiation: the factor type as a
