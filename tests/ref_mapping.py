@@ -116,14 +116,19 @@ def _merger_params(cfg, variant, est, **kw):
 
 def _seed_map(xyz, desc, image_points, max_meas, capacity):
     """scene = points_in_camera_00 with allocated statistics, state = coordinates (test_mergers.cpp:268-271, :377-380); the smoother
-    cases also add the first camera measurement (:425-433)"""
+    cases also add the first camera measurement (:425-433).  The tests never set a covariance: the landmarks carry whatever
+    PointStatisticsField3D::allocate() leaves (srrg2_core, external).  ZERO is used here: the merger sets Matrix3f::Identity()
+    explicitly on the points IT creates (mergers/merger_projective_impl.cpp:317-319), which would be redundant if allocate() did,
+    and with an identity start the stereo EKF moves a far landmark by 7.5 m on frame 01 where the reference asserts 5
+    (test_mergers.cpp:784-786); from zero the estimator's floor (minimum_state_element_covariance 0.01) applies and every
+    bound of the reference holds (1.6 m)."""
     m = om.Map(capacity, max_meas)
     for i in range(len(xyz)):
         meas = None
         if max_meas > 0:
             meas = np.zeros((), om.MEAS_DTYPE)
             meas["point_in_image"], meas["point_in_camera"], meas["frame"] = image_points[i], xyz[i], 0
-        m.add_landmark(xyz[i], xyz[i], np.eye(3), desc=desc[i], measurement=meas)
+        m.add_landmark(xyz[i], xyz[i], np.zeros((3, 3)), desc=desc[i], measurement=meas)
     return m
 
 
@@ -135,9 +140,10 @@ def merger_cases(B):
     m0, m1 = rp.icl_measurements(B, 0), rp.icl_measurements(B, 1)
     uvd = lambda m: np.concatenate([m["uv"], m["depth"][:, None]], axis=1).astype(np.float32)  # noqa: E731
     cases = []
-    # ICL 00To00 / 00To01_MergerCorrespondenceProjectiveDepthEKF_Sparse (:248-355): MergerProjectiveDepthEKF, 10 x 30 bins, appearance 50
+    # ICL 00To00 / 00To01_MergerCorrespondenceProjectiveDepthEKF_Sparse (:248-355): MergerProjectiveDepthEKF, 10 x 30 bins, appearance 50;
+    # bounds 1e-5 (:293-295) and 0.1 (:351-353)
     for name, meas, corr, d2, want, tol in (("icl_depth_ekf_00_to_00", m0, _identity_corr(321), 1.0, 321, 1e-5),
-                                            ("icl_depth_ekf_00_to_01", m1, icl_ideal_correspondences(m0, m1, rp.icl_relative(1, 0)), 0.01, 337, 0.25)):
+                                            ("icl_depth_ekf_00_to_01", m1, icl_ideal_correspondences(m0, m1, rp.icl_relative(1, 0)), 0.01, 337, 0.1)):
         est = om.estimator_params(om.EST_EKF, 3, Ki, max_dist2=d2)
         p = _merger_params(icl, om.MERGER_DEPTH_EKF, est, row_bins=10, col_bins=30, max_appearance=50.0, target_merges=1000)
         cases.append(dict(name=name, params=p, map=_seed_map(m0["xyz"], m0["desc"], None, 0, 1024), T=I4, fixed=uvd(meas), desc=meas["desc"], corr=corr,
@@ -165,10 +171,9 @@ def merger_cases(B):
             cases.append(dict(name="kitti_%s_%s" % (kind, step), params=p, map=_seed_map(xyz0, fix["desc"][0], image00, max_meas, 1024),
                               T=I4 if first else T01, fixed=fix["meas"][0 if first else 1], desc=fix["desc"][0 if first else 1],
                               corr=_identity_corr(n0) if first else c01, size=n0 if first else None, grows=not first,
-                              # 00To00: 1e-5 (:399-403).  00To01: the reference asserts 2 m per coordinate (:510-514); with the correspondences
-                              # restated here a landmark moves by up to 3.1 m (weighted mean) / 7.5 m (EKF, gate 100 m^2), so the bound
-                              # checked is the estimator's own gate sqrt(maximum_distance_geometry_meters_squared)
-                              tol=1e-5 if first else (10.0 if kind == "stereo_ekf" else 5.0), n_frames=4))
+                              # 00To00: 1e-5 (:399-403, :456-460, :721-725).  00To01: 5 m per coordinate (:515-517, :580-582, :784-786);
+                              # measured here: 3.1 m (weighted mean, smoother), 1.6 m (stereo EKF)
+                              tol=1e-5 if first else 5.0, n_frames=4))
     return cases
 
 

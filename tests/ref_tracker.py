@@ -26,9 +26,15 @@ def icl_measurements(B, k):
     return np.concatenate([m["uv"], m["depth"][:, None]], axis=1).astype(np.float32), m["desc"]
 
 
-def kitti_setup(no_merges):
-    """KITTI 00To04_Tracker_* (tests/test_trackers.cpp:258-360 / :362-470): kitti.conf tracker, robustifier chi 1000, circle finder
-    with distance 25..100, Lowe 0.5, radius 50..5, matching ratio 0.1; `no_merges`: appearance and geometry thresholds 0"""
+def kitti_setup(no_merges, kind="weighted_mean"):
+    """KITTI 00To04_Tracker_* (tests/test_trackers.cpp:258-783): kitti.conf tracker, robustifier chi 1000, circle finder
+    with distance 25..100, Lowe 0.5, radius 50..5, matching ratio 0.1.  `no_merges` (:260-360): appearance and geometry thresholds 0.
+    kind (merger + landmark estimator the test plugs in):
+      "weighted_mean"  :362-470  merger_triangulation, appearance 50, landmark_estimator_weighted_mean with 25 m^2
+      "ekf"            :473-576  merger_ekf (MergerRigidStereoProjectiveEKF + landmark_estimator_ekf, kitti.conf:1-18,552-590), appearance 50, 25 m^2
+      "smoother"       :578-682  merger_triangulation + landmark_estimator_smoother (kitti.conf:503-521), appearance 50, 25 m^2
+      "bruteforce_ekf" :684-783  merger_ekf as configured (appearance 100, 25 m^2) and a descriptor-based brute-force finder
+                                 (distance 100, Lowe 0.5) in the aligner slice instead of the projective one"""
     from srrg2_proslam_amd import configs
     cfg = dict(configs.get("kitti"))
     f = dict(cfg["projective_finder"])
@@ -37,10 +43,18 @@ def kitti_setup(no_merges):
     a = dict(cfg["aligner"])
     a["chi_threshold"] = 1000.0
     cfg["projective_finder"], cfg["aligner"] = f, a
+    if kind == "bruteforce_ekf":
+        cfg["bruteforce_finder"] = (100.0, 0.5)  # :722-726
     if no_merges:
         merger = dict(variant="stereo_triangulation", estimator="weighted_mean", max_appearance=0.0, max_dist2=0.0)
-    else:  # :380-388: merger_triangulation, appearance 50, weighted mean with 25 m^2
+    elif kind == "weighted_mean":
         merger = dict(variant="stereo_triangulation", estimator="weighted_mean", max_appearance=50.0, max_dist2=25.0)
+    elif kind == "smoother":
+        merger = dict(variant="stereo_triangulation", estimator="smoother", max_appearance=50.0, max_dist2=25.0, max_measurements=8)
+    elif kind in ("ekf", "bruteforce_ekf"):
+        merger = dict(variant="stereo_ekf", estimator="ekf4", max_appearance=50.0 if kind == "ekf" else 100.0, max_dist2=25.0)
+    else:
+        raise ValueError(kind)
     return cfg, merger
 
 
@@ -58,6 +72,8 @@ class Tracker:
     """stages: object with
          clip(cfg, pose, map) -> (xyzw, desc, scene indices)
          align(cfg, fixed, fixed_desc, xyzw, desc, guess, prior_info) -> (X, corr (fixed = measurement, moving = clipped), status, inliers)
+               (cfg["bruteforce_finder"] = (distance, ratio): the slice's finder is the descriptor-based brute-force one, whose
+                correspondences do not depend on the estimate: max_iterations x (linearize, GN step) on one vector)
          new_map(cfg, merger, capacity) -> map;  merge(map, pose, fixed, fixed_desc, corr, scene_indices) -> (n_merged, n_added)
          map_size(map), predict(prev, pose) -> pose, compose(guess, X) -> guess * X^-1, reset()"""
 
@@ -99,8 +115,8 @@ def same_frame_three_times(stages, B, dataset):
     return [t.process(fixed, desc) for _ in range(3)]
 
 
-def kitti_00_to_04(stages, B, no_merges, **kw):
-    cfg, merger = kitti_setup(no_merges)
+def kitti_00_to_04(stages, B, no_merges, kind="weighted_mean", **kw):
+    cfg, merger = kitti_setup(no_merges, kind)
     t = Tracker(stages, cfg, merger, **kw)
     log = [t.process(*kitti_measurements(B, i)) for i in range(5)]
     error = rp.t2tnq(np.linalg.inv(np.asarray(t.pose, np.float64)) @ rp.kitti_relative(4, 0))

@@ -47,7 +47,7 @@ class HipStages:
         assert C.sizeof(_lib.MergerParams) == C.sizeof(type(po))
         pg = _lib.MergerParams()
         C.memmove(C.byref(pg), C.byref(po), C.sizeof(pg))
-        maps = ops.MapBatch(self.ctx.device, 1, capacity, 0, 16, STRIDE, STRIDE)
+        maps = ops.MapBatch(self.ctx.device, 1, capacity, merger.get("max_measurements", 0), 16, STRIDE, STRIDE)
         clip = ops.ClipScenes(self.ctx.device, 1, capacity)
         clip.scene_xyzw, clip.scene_desc, clip.n_scene, clip.scene_n_opt = maps.coords, maps.desc, maps.n_points, maps.n_opt
         af = ops.AlignFrames(self.ctx.device, 1, STRIDE, capacity)
@@ -79,6 +79,23 @@ class HipStages:
     def align(self, cfg, fixed, desc, xyzw, cdesc, guess, prior_info):
         af = self.af  # the moving cloud is the clipper's output, already in place
         self._set_measurement(af, fixed, desc)
+        if cfg.get("bruteforce_finder"):
+            # descriptor-based brute-force finder in the slice: one correspondence vector (brute-force kernel), then
+            # max_iterations x (prs_pcf_linearize, prs_gn_step) through the host-pointer entry points
+            corr = ops.bruteforce_match(self.ctx, ops.bruteforce_params(*cfg["bruteforce_finder"]), desc, cdesc)[0]
+            gf = ops.ProjectiveFinder(self.ctx, ops.pcf_params(cfg))
+            gf.set_fixed(fixed, desc)
+            gf.set_moving(xyzw[:, :3], cdesc, xyzw[:, 3])
+            ap = ops.aligner_params(cfg, mean_disparity=-1.0, stop_at_fixed_point=0)
+            X = np.asarray(guess, np.float32).reshape(4, 4).copy()
+            for _ in range(cfg["aligner"]["max_iterations"]):
+                res = gf.linearize(ap, X, corr)
+                X, _ = ops.gn_step(self.ctx, np.array(res.H, np.float32), np.array(res.b, np.float32), cfg["aligner"]["damping"], X)
+            gf.close()
+            n = len(corr)  # the merger reads the aligner's correspondence vector in place
+            af.corr[0, :n] = self._t(np.stack([corr["fixed_idx"], corr["moving_idx"], corr["response"].view(np.int32)], axis=1).astype(np.int32))
+            af.n_corr[0] = n
+            return X, corr, int(res.num_inliers >= cfg["aligner"]["min_num_inliers"]), res.num_inliers
         af.X[0] = self._t(np.asarray(guess, np.float32).reshape(16))
         ap = ops.aligner_params(cfg, mean_disparity=-1.0, stop_at_fixed_point=0)
         if prior_info > 0:
@@ -140,6 +157,17 @@ def test_kitti_00_to_04(S, B, oracle, no_merges, motion_model):
     bound = (0.25, 0.2, 0.7) if no_merges else (0.2, 0.2, 0.7)  # see tests/test_ref_tracker.py
     assert np.all(np.abs(error[:3]) < bound) and np.all(np.abs(error[3:]) < 0.01), error
     ref, _ = rt.kitti_00_to_04(OracleStages(), OracleBackend(), no_merges, **kw)
+    _same_as_checker(log, ref)
+
+
+@pytest.mark.parametrize("kind", ["ekf", "smoother", "bruteforce_ekf"])
+def test_kitti_00_to_04_other_mergers(S, B, oracle, kind):
+    """tests/test_trackers.cpp:473-576, :578-682, :684-783 on the HIP path (bounds: tests/test_ref_tracker.py), frame by frame equal to the CPU checker"""
+    from test_ref_tracker import OTHER_MERGER_BOUNDS
+    log, error = rt.kitti_00_to_04(S, B, False, kind)
+    assert all(e["status"] == SUCCESS for e in log[1:])
+    assert np.all(np.abs(error[:3]) < OTHER_MERGER_BOUNDS[kind]) and np.all(np.abs(error[3:]) < 0.01), error
+    ref, _ = rt.kitti_00_to_04(OracleStages(), OracleBackend(), False, kind)
     _same_as_checker(log, ref)
 
 
