@@ -184,6 +184,17 @@ PRS_API int prs_triangulate_dev(prs_context* ctx,
  * configure (srrg2_solver SE3*ProjectiveErrorFactor::errorAndJacobian, RobustifierSaturated,
  * H/b accumulation, damped GN step, MultiAligner3DQR iteration loop).
  * ============================================================================================== */
+/* PRS_SEARCH_KDTREE = CorrespondenceFinderProjectiveKDTree (CF/..projective_kdtree_impl.cpp:8-80) over srrg2_core::KDTree<float, 2>
+ * (external), restated from its published construction with the constants the reference's own pinned results fix: a cluster
+ * is split at its mean along the direction of largest variance until it holds fewer than minimum_number_of_points_per_cluster
+ * points or 3 * sqrt(largest eigenvalue of its covariance) < leaf range (= the search radius when _initializeDatabase ran,
+ * kept in prs_pcf_state.database_leaf_range); findNeighbors(query, r^2) returns the members of the ONE leaf the query descends
+ * to that lie within r.  This reproduces the eight counts the reference asserts for the finder (319, 2, 120, 21, 82, 36, 104, 56:
+ * tests/test_correspondence_finders.cpp:330-609); an exhaustive radius search would return supersets.
+ * Arithmetic (BUILD-DEFINED): cluster sums as exact integers of the coordinates in 1/16 px, mean / covariance / eigenvector in
+ * double, node = (mean, unit normal) in float, side (x - mean_x) * n_x + (y - mean_y) * n_y < 0 -> left in float, leaf members in
+ * ascending fixed index; |u|, |v| < 32768.  Clusters beyond the LDS carve of max_fixed (about max_fixed / 3 inner nodes) give
+ * PRS_ERR_CAPACITY for that frame. */
 enum { PRS_SEARCH_KDTREE = 0, PRS_SEARCH_SQUARE = 1, PRS_SEARCH_CIRCLE = 2, PRS_SEARCH_RHOMBUS = 3 };
 enum { PRS_FACTOR_MONO = 2, PRS_FACTOR_DEPTH = 3, PRS_FACTOR_STEREO = 4 }; /* = fixed dimension */
 
@@ -208,6 +219,7 @@ typedef struct {
   uint64_t number_of_solver_iterations_per_projection; /* :70-74 */
   int32_t search_type;                         /* which subclass: PRS_SEARCH_* */
   prs_projector projector;
+  int32_t minimum_number_of_points_per_cluster; /* KD-tree finder only (CF/..projective_kdtree.h:24-28); 0 = its default, 10 */
 } prs_pcf_params;
 
 /* the finder members that live across calls and frames (CF/..projective_base.h:132-154).  POD so
@@ -221,6 +233,8 @@ typedef struct {
   int32_t num_recomputes; /* bookkeeping only: number of full searches so far */
   float local_map_in_sensor[16];
   float local_map_in_sensor_previous[16];
+  float database_leaf_range; /* KD-tree finder: _search_radius_pixels when _initializeDatabase last ran (the tree's leaf range) */
+  int32_t reserved;
 } prs_pcf_state;
 
 typedef struct {

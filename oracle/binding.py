@@ -75,6 +75,7 @@ class PcfParams(C.Structure):
         ("number_of_solver_iterations_per_projection", C.c_uint64),
         ("search_type", C.c_int32),
         ("projector", Projector),
+        ("minimum_number_of_points_per_cluster", C.c_int32),  # KD-tree finder; 0 = the reference's default (10)
     ]
 
 

@@ -529,6 +529,11 @@ struct orc_pcf {
   int n_projected;
   /* lattice database (square.h:48) */
   orc_element* database_fixed;
+  /* KD-tree database (projective_kdtree.h:44): internal nodes, leaves, and the fixed indices in leaf order */
+  struct orc_kd_node* kd_nodes;
+  int32_t* kd_leaf_start; /* [kd_n_leaves + 1] offsets into kd_order */
+  int32_t* kd_order;      /* [n_fixed] fixed indices, leaf by leaf, ascending inside a leaf */
+  int kd_n_nodes, kd_n_leaves, kd_root;
   /* persisting caller-side correspondence vector */
   orc_corr* correspondences;
   int n_correspondences;
@@ -548,6 +553,9 @@ void orc_pcf_destroy(orc_pcf* h) {
   if (!h) {
     return;
   }
+  free(h->kd_nodes);
+  free(h->kd_leaf_start);
+  free(h->kd_order);
   free(h->fixed_uv);
   free(h->fixed_desc);
   free(h->moving_xyz);
@@ -637,9 +645,145 @@ int orc_pcf_num_recomputes(const orc_pcf* h) {
   return h->num_recomputes;
 }
 
+/* ---- srrg2_core::KDTree<float, 2> as the KD-tree finder uses it (CF/correspondence_finder_projective_kdtree_impl.cpp:8-26,
+ * 39-50; the class itself is external).  Restated from its published construction -- split a cluster at its mean along the
+ * direction of largest variance until it is small -- with the two constants the header does not carry fixed by the reference's
+ * own pinned results: a cluster is a leaf when it holds fewer than minimum_number_of_points_per_cluster points or when its
+ * extent 3 * sqrt(largest eigenvalue of its covariance) is below the leaf range (= _search_radius_pixels at build time), and a
+ * radius query is answered from the ONE leaf the query point descends to.  With these the eight counts the reference asserts
+ * for this finder come out exactly (319, 2, 120, 21, 82, 36, 104, 56: tests/test_correspondence_finders.cpp:330,370,412,427,
+ * 468,552,568,609); an exhaustive radius search returns supersets (123, 83, 89, 41, 108, 64).
+ * Arithmetic (BUILD-DEFINED, identical on the device): cluster statistics are exact integer sums of the coordinates in
+ * 1/16 px (below 2^53: independent of the summation order, exactly convertible to double); mean, covariance and
+ * eigen-decomposition in double, rounded to float for the node; side test (x - mean_x) * n_x + (y - mean_y) * n_y < 0 -> left
+ * in float; leaf members in ascending fixed index. */
+struct orc_kd_node {
+  float mean[2], normal[2];
+  int32_t child[2]; /* >= 0: internal node, < 0: leaf ~child */
+};
+
+typedef struct {
+  int64_t sx, sy, sxx, sxy, syy;
+} orc_kd_stats;
+
+static inline int64_t kd_quantise(float v) {
+  return (int64_t) llrintf(v * 16.0f);
+}
+
+/* leaf decision and split direction of a cluster from its exact sums */
+static int kd_decide(const orc_kd_stats* st, int n, double leaf_range, int min_points, float* mean, float* normal) {
+  const double dn  = (double) n;
+  const double sx = (double) st->sx, sy = (double) st->sy;
+  mean[0]          = (float) (sx / (16.0 * dn));
+  mean[1]          = (float) (sy / (16.0 * dn));
+  const double cxx = ((double) st->sxx - sx * sx / dn) / dn / 256.0;
+  const double cxy = ((double) st->sxy - sx * sy / dn) / dn / 256.0;
+  const double cyy = ((double) st->syy - sy * sy / dn) / dn / 256.0;
+  const double half_diff = 0.5 * (cxx - cyy);
+  double lambda          = 0.5 * (cxx + cyy) + sqrt(half_diff * half_diff + cxy * cxy);
+  if (!(lambda > 0.0)) {
+    lambda = 0.0;
+  }
+  double vx = lambda - cyy, vy = cxy;
+  const double norm = sqrt(vx * vx + vy * vy);
+  if (norm > 0.0) {
+    vx = vx / norm;
+    vy = vy / norm;
+  } else {
+    vx = cxx >= cyy ? 1.0 : 0.0;
+    vy = cxx >= cyy ? 0.0 : 1.0;
+  }
+  normal[0] = (float) vx;
+  normal[1] = (float) vy;
+  return n < min_points || 3.0 * sqrt(lambda) < leaf_range;
+}
+
+static inline float kd_side(const float* mean, const float* normal, float x, float y) {
+  const float dx = x - mean[0], dy = y - mean[1];
+  return dx * normal[0] + dy * normal[1];
+}
+
+/* builds the subtree over idx[0..n) (ascending fixed indices), returns the child code */
+static int32_t kd_build(orc_pcf* h, const int32_t* idx, int n, double leaf_range, int min_points) {
+  orc_kd_stats st = {0, 0, 0, 0, 0};
+  for (int i = 0; i < n; ++i) {
+    const int64_t qx = kd_quantise(h->fixed_uv[2 * idx[i]]), qy = kd_quantise(h->fixed_uv[2 * idx[i] + 1]);
+    st.sx += qx;
+    st.sy += qy;
+    st.sxx += qx * qx;
+    st.sxy += qx * qy;
+    st.syy += qy * qy;
+  }
+  float mean[2], normal[2];
+  int leaf     = kd_decide(&st, n, leaf_range, min_points, mean, normal);
+  int32_t* lft = NULL;
+  int nl = 0, nr = 0;
+  if (!leaf) {
+    lft          = (int32_t*) malloc(sizeof(int32_t) * 2u * (size_t) (n > 0 ? n : 1));
+    int32_t* rgt = lft + n;
+    for (int i = 0; i < n; ++i) {
+      if (kd_side(mean, normal, h->fixed_uv[2 * idx[i]], h->fixed_uv[2 * idx[i] + 1]) < 0.0f) {
+        lft[nl++] = idx[i];
+      } else {
+        rgt[nr++] = idx[i];
+      }
+    }
+    leaf = nl == 0 || nr == 0; /* (cannot shrink any further) */
+  }
+  if (leaf) {
+    const int l = h->kd_n_leaves++;
+    int32_t o   = h->kd_leaf_start[l];
+    for (int i = 0; i < n; ++i) {
+      h->kd_order[o++] = idx[i];
+    }
+    h->kd_leaf_start[l + 1] = o;
+    free(lft);
+    return ~l;
+  }
+  const int me = h->kd_n_nodes++;
+  h->kd_nodes[me].mean[0] = mean[0];
+  h->kd_nodes[me].mean[1] = mean[1];
+  h->kd_nodes[me].normal[0] = normal[0];
+  h->kd_nodes[me].normal[1] = normal[1];
+  const int32_t cl = kd_build(h, lft, nl, leaf_range, min_points);
+  const int32_t cr = kd_build(h, lft + n, nr, leaf_range, min_points);
+  h->kd_nodes[me].child[0] = cl;
+  h->kd_nodes[me].child[1] = cr;
+  free(lft);
+  return me;
+}
+
+/* _initializeDatabase of the KD-tree finder (kdtree_impl.cpp:8-26): leaf range = the CURRENT search radius */
+static void pcf_initialize_kdtree(orc_pcf* h) {
+  free(h->kd_nodes);
+  free(h->kd_leaf_start);
+  free(h->kd_order);
+  const int n      = h->n_fixed;
+  h->kd_nodes      = (struct orc_kd_node*) malloc(sizeof(struct orc_kd_node) * (size_t) (n > 0 ? n : 1));
+  h->kd_leaf_start = (int32_t*) calloc((size_t) n + 2, sizeof(int32_t));
+  h->kd_order      = (int32_t*) malloc(sizeof(int32_t) * (size_t) (n > 0 ? n : 1));
+  h->kd_n_nodes = h->kd_n_leaves = 0;
+  h->kd_root                     = ~0;
+  if (n <= 0) {
+    h->kd_n_leaves = 1; /* one empty leaf */
+    return;
+  }
+  int32_t* idx = (int32_t*) malloc(sizeof(int32_t) * (size_t) n);
+  for (int i = 0; i < n; ++i) {
+    idx[i] = i;
+  }
+  const int min_points = h->params.minimum_number_of_points_per_cluster > 0 ? h->params.minimum_number_of_points_per_cluster : 10;
+  h->kd_root           = kd_build(h, idx, n, (double) (float) h->search_radius_pixels, min_points);
+  free(idx);
+}
+
 /* _initializeDatabase (CF/correspondence_finder_projective_square_impl.cpp:8-31);
  * canonicalisation (a): stable sort by row */
 static void pcf_initialize_database(orc_pcf* h) {
+  if (h->params.search_type == ORC_SEARCH_KDTREE) {
+    pcf_initialize_kdtree(h);
+    return;
+  }
   free(h->database_fixed);
   const int n       = h->n_fixed;
   h->database_fixed = (orc_element*) malloc(sizeof(orc_element) * (size_t)(n > 0 ? n : 1));
@@ -750,9 +894,8 @@ static void pcf_find_lattice(const orc_pcf* h,
   }
 }
 
-/* _findNearestNeighbors for the KD-tree variant (CF/correspondence_finder_projective_kdtree_impl.cpp:30-80).
- * The external KDTree<float,2>::findNeighbors is restated as an exact radius query visited in
- * ascending fixed index (BUILD-DEFINED: "<=" on the squared distance). */
+/* _findNearestNeighbors for the KD-tree variant (CF/correspondence_finder_projective_kdtree_impl.cpp:30-80):
+ * KDTree::findNeighbors(query, r^2) = the points of the leaf the query descends to whose squared distance is below r^2 */
 static void pcf_find_kdtree(const orc_pcf* h,
                             const float* query_uvz,
                             int32_t query_index,
@@ -764,10 +907,17 @@ static void pcf_find_kdtree(const orc_pcf* h,
   size_t index_fixed_best               = 0;
   float descriptor_distance_best        = maximum_descriptor_distance; /* :54 */
   float descriptor_distance_second_best = FLT_MAX;
-  for (int f = 0; f < h->n_fixed; ++f) {
+  int32_t node = h->kd_root;
+  while (node >= 0) {
+    const struct orc_kd_node* nd = &h->kd_nodes[node];
+    node = nd->child[kd_side(nd->mean, nd->normal, query_uvz[0], query_uvz[1]) < 0.0f ? 0 : 1];
+  }
+  const int leaf = ~node;
+  for (int32_t o = h->kd_leaf_start[leaf]; o < h->kd_leaf_start[leaf + 1]; ++o) {
+    const int f    = h->kd_order[o];
     const float du = h->fixed_uv[2 * f + 0] - query_uvz[0];
     const float dv = h->fixed_uv[2 * f + 1] - query_uvz[1];
-    if (du * du + dv * dv > maximum_distance_squared) {
+    if (!(du * du + dv * dv < maximum_distance_squared)) {
       continue;
     }
     const float descriptor_distance =

@@ -161,6 +161,8 @@ typedef struct {
   uint64_t number_of_solver_iterations_per_projection;
   int32_t search_type;
   orc_projector projector;
+  /* KD-tree finder only: PARAM minimum_number_of_points_per_cluster (projective_kdtree.h:24-28); 0 = its default, 10 */
+  int32_t minimum_number_of_points_per_cluster;
 } orc_pcf_params;
 
 typedef struct orc_pcf orc_pcf;

@@ -291,6 +291,7 @@ public:
   PropertyUnsignedInt param_minimum_number_of_iterations{10};
   PropertyFloat param_maximum_estimate_change_norm_for_convergence{1e-5f};
   PropertyUnsignedInt param_number_of_solver_iterations_per_projection{25};
+  PropertyUnsignedInt param_minimum_number_of_points_per_cluster{10};  // KD-tree finder only (CF/..projective_kdtree.h:24-28)
   ProjectorPinholeHIPPtr param_projector;
 
   void setFixed(const FixedType* fixed_) {
@@ -343,6 +344,7 @@ public:
     p.number_of_solver_iterations_per_projection   = param_number_of_solver_iterations_per_projection.value();
     p.search_type                                  = SEARCH_;
     p.projector                                    = param_projector->raw();
+    p.minimum_number_of_points_per_cluster         = (int32_t) param_minimum_number_of_points_per_cluster.value();
     return p;
   }
 

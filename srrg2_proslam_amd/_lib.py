@@ -96,6 +96,7 @@ class PcfParams(C.Structure):
         ("number_of_solver_iterations_per_projection", C.c_uint64),
         ("search_type", C.c_int32),
         ("projector", Projector),
+        ("minimum_number_of_points_per_cluster", C.c_int32),  # KD-tree finder; 0 = the reference's default (10)
     ]
 
 
@@ -110,6 +111,8 @@ class PcfState(C.Structure):
         ("num_recomputes", C.c_int32),
         ("local_map_in_sensor", C.c_float * 16),
         ("local_map_in_sensor_previous", C.c_float * 16),
+        ("database_leaf_range", C.c_float),
+        ("reserved", C.c_int32),
     ]
 
 

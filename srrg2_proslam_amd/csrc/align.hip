@@ -15,7 +15,7 @@
 //   _addCorrespondenceCandidate / _filterCorrespondences                                   ...:8-37, 41-102
 //   Square/Circle/Rhombus _initializeDatabase, _findNearestNeighbors
 //        CF/..square_impl.cpp:8-118, CF/..circle_impl.cpp:8-94, CF/..rhombus_impl.cpp:8-93
-//   KDTree _findNearestNeighbors (exact radius query)  CF/..kdtree_impl.cpp:30-80
+//   KDTree _initializeDatabase / _findNearestNeighbors (srrg2_core's tree restated: single-leaf radius queries)  CF/..kdtree_impl.cpp:8-80
 //   AlignerSliceProcessorProjective{,Stereo}::setupFactor / bindFixed
 //        registration/aligner_slice_processor_projective.cpp:28-112
 //   + the un-vendored pinhole projector, error factors, saturated robustifier, H/b accumulation and
@@ -54,6 +54,8 @@ struct AlignShared {
   float H[36];
   float b[6];
   float chi_in, chi_tot, mean_disp, change_norm, dd;
+  float kd_range;   // KD-tree finder: the search radius _initializeDatabase last ran with (leaf range of the tree)
+  int kd_nodes, kd_leaves, kd_open_next;  // KD-tree build counters
   unsigned long long radius, it;
   int converged, config_changed, num_recomputes;
   int n_corr, n_filtered, n_projected, decision, flags, error;
@@ -415,6 +417,55 @@ __device__ __forceinline__ int gn_slot_destination(const int slot, const bool mi
   return mirror ? 6 * c + r : 6 * r + c;
 }
 
+// ---- srrg2_core::KDTree<float, 2> as the KD-tree finder uses it (CF/correspondence_finder_projective_kdtree_impl.cpp:8-26,39-50;
+// the class is external): split a cluster at its mean along the direction of largest variance until it holds fewer than
+// minimum_number_of_points_per_cluster points or its extent 3 * sqrt(largest eigenvalue) is below the leaf range (the search
+// radius when _initializeDatabase ran); a radius query is answered from the ONE leaf the query point descends to.  With these
+// constants the eight counts the reference asserts for this finder come out exactly (tests/test_ref_pins.py).
+// Arithmetic (defined in include/proslam_hip.h, PRS_SEARCH_KDTREE): exact integer sums of the coordinates in 1/16 px (order
+// independent, exact in double), mean / covariance / eigen-decomposition in double, node = (mean, unit normal) in float, side
+// test (x - mean_x) * n_x + (y - mean_y) * n_y < 0 -> left in float, leaf members in ascending fixed index.
+struct KdNode {
+  float mx, my, nx, ny;
+  short child[2];  // >= 0: internal node, < 0: leaf ~child
+  int pad;
+};
+static_assert(sizeof(KdNode) == 24, "KdNode layout");
+
+__device__ __forceinline__ bool kd_decide(const long long* st, const int n, const double leaf_range, const int min_points, float* mean, float* normal) {
+  const double dn = (double) n;
+  const double sx = (double) st[0], sy = (double) st[1];
+  mean[0]          = (float) (sx / (16.0 * dn));
+  mean[1]          = (float) (sy / (16.0 * dn));
+  const double cxx = ((double) st[2] - sx * sx / dn) / dn / 256.0;
+  const double cxy = ((double) st[3] - sx * sy / dn) / dn / 256.0;
+  const double cyy = ((double) st[4] - sy * sy / dn) / dn / 256.0;
+  const double half_diff = 0.5 * (cxx - cyy);
+  double lambda          = 0.5 * (cxx + cyy) + sqrt(half_diff * half_diff + cxy * cxy);
+  if (!(lambda > 0.0)) {
+    lambda = 0.0;
+  }
+  double vx = lambda - cyy, vy = cxy;
+  const double norm = sqrt(vx * vx + vy * vy);
+  if (norm > 0.0) {
+    vx = vx / norm;
+    vy = vy / norm;
+  } else {
+    vx = cxx >= cyy ? 1.0 : 0.0;
+    vy = cxx >= cyy ? 0.0 : 1.0;
+  }
+  normal[0] = (float) vx;
+  normal[1] = (float) vy;
+  return n < min_points || 3.0 * sqrt(lambda) < leaf_range;
+}
+__device__ __forceinline__ float kd_side(const KdNode& nd, const float x, const float y) {
+  const float dx = x - nd.mx, dy = y - nd.my;
+  return dx * nd.nx + dy * nd.ny;
+}
+__host__ __device__ __forceinline__ int kd_open_capacity(const int max_fixed) {
+  return max_fixed / 5 + 4;  // open clusters of one level: a cluster that is split holds >= 10 points
+}
+
 // SPLIT = the search half of the split pipeline (mode kModeSplitSearch): a compile-time flag, so the
 // Gauss-Newton code (and its registers) is not part of that instantiation
 // STYPE: the search pattern as a compile-time constant (-1 = read it from the parameters), so that the search
@@ -475,6 +526,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
     sh.radius         = gstate->search_radius_pixels;
     sh.it             = gstate->current_iteration;
     sh.dd             = gstate->descriptor_distance;
+    sh.kd_range       = gstate->database_leaf_range;
     sh.converged      = gstate->has_converged;
     sh.config_changed = gstate->config_changed;
     sh.num_recomputes = gstate->num_recomputes;
@@ -625,6 +677,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
             sh.it        = 0;
             se3_identity(sh.Tprev);
             sh.config_changed = 0;
+            sh.kd_range       = (float) sh.radius;  // _initializeDatabase(): KDTree(fixed, _search_radius_pixels, ..) (kdtree_impl.cpp:21-24)
           }
           inputs_changed = false;
           db_built       = false;  // _initializeDatabase() is part of the reset (:131)
@@ -685,6 +738,218 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
           __syncthreads();
           db_built = true;
         }
+        if (!db_built && !lattice) {
+          // _initializeDatabase of the KD-tree finder (kdtree_impl.cpp:8-26), level by level: the open clusters of a level get
+          // their exact coordinate sums (LDS 64-bit atomics), one lane per cluster decides leaf / split, every point moves to
+          // its child.  Node and leaf numbers depend on the scheduling, the tree does not.
+          KdNode* nodes        = reinterpret_cast<KdNode*>(db);
+          uint16_t* order      = inv;
+          short* kdhead        = reinterpret_cast<short*>(cellstart);  // [0] root code, [1] number of leaves
+          uint16_t* leaf_start = cellstart + 2;
+          const int node_cap   = (int) ((size_t) g.max_fixed * sizeof(uint2) / sizeof(KdNode));
+          const int open_cap   = kd_open_capacity(g.max_fixed);
+          const int min_points = g.f.minimum_number_of_points_per_cluster > 0 ? g.f.minimum_number_of_points_per_cluster : 10;
+          unsigned long long* st = reinterpret_cast<unsigned long long*>(terms);  // [open_cap][5]
+          int* cnt        = reinterpret_cast<int*>(st + (size_t) open_cap * 5);
+          int* kind       = cnt + open_cap;
+          int* child_open = kind + open_cap;
+          int* par_cur    = child_open + open_cap;  // parent node, side << 30 folded in below
+          int* pcnt_cur   = par_cur + open_cap;
+          int* par_next   = pcnt_cur + open_cap;
+          int* pcnt_next  = par_next + open_cap;
+          uint16_t* node_of = reinterpret_cast<uint16_t*>(pcnt_next + open_cap);
+          uint16_t* leaf_of = node_of + g.max_fixed + 2;
+          uint16_t* bucket  = leaf_of + g.max_fixed + 2;
+          for (int i = tid; i < nF; i += T) {
+            const float4 c = gfix[i];
+            if (!(c.x > -32768.0f && c.x < 32768.0f && c.y > -32768.0f && c.y < 32768.0f)) {
+              sh.error = PRS_ERR_RANGE;
+            }
+            node_of[i] = 0;
+          }
+          if (tid == 0) {
+            sh.kd_nodes = sh.kd_leaves = 0;
+            par_cur[0]  = -1;
+            pcnt_cur[0] = -1;
+            if (nF == 0) {  // one empty leaf
+              kdhead[0]     = (short) ~0;
+              sh.kd_leaves  = 1;
+            }
+          }
+          __syncthreads();
+          if (sh.error) {
+            break;
+          }
+          int n_open = nF > 0 ? 1 : 0;
+          while (n_open > 0) {
+            for (int k = tid; k < n_open; k += T) {
+#pragma unroll
+              for (int j = 0; j < 5; ++j) {
+                st[5 * k + j] = 0ull;
+              }
+              cnt[k] = 0;
+            }
+            if (tid == 0) {
+              sh.kd_open_next = 0;
+            }
+            __syncthreads();
+            for (int i = tid; i < nF; i += T) {
+              const int k = node_of[i];
+              if (k != 0xffff) {
+                const float4 c     = gfix[i];
+                const long long qx = __float2ll_rn(c.x * 16.0f), qy = __float2ll_rn(c.y * 16.0f);
+                atomicAdd(&st[5 * k + 0], (unsigned long long) qx);
+                atomicAdd(&st[5 * k + 1], (unsigned long long) qy);
+                atomicAdd(&st[5 * k + 2], (unsigned long long) (qx * qx));
+                atomicAdd(&st[5 * k + 3], (unsigned long long) (qx * qy));
+                atomicAdd(&st[5 * k + 4], (unsigned long long) (qy * qy));
+                atomicAdd(&cnt[k], 1);
+              }
+            }
+            __syncthreads();
+            for (int k = tid; k < n_open; k += T) {
+              const int n = cnt[k];
+              int code    = 0x7fffffff;  // nothing here (the empty side of a split that could not separate its points)
+              if (n > 0) {
+                const int P       = par_cur[k] < 0 ? -1 : (par_cur[k] & 0x3fffffff);
+                const int side    = par_cur[k] < 0 ? 0 : ((par_cur[k] >> 30) & 1);
+                const bool forced = pcnt_cur[k] == n;  // every point of the parent went to this side: the parent IS this leaf
+                float mean[2], normal[2];
+                bool leaf = kd_decide(reinterpret_cast<const long long*>(st + 5 * k), n, (double) sh.kd_range, min_points, mean, normal) || forced;
+                int N     = -1;
+                if (!leaf) {
+                  N = atomicAdd(&sh.kd_nodes, 1);
+                  const int c0 = atomicAdd(&sh.kd_open_next, 2);
+                  if (N >= node_cap || N > 32767 || c0 + 2 > open_cap) {
+                    sh.error = PRS_ERR_CAPACITY;  // more clusters than the LDS carve of this max_fixed holds
+                    leaf     = true;
+                  } else {
+                    KdNode nd;
+                    nd.mx = mean[0];
+                    nd.my = mean[1];
+                    nd.nx = normal[0];
+                    nd.ny = normal[1];
+                    nd.child[0] = nd.child[1] = (short) ~0;
+                    nd.pad   = 0;
+                    nodes[N] = nd;
+                    child_open[k]     = c0;
+                    par_next[c0]      = N;
+                    par_next[c0 + 1]  = N | (1 << 30);
+                    pcnt_next[c0]     = n;
+                    pcnt_next[c0 + 1] = n;
+                    code              = N;
+                  }
+                }
+                if (leaf) {
+                  code = ~atomicAdd(&sh.kd_leaves, 1);
+                }
+                if (P < 0) {
+                  kdhead[0] = (short) code;
+                } else if (forced) {
+                  nodes[P].child[0] = nodes[P].child[1] = (short) code;
+                } else {
+                  nodes[P].child[side] = (short) code;
+                }
+              }
+              kind[k] = code;
+            }
+            __syncthreads();
+            if (sh.error) {
+              break;
+            }
+            const int next_open = sh.kd_open_next;
+            for (int i = tid; i < nF; i += T) {
+              const int k = node_of[i];
+              if (k != 0xffff) {
+                const int code = kind[k];
+                if (code < 0) {
+                  leaf_of[i] = (uint16_t) ~code;
+                  node_of[i] = 0xffff;
+                } else {
+                  const float4 c = gfix[i];
+                  node_of[i]     = (uint16_t) (child_open[k] + (kd_side(nodes[code], c.x, c.y) < 0.0f ? 0 : 1));
+                }
+              }
+            }
+            n_open = next_open;
+            {
+              int* t0 = par_cur;
+              par_cur = par_next;
+              par_next = t0;
+              t0       = pcnt_cur;
+              pcnt_cur = pcnt_next;
+              pcnt_next = t0;
+            }
+            __syncthreads();
+          }
+          if (sh.error) {
+            break;
+          }
+          // leaf members in ascending fixed index: counting sort by leaf, rank inside the leaf
+          const int n_leaves = sh.kd_leaves;
+          uint32_t* lh       = reinterpret_cast<uint32_t*>(st);
+          for (int l = tid; l <= n_leaves; l += T) {
+            lh[l] = 0;
+          }
+          __syncthreads();
+          for (int i = tid; i < nF; i += T) {
+            node_of[i] = (uint16_t) atomicAdd(&lh[leaf_of[i]], 1u);  // (node_of is free again: slot inside the leaf)
+          }
+          __syncthreads();
+          if (wave == 0) {
+            const int n     = n_leaves + 1;
+            const int chunk = (n + 63) >> 6;
+            uint32_t sum    = 0;
+            for (int j = 0; j < chunk; ++j) {
+              const int r = lane * chunk + j;
+              sum += r < n ? lh[r] : 0u;
+            }
+            uint32_t incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+              const uint32_t o = __shfl_up(incl, d, 64);
+              if (lane >= d) {
+                incl += o;
+              }
+            }
+            uint32_t run = incl - sum;
+            for (int j = 0; j < chunk; ++j) {
+              const int r = lane * chunk + j;
+              if (r < n) {
+                leaf_start[r] = (uint16_t) run;
+                run += lh[r];
+              }
+            }
+          }
+          __syncthreads();
+          for (int i = tid; i < nF; i += T) {
+            bucket[leaf_start[leaf_of[i]] + node_of[i]] = (uint16_t) i;
+          }
+          __syncthreads();
+          for (int i = tid; i < nF; i += T) {
+            const int l0 = leaf_start[leaf_of[i]], l1 = leaf_start[leaf_of[i] + 1];
+            int rank = 0;
+            for (int j = l0; j < l1; ++j) {
+              rank += bucket[j] < (uint16_t) i ? 1 : 0;
+            }
+            order[l0 + rank] = (uint16_t) i;
+          }
+          if (tid == 0) {
+            kdhead[1] = (short) n_leaves;
+          }
+          __syncthreads();
+          db_built = true;
+          if (split_search && g.dbcache) {
+            const uint4* src = reinterpret_cast<const uint4*>(smem + g.off_db);
+            uint4* dst       = reinterpret_cast<uint4*>(g.dbcache + (size_t) frame * g.db_blob);
+            for (int i = tid; i < (int) (g.db_blob >> 4); i += T) {
+              dst[i] = src[i];
+            }
+            if (tid == 0) {
+              ctl->db_ready = 1;  // read by the NEXT search launch of this frame
+            }
+          }
+        }
         if (!db_built) {
           // _initializeDatabase (square_impl.cpp:8-31).  The reference scans a row-sorted vector; its
           // scan position only matters for tie-breaks ("first wins"), so every fixed point gets its
@@ -714,7 +979,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
           if (sh.error) {
             break;
           }
-          if (lattice) {
+          {
             if (wave == 0) {
               const int n     = R + 1;
               const int chunk = (n + 63) >> 6;
@@ -754,10 +1019,6 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                 rank += bucket[j] < (uint16_t) i ? 1 : 0;
               }
               canon[i] = (uint16_t) (s + rank);
-            }
-          } else {
-            for (int i = tid; i < nF; i += T) {
-              canon[i] = (uint16_t) i;  // KD-tree variant: candidates are visited in ascending fixed index
             }
           }
           __syncthreads();
@@ -914,12 +1175,30 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                 cb0  = col - rad;                           // every pattern accepts only |dcol - col| <= rad
                 cb1  = col + rad;
               } else {
-                r0  = (int) floorf(v) - rad - 1;            // bounding box of the radius query (+1 px margin)
-                r1  = (int) floorf(v) + rad + 1;
-                cb0 = (int) floorf(u) - rad - 1;
-                cb1 = (int) floorf(u) + rad + 1;
+                // KDTree::findNeighbors(query, r^2) (kdtree_impl.cpp:39-50): the leaf the query descends to, its members
+                // within the radius in ascending fixed index, best initialised to maximum_descriptor_distance (:54)
+                const KdNode* nodes        = reinterpret_cast<const KdNode*>(db);
+                const uint16_t* leaf_start = cellstart + 2;
+                int code                   = (int) reinterpret_cast<const short*>(cellstart)[0];
+                while (code >= 0) {
+                  const KdNode nd = nodes[code];
+                  code            = (int) nd.child[kd_side(nd, u, v) < 0.0f ? 0 : 1];
+                }
+                const int leaf = ~code;
+                for (int o = leaf_start[leaf]; o < (int) leaf_start[leaf + 1]; ++o) {
+                  const int fi   = inv[o];
+                  const float2 c = fuv[fi];
+                  const float du = c.x - u, dv = c.y - v;
+                  if (du * du + dv * dv < r2f) {
+                    const uint32_t d   = (uint32_t) hamming_regs(fdesc[2 * fi], fdesc[2 * fi + 1], q0, q1);
+                    const uint32_t key = (float) d < max_dd ? ((d << 16) | (uint32_t) fi) : kNoneU32;
+                    bestk              = key < bestk ? key : bestk;
+                  }
+                }
+                r0 = 1;  // (no lattice scan)
+                r1 = cb0 = cb1 = 0;
               }
-              r0  = r0 < 0 ? 0 : r0;
+              r0  = (lattice && r0 < 0) ? 0 : r0;
               r1  = r1 > R - 1 ? R - 1 : r1;
               cb0 = cb0 < 0 ? 0 : cb0;
               const int colmax = (g.cell_ncx << g.cell_sx) - 1;
@@ -941,12 +1220,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                   }
                   const int drow = (int) (int16_t) (e.x & 0xffffu);
                   const int dcol = (int) (int16_t) (e.x >> 16);
-                  if (!lattice) {
-                    // exact radius query (kdtree_impl.cpp:39-50)
-                    const float2 c = fuv[e.y & 0xffffu];
-                    const float du = c.x - u, dv = c.y - v;
-                    return !(du * du + dv * dv > r2f);
-                  } else if (drow < rmin || drow >= rmax) {
+                  if (drow < rmin || drow >= rmax) {
                     return false;  // outside the scanned rows (circle_impl.cpp:40-47)
                   } else if (stype == PRS_SEARCH_SQUARE) {
                     return dcol > cmin && dcol < cmax;  // square_impl.cpp:80
@@ -966,9 +1240,8 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                 auto score = [&](const uint2 e) {
                   const int fi     = (int) (e.y & 0xffffu);
                   const uint32_t d = (uint32_t) hamming_regs(fdesc[2 * fi], fdesc[2 * fi + 1], q0, q1);
-                  // kdtree_impl.cpp:54: the best is initialised to maximum_descriptor_distance
                   // best / second best (circle_impl.cpp:64-72) as min / second-min of unique keys
-                  const uint32_t key = (lattice || (float) d < max_dd) ? ((d << 16) | (e.y >> 16)) : kNoneU32;
+                  const uint32_t key = (d << 16) | (e.y >> 16);
                   const uint32_t hi  = key > bestk ? key : bestk;
                   seck               = hi < seck ? hi : seck;
                   bestk              = key < bestk ? key : bestk;
@@ -991,7 +1264,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                 }
               }
               if (bestk != kNoneU32) {  // circle_impl.cpp:78-92 / kdtree_impl.cpp:72-78 (best only)
-                cd.x = (uint32_t) inv[bestk & 0xffffu] | ((bestk >> 16) << 16);
+                cd.x = (lattice ? (uint32_t) inv[bestk & 0xffffu] : (bestk & 0xffffu)) | ((bestk >> 16) << 16);
                 if (lattice && seck != kNoneU32) {
                   cd.y = (uint32_t) inv[seck & 0xffffu] | ((seck >> 16) << 16);
                 }
@@ -1350,6 +1623,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
     gstate->search_radius_pixels = sh.radius;
     gstate->current_iteration    = sh.it;
     gstate->descriptor_distance  = sh.dd;
+    gstate->database_leaf_range  = sh.kd_range;
     gstate->has_converged        = sh.converged;
     gstate->config_changed       = sh.config_changed;
     gstate->num_recomputes       = sh.num_recomputes;
@@ -1976,11 +2250,15 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   g.ncells   = ncy * ncx;
   // LDS carve.  with_operands = false: the search half of the split pipeline, which hands the
   // per-correspondence operand rows to the GN kernel through global memory instead of LDS
+  // the KD-tree finder keeps its tree where the lattice finders keep theirs: nodes in `db`, leaf members in `inv`, root + leaf
+  // offsets in `cellstart` (2 + n_leaves + 1 <= max_fixed + 3 entries)
+  const bool kdtree         = finder->search_type == PRS_SEARCH_KDTREE;
+  const uint32_t cs_entries = kdtree && nf + 4u > (uint32_t) g.ncells + 2u ? nf + 4u : (uint32_t) g.ncells + 2u;
   auto carve = [&](AlignArgs& g, bool with_operands) -> size_t {
     uint32_t off = 0;
     g.off_db       = off; off = align_up16(off + nf * 8);
     g.off_inv      = off; off = align_up16(off + nf * 2);
-    g.off_cellstart = off; off = align_up16(off + ((uint32_t) g.ncells + 2) * 2);
+    g.off_cellstart = off; off = align_up16(off + cs_entries * 2);
     g.off_cfix     = off; off = align_up16(off + (with_operands ? nf * 16 : 0));
     g.off_cmov     = off; off = align_up16(off + (with_operands ? nf * 16 : 0));
     g.off_cls      = off; off = align_up16(off + (with_operands ? nf : 0));
@@ -2003,6 +2281,10 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
     }
     if (nf * 4 + 160 > terms_bytes) {
       terms_bytes = nf * 4 + 160;
+    }
+    const uint32_t kd_bytes = (uint32_t) kd_open_capacity((int) nf) * (40 + 7 * 4) + (nf + 2) * 2 * 3 + 64;  // KD-tree build scratch
+    if (kdtree && kd_bytes > terms_bytes) {
+      terms_bytes = kd_bytes;
     }
     const uint32_t t_end = align_up16(off + terms_bytes);
     return u > t_end ? u : t_end;
@@ -2054,7 +2336,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   gs.mode      = kModeSplitSearch;
   const size_t lds_search = carve(gs, false);
   // image of the lattice arrays (contiguous in LDS: db | inv | cellstart), kept per frame between search launches
-  gs.db_blob = align_up16(gs.off_cellstart + ((uint32_t) gs.ncells + 2) * 2) - gs.off_db;
+  gs.db_blob = align_up16(gs.off_cellstart + cs_entries * 2) - gs.off_db;
   gs.dbcache = static_cast<unsigned char*>(ctx_device_scratch_slot(ctx, 0, (size_t) batch->batch * gs.db_blob));
   if (!gs.dbcache) {
     return ctx_fail(ctx, PRS_ERR_HIP, "prs_align_batch_run: lattice cache allocation failed");

@@ -111,6 +111,32 @@ def test_icl_projective_identity_estimate_small_radius(B):
     assert len(corr) == 2 and np.all(corr["response"] <= 50.0)
 
 
+def test_projective_kdtree_counts(B):
+    """the counts the reference asserts for its KD-tree finder, on the HIP path (tests/test_ref_pins.py: ..kdtree_counts):
+    120, 2 -> 21 (ICL, test_correspondence_finders.cpp:370, :412, :427), 82, 56, 36, 104 (KITTI, :468, :609, :552, :568);
+    correspondences equal to the CPU checker's"""
+    from test_ref_pins import OracleBackend
+    O = OracleBackend()
+
+    def same(a, b):
+        return np.array_equal(a["fixed_idx"], b["fixed_idx"]) and np.array_equal(a["moving_idx"], b["moving_idx"]) and np.array_equal(a["response"], b["response"])
+
+    T = np.linalg.inv(rp.icl_relative(50, 0))
+    _, perfect = rp.icl_projective(B, rp.KDTREE, 50, T)
+    assert len(perfect) == 120 and same(perfect, rp.icl_projective(O, rp.KDTREE, 50, T)[1])
+    f, c10 = rp.icl_projective(B, rp.KDTREE, 50, np.eye(4), max_radius=10)
+    f.set_params(f.make_params(rp.finder_params(rp.ICL_K, rp.KDTREE, 0.1, 10.0, max_radius=100)))  # :419 param change
+    fx, mv = rp.icl_measurements(B, 50), rp.icl_measurements(B, 0)
+    f.set_fixed(fx["uv"], fx["desc"])
+    f.set_moving(mv["xyz"], mv["desc"])
+    c100, _ = f.compute()
+    assert len(c10) == 2 and len(c100) == 21
+    for frame, radius, Tk, want in ((1, 10, np.linalg.inv(rp.kitti_relative(1, 0)), 82), (2, 10, np.linalg.inv(rp.kitti_relative(2, 0)), 56),
+                                    (1, 10, np.eye(4), 36), (1, 100, np.eye(4), 104)):
+        _, c = rp.kitti_projective(B, rp.KDTREE, frame, radius, Tk)
+        assert len(c) == want and same(c, rp.kitti_projective(O, rp.KDTREE, frame, radius, Tk)[1]), (frame, radius, len(c), want)
+
+
 def test_kitti_projective_circle_perfect_estimate(B):
     n_fixed, corr = rp.kitti_projective(B, rp.CIRCLE, 1, 10, np.linalg.inv(rp.kitti_relative(1, 0)))  # :474-513
     assert n_fixed == 458
