@@ -610,9 +610,13 @@ typedef struct prs_map prs_map;
 PRS_API int prs_map_create(prs_context* ctx, int32_t capacity, int32_t max_measurements, int32_t max_frames, int32_t max_measured, prs_map** out);
 PRS_API int prs_map_destroy(prs_map* h);
 PRS_API int prs_map_clear(prs_map* h); /* a new local map: no landmarks, frame counter 0 */
+/* grows the landmark arrays to `capacity` (no-op if already that large): every landmark, its state, covariance, counters and
+ * measurement history are kept */
+PRS_API int prs_map_reserve(prs_map* h, int32_t capacity);
 PRS_API int prs_map_size(prs_map* h, int32_t* n_points, int32_t* frames_merged /* may be NULL */);
 /* setScene with allocated statistics: coords_in_scene [n][3]; state_in_world [n][3] or NULL (= the coordinates,
- * tests/test_mergers.cpp:268-271); covariance [n][9] or NULL (identity); desc [n][32]; n_opt [n] or NULL (0);
+ * tests/test_mergers.cpp:268-271); covariance [n][9] or NULL (zero: what statistics().allocate() leaves when no covariance is
+ * set, tests/ref_mapping.py:_seed_map; points the merger creates get the identity, merger_projective_impl.cpp:319); desc [n][32]; n_opt [n] or NULL (0);
  * first_measurement [n] or NULL: the camera measurement the landmark was created from (its .frame names a pose-table row set
  * with prs_map_set_frame_pose; tests/test_mergers.cpp:425-433) */
 PRS_API int prs_map_set_scene(prs_map* h,

@@ -739,6 +739,15 @@ public:
   void setCorrespondences(const CorrespondenceVector* correspondences_) { _correspondences = correspondences_; }
   void setMeasurementInScene(const float* T16) { std::memcpy(_measurement_in_scene, T16, sizeof(_measurement_in_scene)); }
   void setMeasurementInWorld(const float* T16) { std::memcpy(_measurement_in_world, T16, sizeof(_measurement_in_world)); }
+  // pre-sizes the device-resident map (grown in place: landmark states, covariances and counters are kept)
+  void reserve(size_t capacity) {
+    if (_map && (int32_t) capacity > _capacity) {
+      if (prs_map_reserve(_map, (int32_t) capacity) != PRS_OK) {
+        throw std::runtime_error(std::string("MergerRigidStereoTriangulationHIP::reserve|ERROR: ") + prs_last_error(_ctx->get()));
+      }
+      _capacity = (int32_t) capacity;
+    }
+  }
   size_t numberOfMergedPoints() const { return _n_merged; }
   size_t numberOfAddedPoints() const { return _n_added; }
   void compute() {
@@ -747,14 +756,23 @@ public:
     if (!_measurement) throw std::runtime_error("MergerProjective::compute|ERROR: measurement not set");
     if (!_correspondences) throw std::runtime_error("MergerProjective::compute|ERROR: correspondences not set");
     if (!param_projector) throw std::runtime_error("MergerProjective::compute|ERROR: projector not set");
-    const int32_t capacity = (int32_t) (_scene->size() + _measurement->size() + 1024);
-    if (!_map || capacity > _capacity) {
-      if (_map) prs_map_destroy(_map);
-      _map           = nullptr;
-      _capacity      = 2 * capacity;
-      const int rc   = prs_map_create(_ctx->get(), _capacity, 0, 4096, 8192, &_map);
+    // room for this frame's additions.  After the first upload the DEVICE copy of the scene is the master (landmark states in
+    // world coordinates, covariances, counters live there), so a map that has to grow is grown in place (prs_map_reserve keeps
+    // every array); only setScene() makes the host scene authoritative again.
+    int32_t on_device = 0;
+    if (_map && !_scene_changed) prs_map_size(_map, &on_device, nullptr);
+    const size_t scene_size = _scene_changed ? _scene->size() : (size_t) on_device;
+    const int32_t capacity  = (int32_t) (scene_size + _measurement->size() + 1024);
+    if (!_map) {
+      _capacity    = 2 * capacity;
+      const int rc = prs_map_create(_ctx->get(), _capacity, 0, 4096, 8192, &_map);
       if (rc != PRS_OK) throw std::runtime_error(std::string("MergerRigidStereoTriangulationHIP|ERROR: ") + prs_last_error(_ctx->get()));
       _scene_changed = true;
+    } else if (capacity > _capacity) {
+      _capacity = 2 * capacity;
+      if (prs_map_reserve(_map, _capacity) != PRS_OK) {
+        throw std::runtime_error(std::string("MergerRigidStereoTriangulationHIP|ERROR: ") + prs_last_error(_ctx->get()));
+      }
     }
     if (_scene_changed) {  // upload the scene once; afterwards the device copy is the master
       const size_t n = _scene->size();

@@ -304,6 +304,7 @@ SYMBOLS = {
     "prs_map_create": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
     "prs_map_destroy": (C.c_int, [_vp]),
     "prs_map_clear": (C.c_int, [_vp]),
+    "prs_map_reserve": (C.c_int, [_vp, C.c_int32]),
     "prs_map_size": (C.c_int, [_vp, _i32p, _i32p]),
     "prs_map_set_scene": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32]),
     "prs_map_set_frame_pose": (C.c_int, [_vp, C.c_int32, _vp]),

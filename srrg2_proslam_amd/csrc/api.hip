@@ -734,9 +734,11 @@ int prs_extract_features(prs_context* ctx,
   }
   // staging layout (same on both sides): image | n_features, status | keypoints | intensity | descriptors
   const size_t o_small = b_img, o_kp = o_small + b_small, o_int = o_kp + b_kp, o_desc = o_int + b_int;
-  memcpy(h, image, (size_t) rows * (size_t) pitch);
+  // (the last row of a pitched view, e.g. a cv::Mat ROI, owns only `cols` bytes)
+  const size_t image_bytes = (size_t) (rows - 1) * (size_t) pitch + (size_t) cols;
+  memcpy(h, image, image_bytes);
   hipStream_t s = ctx->stream;
-  hipError_t e  = hipMemcpyAsync(d, h, (size_t) rows * (size_t) pitch, hipMemcpyHostToDevice, s);
+  hipError_t e  = hipMemcpyAsync(d, h, image_bytes, hipMemcpyHostToDevice, s);
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_extract_features upload");
   }

@@ -58,10 +58,12 @@ int fail(prs_map* h, int status, const char* what) {
   return prs::ctx_fail(h ? h->ctx : nullptr, status, what);
 }
 
+// (an error return synchronises first: asynchronous copies from the caller's or local staging buffers may be in flight)
 #define MAP_TRY(x)                                           \
   do {                                                       \
     hipError_t e_ = (x);                                     \
     if (e_ != hipSuccess) {                                  \
+      (void) hipStreamSynchronize(h->ctx->stream);           \
       return prs::ctx_fail_hip(h->ctx, e_, "prs_map: " #x);  \
     }                                                        \
   } while (0)
@@ -140,6 +142,73 @@ int prs_map_destroy(prs_map* h) {
   return PRS_OK;
 }
 
+int prs_map_reserve(prs_map* h, int32_t capacity) {
+  if (!h) {
+    return PRS_ERR_NULL;
+  }
+  if (capacity <= h->capacity) {
+    return PRS_OK;
+  }
+  (void) hipSetDevice(h->ctx->device);
+  hipStream_t s    = h->ctx->stream;
+  const size_t cap = (size_t) capacity, n = (size_t) h->n_points;
+  const size_t mm  = (size_t) (h->max_measurements > 0 ? h->max_measurements : 1);
+  float *coords = nullptr, *state = nullptr, *cov = nullptr;
+  uint8_t *desc = nullptr, *inlier = nullptr;
+  uint32_t *n_opt = nullptr, *n_meas = nullptr;
+  prs_camera_measurement* meas = nullptr;
+  int32_t* index_map           = nullptr;
+  hipError_t e = alloc(&coords, cap * 4);
+  e = e == hipSuccess ? alloc(&desc, cap * PRS_DESC_BYTES) : e;
+  e = e == hipSuccess ? alloc(&state, cap * 4) : e;
+  e = e == hipSuccess ? alloc(&cov, cap * 9) : e;
+  e = e == hipSuccess ? alloc(&n_opt, cap) : e;
+  e = e == hipSuccess ? alloc(&inlier, cap) : e;
+  e = e == hipSuccess ? alloc(&n_meas, cap) : e;
+  e = e == hipSuccess ? alloc(&meas, cap * mm) : e;
+  e = e == hipSuccess ? alloc(&index_map, cap) : e;
+  auto copy = [&](void* dst, const void* src, size_t bytes) {
+    if (e == hipSuccess && bytes) {
+      e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+    }
+  };
+  copy(coords, h->d_coords, n * 16);
+  copy(desc, h->d_desc, n * PRS_DESC_BYTES);
+  copy(state, h->d_state, n * 16);
+  copy(cov, h->d_cov, n * 36);
+  copy(n_opt, h->d_n_opt, n * 4);
+  copy(inlier, h->d_inlier, n);
+  copy(n_meas, h->d_n_meas, n * 4);
+  copy(meas, h->d_meas, n * mm * sizeof(prs_camera_measurement));
+  if (e == hipSuccess) {
+    e = hipStreamSynchronize(s);
+  }
+  void* fresh[] = {coords, desc, state, cov, n_opt, inlier, n_meas, meas, index_map};
+  if (e != hipSuccess) {
+    for (void* p : fresh) {
+      if (p) {
+        (void) hipFree(p);
+      }
+    }
+    return prs::ctx_fail_hip(h->ctx, e, "prs_map_reserve: device allocation / copy");
+  }
+  void* old[] = {h->d_coords, h->d_desc, h->d_state, h->d_cov, h->d_n_opt, h->d_inlier, h->d_n_meas, h->d_meas, h->d_index_map};
+  for (void* p : old) {
+    (void) hipFree(p);
+  }
+  h->d_coords = coords;
+  h->d_desc = desc;
+  h->d_state = state;
+  h->d_cov = cov;
+  h->d_n_opt = n_opt;
+  h->d_inlier = inlier;
+  h->d_n_meas = n_meas;
+  h->d_meas = meas;
+  h->d_index_map = index_map;
+  h->capacity = capacity;
+  return PRS_OK;
+}
+
 int prs_map_clear(prs_map* h) {
   if (!h) {
     return PRS_ERR_NULL;
@@ -200,7 +269,7 @@ int prs_map_set_scene(prs_map* h,
       s4[4 * i + k] = st[3 * i + k];
     }
     for (int k = 0; k < 9; ++k) {
-      cov[9 * i + k] = covariance ? covariance[9 * i + k] : ((k % 4) == 0 ? 1.0f : 0.0f);
+      cov[9 * i + k] = covariance ? covariance[9 * i + k] : 0.0f;  // statistics().allocate() without setCovariance (test_mergers.cpp:268-271)
     }
     nopt[i] = n_opt ? n_opt[i] : 0u;
     if (first_measurement) {
@@ -293,6 +362,18 @@ int prs_map_merge(prs_map* h,
   if (dim < 2 || dim > 4) {
     return fail(h, PRS_ERR_UNSUPPORTED, "prs_map_merge: measurement_dim must be 2, 3 or 4");
   }
+  // host-side validation of the correspondence vector before anything is uploaded
+  int32_t need = 0;
+  for (int32_t i = 0; i < n_corr; ++i) {
+    if (corr[i].fixed_idx < 0 || corr[i].moving_idx < 0) {
+      return fail(h, PRS_ERR_RANGE, "prs_map_merge: negative index in the correspondence vector");
+    }
+    const int32_t ci = corr_from_aligner ? corr[i].moving_idx : corr[i].fixed_idx;
+    need             = ci + 1 > need ? ci + 1 : need;
+  }
+  if (scene_index_map && need > h->capacity) {
+    return fail(h, PRS_ERR_RANGE, "prs_map_merge: correspondence names a clipped index beyond the map capacity");
+  }
   (void) hipSetDevice(h->ctx->device);
   hipStream_t s = h->ctx->stream;
   const size_t nm = (size_t) n_measured;
@@ -310,19 +391,9 @@ int prs_map_merge(prs_map* h,
   if (n_corr > 0) {
     MAP_TRY(hipMemcpyAsync(h->d_corr, corr, (size_t) n_corr * sizeof(prs_corr), hipMemcpyHostToDevice, s));
   }
-  if (scene_index_map) {
+  if (scene_index_map && need > 0) {
     // clipped index -> scene index for every clipped point the correspondences may name
-    int32_t need = 0;
-    for (int32_t i = 0; i < n_corr; ++i) {
-      const int32_t ci = corr_from_aligner ? corr[i].moving_idx : corr[i].fixed_idx;
-      need             = ci + 1 > need ? ci + 1 : need;
-    }
-    if (need > h->capacity) {
-      return fail(h, PRS_ERR_RANGE, "prs_map_merge: correspondence names a clipped index beyond the map capacity");
-    }
-    if (need > 0) {
-      MAP_TRY(hipMemcpyAsync(h->d_index_map, scene_index_map, (size_t) need * 4, hipMemcpyHostToDevice, s));
-    }
+    MAP_TRY(hipMemcpyAsync(h->d_index_map, scene_index_map, (size_t) need * 4, hipMemcpyHostToDevice, s));
   }
   int32_t head[4] = {h->n_points, n_measured, n_corr, h->frames};
   MAP_TRY(hipMemcpyAsync(h->d_small, head, sizeof(head), hipMemcpyHostToDevice, s));
@@ -359,6 +430,7 @@ int prs_map_merge(prs_map* h,
   b.corr_from_aligner = corr_from_aligner ? 1 : 0;
   const int rc = prs::merge_batch_launch(h->ctx, params, &b);
   if (rc != PRS_OK) {
+    (void) hipStreamSynchronize(s);  // (the staging vector of the measurements goes out of scope)
     return rc;
   }
   struct {

@@ -711,11 +711,18 @@ class MapHandle:
         self.capacity = int(capacity)
         rc = _lib.load().prs_map_create(ctx._h, int(capacity), int(max_measurements), int(max_frames), int(max_measured), C.byref(self._h))
         _check(ctx, rc, "prs_map_create")
+        ctx._children.add(self)  # the handle points into the context: Context.close() closes it first
 
     def close(self):
-        if self._h:
-            _lib.load().prs_map_destroy(self._h)
+        if getattr(self, "_h", None):
+            if getattr(self._ctx, "_h", None):  # (a context that is gone has already released the device memory's owner)
+                _lib.load().prs_map_destroy(self._h)
             self._h = C.c_void_p()
+
+    def reserve(self, capacity):
+        """grow the landmark arrays in place (every landmark keeps its state, covariance and history)"""
+        _check(self._ctx, _lib.load().prs_map_reserve(self._h, int(capacity)), "prs_map_reserve")
+        self.capacity = max(self.capacity, int(capacity))
 
     def __del__(self):
         try:

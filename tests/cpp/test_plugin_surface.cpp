@@ -467,6 +467,77 @@ static void test_MergerRigidStereoTriangulation(ContextPtr ctx) {
   }
 }
 
+// a map that has to grow between two merges keeps its landmark statistics (the device copy is the master after the first
+// upload): two mergers on the same frames, one of them grown in place between the frames -- same scene afterwards.  (State,
+// covariance and measurement history across prs_map_reserve are compared bit for bit, with world != scene, in
+// tests/test_ref_mapping_gpu.py.)
+static void test_MergerGrowsInPlace(ContextPtr ctx) {
+  const float K[9] = {718.856f, 0, 607.193f, 0, 718.856f, 185.216f, 0, 0, 1};
+  const float bx   = 386.1448f;
+  std::mt19937 rng(12);
+  std::uniform_real_distribution<float> ux(-8.f, 8.f), uy(-2.f, 1.5f), uz(6.f, 40.f);
+  PointIntensityDescriptorVectorCloud<3> scene_a, scene_b;
+  PointIntensityDescriptorVectorCloud<4> measurements;
+  while (scene_a.size() < 120) {
+    const float X = ux(rng), Y = uy(rng), Z = uz(rng);
+    const float uL = std::round(K[0] * X / Z + K[2]), v = std::round(K[4] * Y / Z + K[5]), uR = std::round(uL - bx / Z);
+    if (uL < 1 || uL >= 1240 || v < 1 || v >= 375 || uL - uR < 1.f) continue;
+    PointIntensityDescriptor_<4> m;
+    m.coords[0] = uL;
+    m.coords[1] = v;
+    m.coords[2] = uR;
+    m.coords[3] = v;
+    randomDescriptor(rng, m.descriptor_row);
+    measurements.push_back(m);
+    const float d = uL - uR, z = bx / d;
+    PointIntensityDescriptor_<3> p;
+    p.coords[0] = (uL - K[2]) / K[0] * z + 0.05f;  // (not exactly the triangulated point: the weighted mean has something to do)
+    p.coords[1] = (v - K[5]) / K[4] * z;
+    p.coords[2] = z + 0.1f;
+    std::memcpy(p.descriptor_row, m.descriptor_row, PRS_DESC_BYTES);
+    scene_a.push_back(p);
+  }
+  scene_b = scene_a;
+  float in_scene[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  float in_world[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  CorrespondenceVector mirror, half;
+  for (size_t i = 0; i < scene_a.size(); ++i) mirror.push_back(Correspondence{(int) i, (int) i, 0.f});
+  for (size_t i = 0; i < mirror.size(); i += 2) half.push_back(mirror[i]);
+  MergerRigidStereoTriangulationHIP a(ctx), b(ctx);
+  MergerRigidStereoTriangulationHIP* both[2] = {&a, &b};
+  PointIntensityDescriptorVectorCloud<3>* scenes[2] = {&scene_a, &scene_b};
+  for (int k = 0; k < 2; ++k) {
+    MergerRigidStereoTriangulationHIP& m = *both[k];
+    m.param_projector->setCameraMatrix(K);
+    m.param_projector->param_canvas_rows.setValue(376);
+    m.param_projector->param_canvas_cols.setValue(1241);
+    m.setBaselineRightInLeftPixels(bx);
+    m.param_maximum_distance_appearance.setValue(50);
+    m.param_maximum_distance_geometry_meters_squared.setValue(25);
+    m.setMeasurementInScene(in_scene);
+    m.setMeasurementInWorld(in_world);
+    m.setScene(scenes[k]);
+    m.setMeasurement(&measurements);
+    m.setCorrespondences(&mirror);
+    m.compute();
+    ASSERT_TRUE(m.numberOfMergedPoints() > 0);
+    if (k == 1) m.reserve(20000);  // grow the device map between the frames
+    m.setCorrespondences(&half);
+    m.compute();
+    m.compute();
+  }
+  ASSERT_EQ(scene_a.size(), scene_b.size());
+  bool moved = false;
+  for (size_t i = 0; i < scene_a.size() && i < scene_b.size(); ++i) {
+    for (int c = 0; c < 3; ++c) {
+      ASSERT_TRUE(scene_a[i].coords[c] == scene_b[i].coords[c]);
+    }
+    ASSERT_TRUE(scene_a[i].number_of_optimizations == scene_b[i].number_of_optimizations);
+    moved = moved || scene_a[i].number_of_optimizations > 1;
+  }
+  ASSERT_TRUE(moved);  // the landmarks were refined across the frames (their world states were used after the growth)
+}
+
 int main() {
   ContextPtr ctx;
   try {
@@ -491,6 +562,7 @@ int main() {
   RUN(test_Bruteforce_CloudVersusItself);
   RUN(test_IntensityFeatureExtractorBinned);
   RUN(test_MergerRigidStereoTriangulation);
+  RUN(test_MergerGrowsInPlace);
   std::printf("%d failure(s)\n", g_failures);
   return g_failures ? 1 : 0;
 }

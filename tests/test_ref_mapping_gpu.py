@@ -78,6 +78,26 @@ def test_merger_cases_through_the_host_handle(B, hip_ctx, oracle):
         assert np.array_equal(bits(sc["coords"]), bits(om_.coords[:n, :3])) and np.array_equal(bits(sc["state"]), bits(om_.state[:n, :3])), case["name"]
         assert np.array_equal(sc["desc"], om_.desc[:n]) and np.array_equal(sc["n_opt"], om_.n_opt[:n]) and np.array_equal(sc["inlier"], om_.inlier[:n])
         h.close()
+    # a map grown in place between two merges keeps every landmark's state, covariance, counters and history
+    cases = {c["name"]: c for c in rm.merger_cases(B)}
+    for kind in ("weighted_mean", "smoother", "stereo_ekf"):
+        c0, c1 = cases["kitti_%s_00_to_00" % kind], cases["kitti_%s_00_to_01" % kind]
+        m0, n0 = c0["map"], c0["map"].n_points
+        out = []
+        for grow in (False, True):
+            h = ops.MapHandle(hip_ctx, n0 + 300 if grow else 4096, m0.max_measurements, max_frames=4, max_measured=1024)
+            first = np.ascontiguousarray(m0.meas[:n0, 0]) if m0.max_measurements > 0 else None
+            h.set_scene(m0.coords[:n0, :3], m0.desc[:n0], state=m0.state[:n0, :3], covariance=m0.covariance[:n0], n_opt=m0.n_opt[:n0], first_measurement=first)
+            h.set_frame_pose(0, rm.I4)
+            h.merge(_gpu_params(c0["params"]), c0["T"], c0["T"], c0["fixed"], c0["desc"], c0["corr"])
+            if grow:
+                h.reserve(4096)
+            got = h.merge(_gpu_params(c1["params"]), c1["T"], c1["T"], c1["fixed"], c1["desc"], c1["corr"])
+            out.append((got, h.scene()))
+            h.close()
+        assert out[0][0] == out[1][0], kind
+        for key in ("coords", "state", "desc", "n_opt", "inlier"):
+            assert np.array_equal(np.ascontiguousarray(out[0][1][key]).view(np.uint8), np.ascontiguousarray(out[1][1][key]).view(np.uint8)), (kind, key)
     # loud errors: more measurements than the handle holds, a full pose table
     h = ops.MapHandle(hip_ctx, 64, 0, max_frames=1, max_measured=8)
     case = rm.merger_cases(B)[0]
