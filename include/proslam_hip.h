@@ -336,15 +336,27 @@ typedef struct {
                                     gets PRS_ERR_CAPACITY in result[].warnings */
 } prs_align_batch;
 
-/* mode PRS_MODE_FINDER only enqueues.  mode PRS_MODE_ALIGN BLOCKS THE CALLING THREAD until the batch is done: the loop
- * alternates a search launch and a Gauss-Newton launch over the frames that are still pending and reads one 4-byte
- * counter back after every round (4-5 rounds at kitti.conf settings); results are complete in device memory when it
- * returns.  A caller that must stay asynchronous runs it on its own thread (a context has a single owner). */
+/* mode PRS_MODE_FINDER and PRS_MODE_LINEARIZE only enqueue.  mode PRS_MODE_ALIGN alternates a search launch and a Gauss-Newton
+ * launch over the frames that are still pending (4-5 rounds at kitti.conf settings) and BLOCKS until the batch is done
+ * (= prs_align_batch_enqueue + prs_align_batch_finish); results are complete in device memory when it returns. */
 PRS_API int prs_align_batch_run(prs_context* ctx,
                                 const prs_pcf_params* finder,
                                 const prs_aligner_params* aligner,
                                 const prs_align_batch* batch,
                                 int32_t mode);
+/* The two halves of mode PRS_MODE_ALIGN, for callers that pipeline (several contexts from one thread, or other work between
+ * the two calls).  enqueue: `rounds` (0 = the nominal 5) x (search launch, Gauss-Newton launch) on the context's stream and
+ * nothing else -- no host synchronisation, no readback; every launch skips the frames that are finished or not waiting for
+ * it.  Once the context's scratch buffers exist (after a first batch of the same shape) the sequence allocates nothing and
+ * can be captured in a HIP graph.  finish: one 4-byte readback; while frames are still pending (finder retries shift the
+ * nominal schedule) four more rounds and another readback.  Between the two calls the context must not start another
+ * aligner batch, and `batch`'s buffers must stay valid; the structs themselves are copied. */
+PRS_API int prs_align_batch_enqueue(prs_context* ctx,
+                                    const prs_pcf_params* finder,
+                                    const prs_aligner_params* aligner,
+                                    const prs_align_batch* batch,
+                                    int32_t rounds);
+PRS_API int prs_align_batch_finish(prs_context* ctx);
 
 /* ---- host, one frame: stateful finder handle mirroring the reference object -------------------
  * setFixed / setMoving / setLocalMapInSensor / compute (tests/test_correspondence_finders.cpp:314,

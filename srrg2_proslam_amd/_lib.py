@@ -277,6 +277,8 @@ SYMBOLS = {
     "prs_stereo_match": (C.c_int, [_vp, C.POINTER(StereoParams), _vp, _vp, C.c_int32, _vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
     "prs_stereo_match_batch": (C.c_int, [_vp, C.POINTER(StereoParams), C.POINTER(StereoBatch)]),
     "prs_align_batch_run": (C.c_int, [_vp, C.POINTER(PcfParams), C.POINTER(AlignerParams), C.POINTER(AlignBatch), C.c_int32]),
+    "prs_align_batch_enqueue": (C.c_int, [_vp, C.POINTER(PcfParams), C.POINTER(AlignerParams), C.POINTER(AlignBatch), C.c_int32]),
+    "prs_align_batch_finish": (C.c_int, [_vp]),
     "prs_pcf_create": (C.c_int, [_vp, C.POINTER(PcfParams), C.POINTER(_vp)]),
     "prs_pcf_destroy": (C.c_int, [_vp]),
     "prs_pcf_set_params": (C.c_int, [_vp, C.POINTER(PcfParams)]),

@@ -2188,7 +2188,24 @@ static inline uint32_t align_up16(uint32_t v) {
   return (v + 15u) / 16u * 16u;
 }
 
-int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs_aligner_params* aligner, const prs_align_batch* batch, int mode) {
+// an enqueued batch of the split pipeline (kept in the context between align_batch_launch and align_batch_finish)
+struct SplitJob {
+  bool active = false;
+  AlignArgs g, gs;                      // Gauss-Newton / search kernel arguments
+  void (*search)(AlignArgs) = nullptr;  // kernel instantiations of this batch
+  void (*gn)(AlignArgs)     = nullptr;
+  size_t lds_search = 0, lds_gn = 0;
+  int total = 0, limit = 0;  // rounds launched so far / upper bound
+  int ev_used = 0;
+  bool stamps = false;
+};
+static int split_rounds(prs_context* ctx, SplitJob* job, int rounds);
+
+// mode PRS_MODE_ALIGN with the split pipeline only ENQUEUES `rounds` rounds (0 = the nominal five); align_batch_finish completes it
+int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs_aligner_params* aligner, const prs_align_batch* batch, int mode, int rounds) {
+  if (ctx->align_job && static_cast<SplitJob*>(ctx->align_job)->active) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_*: the previous batch of this context has not been finished (prs_align_batch_finish)");
+  }
   if (!finder || !aligner || !batch || !batch->fixed || !batch->fixed_desc || !batch->n_fixed || !batch->moving ||
       !batch->moving_desc || !batch->n_moving || !batch->state || !batch->X || !batch->corr || !batch->n_corr || !batch->result) {
     return ctx_fail(ctx, PRS_ERR_NULL, "prs_align_batch_run: fixed, moving, correspondences, state or result not set");
@@ -2355,23 +2372,75 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
     return ctx_fail_hip(ctx, e, "prs_align_batch_run attribute");
   }
   hipLaunchKernelGGL(split_init_kernel, dim3((batch->batch + 255) / 256), dim3(256), 0, stream, g.ctl, batch->result, g.pending, batch->batch);
-  // nominal schedule: searches at finder iterations 0, 1, k, 2k, ... until the finder latches (typically
-  // 4 rounds); retries can shift it, so completion is confirmed by reading back the pending counter
-  int rounds_left = 5;
-  int total       = 0;
-  const int limit = 2 * (aligner->max_iterations + inlier_run_length(*aligner)) + 8;
-  int ev_used = 0;
+  // (the rectified-stereo factor, the one kitti.conf / euroc.conf use, has its own instantiation: the factor type as a
+  // compile-time constant removes ~10 selects per linearised correspondence; so does not remembering the factor classes)
+  const bool fast = aligner->factor_type == PRS_FACTOR_STEREO && !aligner->keep_only_inlier_correspondences;
+  auto gnk        = max_fixed <= 4 * 128 ? (fast ? gn_kernel<4, PRS_FACTOR_STEREO, false> : gn_kernel<4, 0, true>)
+                                         : (fast ? gn_kernel<8, PRS_FACTOR_STEREO, false> : gn_kernel<8, 0, true>);
+  // The job lives in the context until align_batch_finish: the rounds are plain launches on the context's stream (no host
+  // synchronisation here, the sequence can be captured in a HIP graph once the scratch buffers exist).
+  SplitJob* job = static_cast<SplitJob*>(ctx->align_job);
+  if (!job) {
+    job                 = new SplitJob();
+    ctx->align_job      = job;
+    ctx->align_job_free = [](void* p) { delete static_cast<SplitJob*>(p); };
+  }
+  job->active      = true;
+  job->g           = g;
+  job->gs          = gs;
+  job->search      = reinterpret_cast<void (*)(AlignArgs)>(skernel);
+  job->gn          = reinterpret_cast<void (*)(AlignArgs)>(gnk);
+  job->lds_search  = lds_search;
+  job->lds_gn      = lds_gn;
+  job->total       = 0;
+  job->limit       = 2 * (aligner->max_iterations + inlier_run_length(*aligner)) + 8;
+  job->ev_used     = 0;
+  job->stamps      = stamps_split;
+  return split_rounds(ctx, job, rounds > 0 ? rounds : 5);
+}
+
+// `rounds` x (search launch, Gauss-Newton launch) over the frames that are still pending; every launch skips the others
+static int split_rounds(prs_context* ctx, SplitJob* job, int rounds) {
+  hipStream_t stream = ctx_stream(ctx);
   auto tick = [&]() {  // measurement only (prs_context_enable_timing): one event per kernel boundary
-    if (ctx->timing && ev_used < 3 * 64) {
-      if (!ctx->timing_ev[ev_used]) {
-        (void) hipEventCreate(&ctx->timing_ev[ev_used]);
+    if (ctx->timing && job->ev_used < 3 * 64) {
+      if (!ctx->timing_ev[job->ev_used]) {
+        (void) hipEventCreate(&ctx->timing_ev[job->ev_used]);
       }
-      (void) hipEventRecord(ctx->timing_ev[ev_used], stream);
-      ++ev_used;
+      (void) hipEventRecord(ctx->timing_ev[job->ev_used], stream);
+      ++job->ev_used;
     }
   };
+  const int batch = job->g.b.batch;
+  for (int r = 0; r < rounds; ++r) {
+    (void) hipMemsetAsync(job->g.pending, 0, sizeof(int), stream);
+    tick();
+    hipLaunchKernelGGL(job->search, dim3(batch), dim3(kSearchThreads), job->lds_search, stream, job->gs);
+    tick();
+    if (job->stamps) {
+      ctx_report_stamps(ctx, batch, 10, "search launch (split): - | - | - | - || lattice build | projection+search | staging (keys, fixed rows -> LDS) | filter | commit");
+    }
+    hipLaunchKernelGGL(job->gn, dim3(batch), dim3(kGnThreads), job->lds_gn, stream, job->g);
+    tick();
+    ++job->total;
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    job->active = false;
+    return ctx_fail_hip(ctx, e, "prs_align_batch_run split launch");
+  }
+  return PRS_OK;
+}
+
+// blocks until the enqueued batch is complete: one 4-byte readback per group of rounds; more rounds while frames are pending
+int align_batch_finish(prs_context* ctx) {
+  SplitJob* job = static_cast<SplitJob*>(ctx->align_job);
+  if (!job || !job->active) {
+    return PRS_OK;
+  }
+  hipStream_t stream = ctx_stream(ctx);
   auto collect = [&]() {  // after a stream synchronisation: add up (search, GN) pairs of [e0, e1, e2] triples
-    for (int i = 0; i + 2 < ev_used; i += 3) {
+    for (int i = 0; i + 2 < job->ev_used; i += 3) {
       float a = 0.f, b = 0.f;
       if (hipEventElapsedTime(&a, ctx->timing_ev[i], ctx->timing_ev[i + 1]) == hipSuccess &&
           hipEventElapsedTime(&b, ctx->timing_ev[i + 1], ctx->timing_ev[i + 2]) == hipSuccess) {
@@ -2381,49 +2450,32 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
         ++ctx->n_gn;
       }
     }
-    ev_used = 0;
+    job->ev_used = 0;
   };
   for (;;) {
-    for (int r = 0; r < rounds_left; ++r) {
-      (void) hipMemsetAsync(g.pending, 0, sizeof(int), stream);
-      tick();
-      hipLaunchKernelGGL(skernel, dim3(batch->batch), dim3(kSearchThreads), lds_search, stream, gs);
-      tick();
-      if (stamps_split) {
-        ctx_report_stamps(ctx, batch->batch, 10, "search launch (split): - | - | - | - || lattice build | projection+search | staging (keys, fixed rows -> LDS) | filter | commit");
-      }
-      {
-        // (the rectified-stereo factor, the one kitti.conf / euroc.conf use, has its own instantiation: the factor type as a
-        // compile-time constant removes ~10 selects per linearised correspondence; so does not remembering the factor classes)
-        const bool fast = aligner->factor_type == PRS_FACTOR_STEREO && !aligner->keep_only_inlier_correspondences;
-        auto gnk        = max_fixed <= 4 * 128 ? (fast ? gn_kernel<4, PRS_FACTOR_STEREO, false> : gn_kernel<4, 0, true>)
-                                               : (fast ? gn_kernel<8, PRS_FACTOR_STEREO, false> : gn_kernel<8, 0, true>);
-        hipLaunchKernelGGL(gnk, dim3(batch->batch), dim3(kGnThreads), lds_gn, stream, g);
-      }
-      tick();
-      ++total;
-    }
-    e = hipGetLastError();
-    if (e != hipSuccess) {
-      return ctx_fail_hip(ctx, e, "prs_align_batch_run split launch");
-    }
-    int pending = 0;
-    e           = hipMemcpyAsync(&pending, g.pending, sizeof(int), hipMemcpyDeviceToHost, stream);
+    int pending  = 0;
+    hipError_t e = hipMemcpyAsync(&pending, job->g.pending, sizeof(int), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) {
       e = hipStreamSynchronize(stream);
     }
     if (e != hipSuccess) {
-      return ctx_fail_hip(ctx, e, "prs_align_batch_run split completion check");
+      job->active = false;
+      return ctx_fail_hip(ctx, e, "prs_align_batch_finish: completion check");
     }
     collect();
     if (pending == 0) {
       break;
     }
-    if (total > limit) {
-      return ctx_fail(ctx, PRS_ERR_HIP, "prs_align_batch_run: split pipeline did not finish");
+    if (job->total > job->limit) {
+      job->active = false;
+      return ctx_fail(ctx, PRS_ERR_HIP, "prs_align_batch_finish: split pipeline did not finish");
     }
-    rounds_left = 4;
+    const int rc = split_rounds(ctx, job, 4);
+    if (rc != PRS_OK) {
+      return rc;
+    }
   }
+  job->active = false;
   return PRS_OK;
 }
 

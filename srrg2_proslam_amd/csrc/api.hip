@@ -211,6 +211,9 @@ int prs_context_destroy(prs_context* ctx) {
   }
   (void) hipSetDevice(ctx->device);
   (void) hipStreamSynchronize(ctx->stream);
+  if (ctx->align_job && ctx->align_job_free) {
+    ctx->align_job_free(ctx->align_job);
+  }
   if (ctx->d_scratch) {
     (void) hipFree(ctx->d_scratch);
   }
@@ -391,7 +394,24 @@ int prs_align_batch_run(prs_context* ctx, const prs_pcf_params* finder, const pr
     return PRS_ERR_NULL;
   }
   (void) hipSetDevice(ctx->device);
-  return align_batch_launch(ctx, finder, aligner, batch, mode);
+  const int rc = align_batch_launch(ctx, finder, aligner, batch, mode, 0);
+  return rc != PRS_OK ? rc : align_batch_finish(ctx);
+}
+
+int prs_align_batch_enqueue(prs_context* ctx, const prs_pcf_params* finder, const prs_aligner_params* aligner, const prs_align_batch* batch, int32_t rounds) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  (void) hipSetDevice(ctx->device);
+  return align_batch_launch(ctx, finder, aligner, batch, PRS_MODE_ALIGN, rounds);
+}
+
+int prs_align_batch_finish(prs_context* ctx) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  (void) hipSetDevice(ctx->device);
+  return align_batch_finish(ctx);
 }
 
 int prs_triangulate_dev(prs_context* ctx, const prs_triangulator_params* params, const float* d_uvuv, int64_t n, float* d_xyz4) {

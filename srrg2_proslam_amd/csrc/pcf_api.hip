@@ -161,7 +161,10 @@ int run(prs_pcf* h, const prs_aligner_params* aligner, int mode, const float* X_
     PCF_TRY(hipMemcpyAsync(sl.prior_mean, h->prior_mean, sizeof(float) * 16, hipMemcpyHostToDevice, s));
     b.prior_mean = sl.prior_mean;
   }
-  const int rc     = prs::align_batch_launch(h->ctx, &h->params, &ap, &b, mode);
+  int rc           = prs::align_batch_launch(h->ctx, &h->params, &ap, &b, mode, 0);
+  if (rc == PRS_OK) {
+    rc = prs::align_batch_finish(h->ctx);
+  }
   if (rc != PRS_OK) {
     return rc;
   }

@@ -31,6 +31,9 @@ struct prs_context {
   double t_search_ms = 0.0, t_gn_ms = 0.0;
   long long n_search = 0, n_gn = 0;
   hipEvent_t timing_ev[3 * 64] = {};
+  // the batch of the split aligner pipeline that has been enqueued and not yet finished (owned by align.hip)
+  void* align_job               = nullptr;
+  void (*align_job_free)(void*) = nullptr;
   // diagnostic phase stamps (PRS_STAMPS=1): never enabled in timed runs
   bool stamps_enabled   = false;
   unsigned long long* d_stamps = nullptr;
@@ -70,7 +73,8 @@ void ctx_report_stamps(prs_context* ctx, int blocks, int n_stamps, const char* l
 void fill_accept_table(const prs_stereo_params* params, int* best_lim, int16_t* bmax258);
 int stereo_match_v5_launch(prs_context* ctx, const prs_stereo_params* params, const prs_stereo_batch* batch);
 int stereo_match_batch_launch(prs_context* ctx, const prs_stereo_params* params, const prs_stereo_batch* batch);
-int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs_aligner_params* aligner, const prs_align_batch* batch, int mode);
+int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs_aligner_params* aligner, const prs_align_batch* batch, int mode, int rounds);
+int align_batch_finish(prs_context* ctx);
 int gn_step_launch(prs_context* ctx, const float* dH, const float* db, float damping, float* dX, int* dok);
 int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* params, const prs_bruteforce_batch* batch);
 int extract_features_launch(prs_context* ctx, const prs_extractor_params* params, const prs_extract_batch* batch);

@@ -479,10 +479,25 @@ class AlignFrames:
 
 
 def align_batch(ctx, finder_params, aligner_params_, frames, mode=_lib.MODE_ALIGN):
-    """enqueue the fused finder + aligner kernel on the context stream (asynchronous)"""
+    """prs_align_batch_run: the finder + aligner loop of every frame of the batch (mode ALIGN blocks until it is complete)"""
     d = frames.descriptor()
     rc = _lib.load().prs_align_batch_run(ctx._h, C.byref(finder_params), C.byref(aligner_params_), C.byref(d), int(mode))
     _check(ctx, rc, "prs_align_batch_run")
+    return rc
+
+
+def align_batch_enqueue(ctx, finder_params, aligner_params_, frames, rounds=0):
+    """prs_align_batch_enqueue: `rounds` search + Gauss-Newton rounds on the context stream, no host synchronisation"""
+    d = frames.descriptor()
+    rc = _lib.load().prs_align_batch_enqueue(ctx._h, C.byref(finder_params), C.byref(aligner_params_), C.byref(d), int(rounds))
+    _check(ctx, rc, "prs_align_batch_enqueue")
+    return rc
+
+
+def align_batch_finish(ctx):
+    """prs_align_batch_finish: wait for the enqueued batch, run more rounds for frames that are still pending"""
+    rc = _lib.load().prs_align_batch_finish(ctx._h)
+    _check(ctx, rc, "prs_align_batch_finish")
     return rc
 
 

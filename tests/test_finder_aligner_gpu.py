@@ -256,6 +256,65 @@ def test_split_pipeline_equals_fused_kernel(oracle, monkeypatch):
     assert np.array_equal(_bits(np.array(res.X)), _bits(outs[0][0]).ravel()) and corr_equal(rcorr, outs[0][1])
 
 
+def test_enqueue_finish_overlaps_two_contexts_and_replays_from_a_graph(oracle):
+    """prs_align_batch_enqueue / prs_align_batch_finish: two contexts (own streams) are enqueued back to back from one thread and
+    finished afterwards; one of them gets a single round so that finish has to add the rest.  Results equal the blocking call's.
+    Then the enqueue sequence is captured in a HIP graph (torch stream capture) and replayed on fresh inputs."""
+    import torch
+    cases = [make_align_case("kitti", 4100 + i, 500, 600) for i in range(6)]
+    cfg = cases[0][0]
+    fp, ap = ops.pcf_params(cfg), ops.aligner_params(cfg, stop_at_fixed_point=0)
+
+    def batch():
+        fr = ops.AlignFrames(0, len(cases), 700, 700)
+        for b, (_, fixed, dfix, mp, T, X0) in enumerate(cases):
+            fr.upload(b, fixed, dfix, mp["xyz"], oracle.info_scale_from_nopt(mp["n_opt"]), mp["desc"], X0)
+        return fr
+
+    def outputs(fr):
+        torch.cuda.synchronize()
+        return [(fr.X[b].cpu().numpy().view(np.uint32).copy(), fr.corr_of(b).copy(), fr.result_of(b).num_inliers, int(fr.state_of(b).current_iteration))
+                for b in range(len(cases))]
+
+    def same(a, b):
+        return all(np.array_equal(x[0], y[0]) and corr_equal(x[1], y[1]) and x[2:] == y[2:] for x, y in zip(a, b))
+
+    ref_ctx = ops.Context(0, stream="own")
+    ref_fr = batch()
+    ops.align_batch(ref_ctx, fp, ap, ref_fr)
+    want = outputs(ref_fr)
+    ca, cb = ops.Context(0, stream="own"), ops.Context(0, stream="own")
+    fa, fb = batch(), batch()
+    torch.cuda.synchronize()
+    ops.align_batch_enqueue(ca, fp, ap, fa)             # the nominal five rounds
+    ops.align_batch_enqueue(cb, fp, ap, fb, rounds=1)   # one round: finish must add the others
+    with pytest.raises(ops.ProslamHipError):            # a context has one batch in flight
+        ops.align_batch_enqueue(ca, fp, ap, fa)
+    ops.align_batch_finish(cb)
+    ops.align_batch_finish(ca)
+    assert same(outputs(fa), want) and same(outputs(fb), want)
+    ops.align_batch_finish(ca)  # nothing in flight: no-op
+    # graph capture of the enqueue sequence (the scratch buffers of `ca` exist by now: nothing is allocated during capture)
+    fg = batch()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ca.use_torch_stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            ca.use_torch_stream()
+            ops.align_batch_enqueue(ca, fp, ap, fg, rounds=6)
+        fresh = batch()  # reload the in/out buffers the capture pass has already advanced
+        for name in ("X", "state", "corr", "n_corr"):
+            getattr(fg, name).copy_(getattr(fresh, name))
+        side.synchronize()
+        graph.replay()
+        side.synchronize()
+        ops.align_batch_finish(ca)
+    assert same(outputs(fg), want)
+    for c in (ref_ctx, ca, cb):
+        c.close()
+
+
 def test_randomised_configurations_through_the_batched_pipeline(oracle, hip_ctx):
     """a bounded run of tools/fuzz_align.py: search patterns, finder / aligner parameters, cloud sizes, LDS bounds"""
     import os
