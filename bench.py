@@ -12,17 +12,23 @@ shard them with no data-path collective (weak scaling: per-GPU work is fixed).
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
-  roofline          the time-dominant kernel (the aligner's Gauss-Newton kernel, VALU-bound): achieved algorithmic
-                    fp32 TFLOP/s against the 157.3 TFLOP/s vector peak, live HIP-event time of its launches
-  roofline_search   the projective search kernel, roofline_matcher the stereo matcher kernel (the one BASELINE.json's
-                    north star prices: achieved algorithmic HBM GB/s against 8 TB/s)
+Rank 0 prints ONE JSON line (contract in the task statement).  Besides the contract's fields:
+  roofline          the time-dominant kernel of the step (a copy of one of the three below)
+  roofline_search / roofline_gn / roofline_matcher
+                    projective search kernel and stereo matcher kernel (the one BASELINE.json's north star prices): achieved
+                    algorithmic HBM GB/s against 8 TB/s; Gauss-Newton kernel: achieved algorithmic fp32 TFLOP/s against the
+                    157.3 TFLOP/s vector peak.  Times are HIP events on the launch stream, taken in a separate UNTIMED pass after
+                    the headline loop (per launch of every round), `traffic` comes from the committed PMC passes of the same command
   steady_state      the same step with the finder objects carried over from frame to frame (the reference's adaptive
                     radius / threshold schedule live) instead of fresh finders
-  cpu_baseline      the single-threaded CPU restatement (oracle, "port") timed on a bounded sample
-                    of the same frames on this box's host cores (rank 0, N=1 only)
-`--mode closed-loop` runs the whole per-frame loop (matcher -> clipper -> finder / aligner -> pose update -> merger)
-along the KITTI-00 ground-truth trajectory instead (tools/bench_tracking.py) and prints its line.
+  other_configs     BASELINE.json configs 3 and 4 and the reference's own keypoint budget: EuRoC-shaped stereo (752x480), TUM-shaped
+                    RGB-D (640x480, depth-projective path), KITTI at 1000 keypoints per image; a few steps each, with a parity check
+  closed_loop       the stateful per-frame loop (matcher -> clipper -> finder / aligner + motion prior -> pose update -> merger) along
+                    the KITTI-00 trajectory, checked frame by frame against the same loop on the CPU checker
+  cpu_baseline      the single-threaded CPU restatement ("port") timed on a bounded sample of the same frames on this box's host
+                    cores (rank 0, N=1 only); cpu_baseline_all_cores: one independent sequence per core
+`--mode closed-loop` prints the closed-loop line alone; under torch.distributed.run it shards KITTI sequences 00-07 (BASELINE.json
+config 5) over the ranks, longest first.
 """
 import argparse
 import json
@@ -48,18 +54,22 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=18432,
                     help="independent sequences (frames per step) per GPU; 18432 = 72 per CU, a multiple of the 1 / 3 / 8 workgroups "
-                         "per CU the matcher / search / GN kernels keep resident (no partial last wave); the five search + GN "
-                         "rounds of a step each end in a 4-byte readback, which larger batches amortise")
+                         "per CU the matcher / search / GN kernels keep resident (no partial last wave)")
     ap.add_argument("--keypoints", type=int, default=2000, help="keypoints per image (KITTI config: ~2000)")
     ap.add_argument("--moving", type=int, default=2000, help="local-map points per frame")
     ap.add_argument("--max-fixed", type=int, default=896, help="LDS sizing bound on stereo matches per frame")
     ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames generated on the host and tiled")
     ap.add_argument("--cpu-frames", type=int, default=1024, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-steady-state", action="store_true", help="skip the steady-state leg (profiles of the headline workload alone)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the EuRoC / TUM / KITTI-1000 legs and the closed loop")
+    ap.add_argument("--timing-steps", type=int, default=4, help="steps of the untimed per-kernel timing pass")
     ap.add_argument("--mode", choices=["frame", "closed-loop"], default="frame",
                     help="frame: the section-8(a) hot path on B independent frames per step (the headline); closed-loop: the "
                          "stateful per-frame loop incl. clipper and merger along the KITTI-00 trajectory (tools/bench_tracking.py)")
-    ap.add_argument("--frames", type=int, default=60, help="closed-loop mode: frames per sequence")
+    ap.add_argument("--frames", type=int, default=60, help="closed-loop mode: frames per sequence (single GPU)")
+    ap.add_argument("--frames-scale", type=float, default=0.02,
+                    help="closed-loop mode under torch.distributed: fraction of every KITTI sequence's length that is run")
     ap.add_argument("--all-iterations", action="store_true", help="disable the exact fixed-point early exit of the GN loop")
     ap.add_argument("--cpu-all-cores", type=int, default=-1,
                     help="worker processes of the all-core CPU figure (one independent sequence per core, SURVEY 8d); "
@@ -68,12 +78,19 @@ def parse():
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# synthetic frames of one configuration + the same frames on the CPU checker
+# ---------------------------------------------------------------------------------------------------------------------
 def make_unique_frames(cfg, n_unique, n_kp, n_moving, seed_base):
     from srrg2_proslam_amd import synthetic as syn
     frames = []
+    stereo = cfg["aligner"]["factor_type"] == 4
     for i in range(n_unique):
         rng = np.random.default_rng(seed_base + i)
-        fr = syn.stereo_frame(rng, cfg, n_kp, visible_fraction=0.36)  # M ~ 0.35 N stereo matches
+        if stereo:
+            fr = syn.stereo_frame(rng, cfg, n_kp, visible_fraction=0.36)  # M ~ 0.35 N stereo matches
+        else:
+            fr = syn.rgbd_frame(rng, cfg, n_kp)  # (u, v, d) + descriptor: what the RGB-D adaptor hands over (out of scope, SURVEY #9)
         T = syn.default_motion(rng, cfg)
         mp = syn.local_map(rng, cfg, fr, T, n_moving=n_moving, tracked_fraction=0.75)
         X0 = syn.perturb(rng, T, 0.05, 0.003)  # stand-in for the constant-velocity prediction error
@@ -81,16 +98,9 @@ def make_unique_frames(cfg, n_unique, n_kp, n_moving, seed_base):
     return frames
 
 
-def cpu_baseline(cfg, frames, n_frames):
-    """single-threaded oracle on the same frames: stereo match + assemble + triangulate + align"""
+def oracle_params(cfg):
     from oracle import binding as ob
-    ob.lib()
-    m = cfg["stereo_matcher"]
-    sp = ob.StereoParams(m["maximum_descriptor_distance"], m["maximum_distance_ratio_to_second_best"],
-                         m["minimum_matching_ratio"], m["maximum_disparity_pixels"], m["epipolar_line_thickness_pixels"])
-    cam, tri, f = cfg["camera"], cfg["triangulator"], cfg["projective_finder"]
-    tp = ob.TriangulatorParams(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["fx"] * cam["baseline_m"],
-                               tri["minimum_disparity_pixels"], tri["infinity_depth_meters"])
+    cam, f, al = cfg["camera"], cfg["projective_finder"], cfg["aligner"]
     proj = ob.Projector(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["cols"], cam["rows"],
                         cfg["projector"]["range_min"], cfg["projector"]["range_max"])
     pp = ob.PcfParams(f["maximum_descriptor_distance"], f["maximum_distance_ratio_to_second_best"], f["minimum_matching_ratio"],
@@ -98,37 +108,56 @@ def cpu_baseline(cfg, frames, n_frames):
                       f["maximum_search_radius_pixels"], f["minimum_search_radius_pixels"], f["search_radius_step_size_pixels"],
                       f["minimum_number_of_iterations"], f["maximum_estimate_change_norm_for_convergence"],
                       f["number_of_solver_iterations_per_projection"], f["search_type"], proj)
-    al = cfg["aligner"]
     ap = ob.AlignerParams()
     ap.factor_type = al["factor_type"]
     ap.fx, ap.fy, ap.cx, ap.cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
     ap.image_cols, ap.image_rows = cam["cols"], cam["rows"]
-    ap.baseline_left_in_right_px[0] = -cam["fx"] * cam["baseline_m"]
+    ap.baseline_left_in_right_px[0] = -cam["fx"] * cam.get("baseline_m", 0.0)
     for i in range(3):
         ap.diagonal_info[i] = al["diagonal_info"][i]
     ap.chi_threshold, ap.enable_inverse_depth_weighting = al["chi_threshold"], al["enable_inverse_depth_weighting"]
     ap.damping, ap.max_iterations = al["damping"], al["max_iterations"]
     ap.min_num_inliers, ap.min_num_correspondences = al["min_num_inliers"], al["min_num_correspondences"]
+    ap.enable_inlier_only_runs = int(al.get("enable_inlier_only_runs", 0))
+    ap.keep_only_inlier_correspondences = int(al.get("keep_only_inlier_correspondences", 0))
+    sp = tp = None
+    if cfg.get("stereo_matcher"):
+        m, tri = cfg["stereo_matcher"], cfg["triangulator"]
+        sp = ob.StereoParams(m["maximum_descriptor_distance"], m["maximum_distance_ratio_to_second_best"],
+                             m["minimum_matching_ratio"], m["maximum_disparity_pixels"], m["epipolar_line_thickness_pixels"])
+        tp = ob.TriangulatorParams(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["fx"] * cam["baseline_m"],
+                                   tri["minimum_disparity_pixels"], tri["infinity_depth_meters"])
+    return sp, tp, pp, ap
+
+
+def cpu_baseline(cfg, frames, n_frames):
+    """single-threaded CPU checker on the same frames: (stereo match + assemble + triangulate +) align -> (fps, seconds, poses)"""
+    from oracle import binding as ob
+    ob.lib()
+    sp, tp, pp, ap = oracle_params(cfg)
     scales = [ob.info_scale_from_nopt(fr["mp"]["n_opt"]) for fr in frames]
     poses = []
     t0 = time.perf_counter()
     for k in range(n_frames):
         d = frames[k % len(frames)]
         fr, mp = d["fr"], d["mp"]
-        corr, _ = ob.stereo_match(fr["uv_left"], fr["desc_left"], fr["uv_right"], fr["desc_right"], sp)
-        uvuv, src = ob.stereo_assemble(fr["uv_left"], fr["uv_right"], corr)
-        ob.triangulate(uvuv, tp)
+        if sp is not None:
+            corr, _ = ob.stereo_match(fr["uv_left"], fr["desc_left"], fr["uv_right"], fr["desc_right"], sp)
+            fixed, src = ob.stereo_assemble(fr["uv_left"], fr["uv_right"], corr)
+            ob.triangulate(fixed, tp)
+            fdesc = fr["desc_left"][src]
+            ap.mean_disparity = ob.mean_disparity(fixed)
+        else:
+            fixed, fdesc = fr["fixed"], fr["desc_fixed"]
         finder = ob.ProjectiveFinder(pp)
-        finder.set_fixed(uvuv, fr["desc_left"][src])
+        finder.set_fixed(fixed, fdesc)
         finder.set_moving(mp["xyz"], mp["desc"])
-        ap.mean_disparity = ob.mean_disparity(uvuv)
-        res, c = ob.align_frame(finder, ap, uvuv, mp["xyz"], scales[k % len(frames)], d["X0"])
+        res, c = ob.align_frame(finder, ap, fixed, mp["xyz"], scales[k % len(frames)], d["X0"])
         finder.close()
         if k < len(frames):
             poses.append((np.array(res.X, np.float32), c))
     dt = time.perf_counter() - t0
     return n_frames / dt, dt, poses
-
 
 
 def cpu_worker(args):
@@ -141,7 +170,7 @@ def cpu_worker(args):
 
 
 def cpu_all_cores(args, n_workers, frames_each):
-    """the oracle on every host core at once, one independent sequence per process"""
+    """the CPU checker on every host core at once, one independent sequence per process"""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(frames_each), "--keypoints", str(args.keypoints),
            "--moving", str(args.moving)]
@@ -162,7 +191,7 @@ def cpu_all_cores(args, n_workers, frames_each):
 
 
 def profile_evidence(frames_per_launch, keypoints):
-    """HBM bytes per bench step and VALU-busy fractions of the kernels from the COMMITTED rocprofv3 passes of this same command
+    """HBM bytes per bench step of the kernels from the COMMITTED rocprofv3 passes of this same command
     (profiles/rNN/rocprof_summary.json, written by tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in separate passes).
     Per /opt/skills/guides/MI355X_MICROARCH.md the counters are KiB and FETCH_SIZE reports half of wide coalesced reads on
     gfx950, so it is doubled.  Evidence from a file, not a live measurement: every figure carries its source.  Kernels are
@@ -195,13 +224,198 @@ def profile_evidence(frames_per_launch, keypoints):
     return None
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# B independent frames of one configuration resident in HBM; step() = one pass of the hot path over all of them
+# ---------------------------------------------------------------------------------------------------------------------
+class FrameWorkload:
+    def __init__(self, cfg, device_index, batch, keypoints, moving, max_fixed, unique, seed, all_iterations=False):
+        import torch
+        from srrg2_proslam_amd import ops
+        self.cfg, self.B, self.N, self.NM = cfg, batch, keypoints, moving
+        self.stereo = cfg["aligner"]["factor_type"] == 4
+        self.dev = torch.device("cuda", device_index)
+        self.uniq = make_unique_frames(cfg, unique, keypoints, moving, seed)
+        idx = (torch.arange(batch, device=self.dev) % len(self.uniq))
+        self.aframes = ops.AlignFrames(device_index, batch, keypoints, moving)
+        astage = ops.AlignFrames(device_index, len(self.uniq), 1 if self.stereo else keypoints, moving)
+        if self.stereo:
+            self.sframes = ops.StereoFrames(device_index, batch, keypoints, epilogue=True)
+            stage = ops.StereoFrames(device_index, len(self.uniq), keypoints, epilogue=False)
+        for u, d in enumerate(self.uniq):
+            fr, mp = d["fr"], d["mp"]
+            if self.stereo:
+                stage.upload(u, fr["uv_left"], fr["desc_left"], fr["uv_right"], fr["desc_right"])
+                astage.upload(u, np.zeros((0, 4), np.float32), np.zeros((0, 32), np.uint8), mp["xyz"],
+                              ops.info_scale_from_nopt(mp["n_opt"]), mp["desc"], d["X0"])
+            else:
+                astage.upload(u, fr["fixed"], fr["desc_fixed"], mp["xyz"], ops.info_scale_from_nopt(mp["n_opt"]), mp["desc"], d["X0"])
+        pairs = [(self.aframes.moving, astage.moving), (self.aframes.moving_desc, astage.moving_desc), (self.aframes.n_moving, astage.n_moving)]
+        if self.stereo:
+            sf = self.sframes
+            pairs += [(sf.left_kp, stage.left_kp), (sf.right_kp, stage.right_kp), (sf.left_desc, stage.left_desc),
+                      (sf.right_desc, stage.right_desc), (sf.n_left, stage.n_left), (sf.n_right, stage.n_right)]
+        else:
+            pairs += [(self.aframes.fixed, astage.fixed), (self.aframes.fixed_desc, astage.fixed_desc), (self.aframes.n_fixed, astage.n_fixed)]
+        for dst, src in pairs:
+            dst.copy_(src.index_select(0, idx))
+        self.X0_all = astage.X.index_select(0, idx).clone()
+        self.state0 = self.aframes.state.clone()
+        if self.stereo:  # the aligner consumes the matcher's device-resident outputs directly
+            self.aframes.fixed, self.aframes.fixed_desc, self.aframes.n_fixed = self.sframes.fixed_uvuv, self.sframes.fixed_desc, self.sframes.n_fixed
+        self.aframes.max_fixed = max_fixed  # a frame above the bound fails loudly
+        self.ctx = ops.Context(device_index)
+        self.sp = ops.stereo_params(cfg["stereo_matcher"], cfg["camera"]["rows"]) if self.stereo else None
+        self.tp = ops.triangulator_params(cfg) if self.stereo else None
+        self.pp = ops.pcf_params(cfg)
+        self.ap = ops.aligner_params(cfg, stop_at_fixed_point=0 if all_iterations else 1)
+        self.ops = ops
+
+    def step(self, ev=None, fresh_finders=True):
+        # the motion-model guess for every frame of the batch; fresh finder objects (heaviest case: maximum search radius)
+        # or the finders of the previous step (the reference's objects live across frames)
+        a = self.aframes
+        if fresh_finders:
+            a.state.copy_(self.state0, non_blocking=True)
+        a.X.copy_(self.X0_all, non_blocking=True)
+        a.n_corr.zero_()
+        if ev:
+            ev[0].record()
+        if self.stereo:
+            self.ops.stereo_match_batch(self.ctx, self.sp, self.sframes, self.tp)
+        if ev:
+            ev[1].record()
+        self.ops.align_batch(self.ctx, self.pp, self.ap, a)
+        if ev:
+            ev[2].record()
+
+    def kernel_times(self, n_steps, fresh_finders=True):
+        """untimed pass: HIP events on the launch stream around the matcher launch and around every launch of the aligner's two
+        kernels -> ms per step of each kernel and ms of every round's launches"""
+        import torch
+        events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_steps)]
+        self.ctx.enable_timing(True)
+        for k in range(n_steps):
+            self.step(events[k], fresh_finders)
+        torch.cuda.synchronize()
+        t = self.ctx.align_timing()
+        s_round, g_round, nb = self.ctx.align_round_timing()
+        self.ctx.enable_timing(False)
+        nb = max(nb, 1)
+        rounds = max(i + 1 for i in range(16) if s_round[i] > 0 or g_round[i] > 0 or i == 0)
+        return {"matcher_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in events])) if self.stereo else 0.0,
+                "align_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in events])),
+                "search_ms": t["search_ms"] / n_steps, "gn_ms": t["gn_ms"] / n_steps,
+                "search_launches": t["search_launches"] / n_steps, "gn_launches": t["gn_launches"] / n_steps,
+                "search_ms_by_round": [s_round[i] / nb for i in range(rounds)], "gn_ms_by_round": [g_round[i] / nb for i in range(rounds)]}
+
+    def snapshot(self):
+        a = self.aframes
+        n = min(len(self.uniq), self.B)
+        out = {"n_corr": a.n_corr.float().mean().item(), "results": a.result.cpu().numpy(), "X": a.X[:n].cpu().numpy(),
+               "corr": [a.corr_of(u) for u in range(n)], "n_fixed": a.n_fixed.float().mean().item()}
+        if self.stereo:
+            out["n_match"] = self.sframes.n_matches.float().mean().item()
+        return out
+
+    def check(self, snap):
+        """errors the kernels report per frame are loud; -> (success fraction, mean executed iterations)"""
+        from srrg2_proslam_amd import _lib
+        res = [_lib.AlignResult.from_buffer_copy(snap["results"][b].tobytes()) for b in range(self.B)]
+        worst = min(r.warnings for r in res)
+        if worst < 0:
+            raise SystemExit("align kernel reported error %d (raise --max-fixed?)" % worst)
+        head = res[: min(self.B, 256)]
+        return float(np.mean([r.status for r in head])), float(np.mean([r.iterations_executed for r in head]))
+
+    def parity(self, snap, poses):
+        worst, exact = 0.0, True
+        for u, (Xr, c) in enumerate(poses[: len(snap["corr"])]):
+            worst = max(worst, float(np.linalg.norm(snap["X"][u] - Xr) / np.linalg.norm(Xr)))
+            gc = snap["corr"][u]
+            exact = exact and len(gc) == len(c) and bool(np.array_equal(gc["fixed_idx"], c["fixed_idx"])) and bool(np.array_equal(gc["moving_idx"], c["moving_idx"]))
+        return {"pose_rel_frobenius_max": worst, "correspondences_bit_exact": exact, "frames_checked": min(len(poses), len(snap["corr"]))}
+
+    def close(self):
+        self.ctx.close()
+
+
+def small_config_leg(name, cfg, keypoints, moving, max_fixed, batch, device_index, seed, steps=3):
+    """one of the other BASELINE configurations: a few steps, per-kernel times, parity of four frames against the CPU checker"""
+    import torch
+    w = FrameWorkload(cfg, device_index, batch, keypoints, moving, max_fixed, 8, seed)
+    stream = torch.cuda.Stream(device=w.dev)
+    with torch.cuda.stream(stream):
+        w.ctx.use_torch_stream()
+        w.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            w.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        snap = w.snapshot()
+        ok, it_exec = w.check(snap)
+        kt = w.kernel_times(2)
+    _, _, poses = cpu_baseline(cfg, w.uniq[:4], 4)
+    cam = cfg["camera"]
+    out = {"workload": "%s: %dx%d, %d keypoints per image, %d local-map points, %s, %s.conf finder / aligner parameters" % (
+               name, cam["cols"], cam["rows"], keypoints, moving,
+               "stereo matcher + triangulator + projective finder + stereo GN aligner" if w.stereo else
+               "depth-projective path: (u, v, d) measurements from the RGB-D adaptor (host-side input prep, out of scope) -> projective finder + depth GN aligner "
+               "with inlier-only runs", cfg["name"]),
+           "value": batch * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "frames_per_step": batch, "steps": steps,
+           "ms_per_kernel": {"stereo_match5_kernel": kt["matcher_ms"], "align_kernel (search)": kt["search_ms"], "gn_kernel": kt["gn_ms"]},
+           "fixed_points_per_frame": snap["n_fixed"], "aligner_correspondences_per_frame": snap["n_corr"],
+           "aligner_success_fraction": ok, "gn_iterations_executed_mean": it_exec, "parity": w.parity(snap, poses)}
+    w.close()
+    del w
+    torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# closed loop (tools/bench_tracking.py); distributed = BASELINE.json config 5
+# ---------------------------------------------------------------------------------------------------------------------
 def closed_loop(args):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_tracking
-    out = bench_tracking.run(batch=min(args.batch, 4096), frames=args.frames, keypoints=args.keypoints, check=1 if not args.no_cpu_baseline else 0)
-    out.update({"steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "u64 popcount (Hamming) + f32 (projection, Jacobians, 6x6 normal equations) + f64 (landmark filters)", "data": "synthetic"})
-    print(json.dumps(out))
+    from srrg2_proslam_amd import sharding
+    from srrg2_proslam_amd.sharding import KITTI_SEQUENCE_FRAMES
+    rank, world, local_rank = sharding.rank_world()
+    extra = {"steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+             "dtype": "u64 popcount (Hamming) + f32 (projection, Jacobians, 6x6 normal equations) + f64 (landmark filters)", "data": "synthetic"}
+    if world <= 1:
+        out = bench_tracking.run(batch=min(args.batch, 4096), frames=args.frames, keypoints=args.keypoints, check=1 if not args.no_cpu_baseline else 0)
+        out.update(extra)
+        print(json.dumps(out))
+        return
+    # config 5: KITTI sequences 00-07, longest first to the least loaded rank (a sequence is a serial chain: it stays on one GPU);
+    # every sequence runs as `batch` independent replicas (own landmarks and noise) for frames-scale of its length
+    import torch
+    shared = os.environ.get("PRS_BENCH_SHARE_GPU", "0") == "1"
+    dev = 0 if shared else local_rank
+    torch.cuda.set_device(dev)
+    sharding.init_distributed("gloo" if shared else "nccl", dev)
+    red_dev = "cpu" if shared else torch.device("cuda", dev)
+    batch = min(args.batch, 1024)
+
+    def run_sequence(s, n_frames):
+        o = bench_tracking.run(batch=batch, frames=n_frames, keypoints=min(args.keypoints, 1000), check=0, device=dev, seed_offset=1000 * s)
+        n = o["config"]["tracked_frames_timed"] * batch
+        return n, n / o["value"]
+
+    torch.cuda.synchronize()
+    fps, slowest, parts = sharding.run_sequences_over_ranks(KITTI_SEQUENCE_FRAMES, args.frames_scale, run_sequence, red_dev)
+    mine = [p[0] for p in parts]
+    if rank == 0:
+        out = {"metric": "tracked frames/sec on KITTI-00 stereo (1241x376, ~2k kp); SE(3) vs ref", "value": fps, "unit": "frames/s", "n_gpus": world,
+               "ms_per_step": None,
+               "config": {"workload": "closed loop, KITTI sequences 00-07 (%s frames x %.3f) sharded over %d ranks longest-first, %d replicas per sequence; "
+                                      "trajectories follow KITTI 00 (the only ground truth shipped besides 01)" % (list(KITTI_SEQUENCE_FRAMES), args.frames_scale, world, batch),
+                          "sequences_of_rank_0": mine, "rank_0_parts": parts, "slowest_rank_seconds": slowest}}
+        out.update(extra)
+        print(json.dumps(out))
+    sharding.shutdown()
 
 
 def main():
@@ -227,124 +441,96 @@ def main():
     sharding.init_distributed("gloo" if shared else "nccl", local_rank)
     red_dev = "cpu" if shared else torch.device("cuda", local_rank)
 
-    from srrg2_proslam_amd import _lib, configs, ops, synthetic as syn
+    from srrg2_proslam_amd import configs, synthetic as syn
 
     cfg = configs.get("kitti")
     B, N, NM = args.batch, args.keypoints, args.moving
-    dev = torch.device("cuda", local_rank)
-
-    # ---- synthetic KITTI-00-shaped inputs: distinct seeds per rank (independent sequences) -------
-    uniq = make_unique_frames(cfg, args.unique, N, NM, syn.seed_for(1, 0) + 100000 * rank)
-    sframes = ops.StereoFrames(local_rank, B, N, epilogue=True)
-    aframes = ops.AlignFrames(local_rank, B, N, NM)
-    stage = ops.StereoFrames(local_rank, len(uniq), N, epilogue=False)
-    astage = ops.AlignFrames(local_rank, len(uniq), 1, NM)
-    for u, d in enumerate(uniq):
-        fr, mp = d["fr"], d["mp"]
-        stage.upload(u, fr["uv_left"], fr["desc_left"], fr["uv_right"], fr["desc_right"])
-        astage.upload(u, np.zeros((0, 4), np.float32), np.zeros((0, 32), np.uint8), mp["xyz"],
-                      ops.info_scale_from_nopt(mp["n_opt"]), mp["desc"], d["X0"])
-    idx = (torch.arange(B, device=dev) % len(uniq))
-    for dst, src in ((sframes.left_kp, stage.left_kp), (sframes.right_kp, stage.right_kp),
-                     (sframes.left_desc, stage.left_desc), (sframes.right_desc, stage.right_desc),
-                     (sframes.n_left, stage.n_left), (sframes.n_right, stage.n_right),
-                     (aframes.moving, astage.moving), (aframes.moving_desc, astage.moving_desc),
-                     (aframes.n_moving, astage.n_moving)):
-        dst.copy_(src.index_select(0, idx))
-    X0_all = astage.X.index_select(0, idx).clone()
-    state0 = aframes.state.clone()
-    del stage, astage
-    # the aligner consumes the matcher's device-resident outputs directly
-    aframes.fixed, aframes.fixed_desc, aframes.n_fixed = sframes.fixed_uvuv, sframes.fixed_desc, sframes.n_fixed
-    aframes.max_fixed = args.max_fixed  # stereo matches per frame are ~0.35 N; a frame above the bound fails loudly
-
-    ctx = ops.Context(local_rank)
-    stream = torch.cuda.Stream(device=dev)
-    sp = ops.stereo_params(cfg["stereo_matcher"], cfg["camera"]["rows"])
-    tp = ops.triangulator_params(cfg)
-    pp = ops.pcf_params(cfg)
-    ap = ops.aligner_params(cfg, stop_at_fixed_point=0 if args.all_iterations else 1)
-
-    def step(ev=None, fresh_finders=True):
-        # the motion-model guess for every frame of the batch; fresh finder objects (heaviest case: maximum search radius)
-        # or the finders of the previous step (the reference's objects live across frames)
-        if fresh_finders:
-            aframes.state.copy_(state0, non_blocking=True)
-        aframes.X.copy_(X0_all, non_blocking=True)
-        aframes.n_corr.zero_()
-        if ev:
-            ev[0].record()
-        ops.stereo_match_batch(ctx, sp, sframes, tp)
-        if ev:
-            ev[1].record()
-        ops.align_batch(ctx, pp, ap, aframes)
-        if ev:
-            ev[2].record()
+    # synthetic KITTI-00-shaped inputs: distinct seeds per rank (independent sequences)
+    w = FrameWorkload(cfg, local_rank, B, N, NM, args.max_fixed, args.unique, syn.seed_for(1, 0) + 100000 * rank, args.all_iterations)
+    stream = torch.cuda.Stream(device=w.dev)
 
     def barrier():
         torch.cuda.synchronize()
         sharding.barrier()
 
     with torch.cuda.stream(stream):
-        ctx.use_torch_stream()
+        w.ctx.use_torch_stream()
         for _ in range(args.warmup):
-            step()
-        events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-        ctx.enable_timing(True)  # HIP events around every launch of the aligner's two kernels, on this stream
+            w.step()
         barrier()
         t0 = time.perf_counter()
-        for k in range(args.steps):
-            step(events[k])
+        for _ in range(args.steps):
+            w.step()
         barrier()
         elapsed_local = time.perf_counter() - t0
-        timing = ctx.align_timing()
-        ctx.enable_timing(False)
         fps, elapsed = sharding.aggregate_throughput(B * args.steps, elapsed_local, red_dev)
-        # results of the timed configuration, before the steady-state leg overwrites them
-        n_match = sframes.n_matches.float().mean().item()
-        n_fixed = sframes.n_fixed.float().mean().item()
-        n_corr = aframes.n_corr.float().mean().item()
-        results = aframes.result.cpu().numpy()
-        Xg = aframes.X.cpu().numpy()
-        corr_g = [aframes.corr_of(u) for u in range(min(len(uniq), B))]
+        snap = w.snapshot()  # results of the timed configuration
+        status_ok, it_exec = w.check(snap)
+        kt = w.kernel_times(max(args.timing_steps, 1))  # per-kernel times: a separate pass, outside the timed region
         # ---- steady state: the same frames again with the finders carried over (radius / threshold schedule adapted) ----
         steady = None
-        if rank == 0 and world == 1:
+        if rank == 0 and world == 1 and not args.no_steady_state:
             for _ in range(6):  # radius 50 -> 10 px in steps of 10, threshold 25 -> 50
-                step(fresh_finders=False)
+                w.step(fresh_finders=False)
             torch.cuda.synchronize()
+            n_st = max(args.steps // 2, 1)
             t1 = time.perf_counter()
-            for _ in range(max(args.steps // 2, 1)):
-                step(fresh_finders=False)
+            for _ in range(n_st):
+                w.step(fresh_finders=False)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
-            st = aframes.state_of(0)
-            steady = {"value": B * max(args.steps // 2, 1) / dt, "unit": "frames/s", "ms_per_step": dt / max(args.steps // 2, 1) * 1e3,
+            st = w.aframes.state_of(0)
+            skt = w.kernel_times(2, fresh_finders=False)
+            steady = {"value": B * n_st / dt, "unit": "frames/s", "ms_per_step": dt / n_st * 1e3,
                       "search_radius_pixels": int(st.search_radius_pixels), "descriptor_distance": float(st.descriptor_distance),
-                      "aligner_correspondences_per_frame": aframes.n_corr.float().mean().item(),
+                      "aligner_correspondences_per_frame": w.aframes.n_corr.float().mean().item(),
+                      "ms_per_kernel": {"stereo_match5_kernel": skt["matcher_ms"], "align_kernel (search)": skt["search_ms"], "gn_kernel": skt["gn_ms"]},
                       "note": "finder objects live across steps like the reference's (correspondence_finder_projective_base_impl.cpp:277-287): "
                               "after six tracked frames the search radius has shrunk to its minimum and the descriptor threshold has grown"}
 
-    # ---- per-kernel time (HIP events on the launch stream) + algorithmic bytes / flops ------------------
-    ms_match = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
-    ms_align = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
-    ms_search = timing["search_ms"] / args.steps
-    ms_gn = timing["gn_ms"] / args.steps
-    res = [_lib.AlignResult.from_buffer_copy(results[b].tobytes()) for b in range(min(B, 256))]
-    warn_min = min(_lib.AlignResult.from_buffer_copy(results[b].tobytes()).warnings for b in range(B))
-    if warn_min < 0:
-        raise SystemExit("align kernel reported error %d (raise --max-fixed?)" % warn_min)
-    status_ok = float(np.mean([r.status for r in res]))
-    it_exec = float(np.mean([r.iterations_executed for r in res]))
+    # ---- algorithmic bytes / flops per kernel -----------------------------------------------------------------
+    n_match, n_fixed, n_corr = snap["n_match"], snap["n_fixed"], snap["n_corr"]
+    ms_match, ms_search, ms_gn = kt["matcher_ms"], kt["search_ms"], kt["gn_ms"]
     # matcher 40 (N_L + N_R) + 12 M, triangulator 16 M + 13 M: the launch runs both (fused epilogue)
     bytes_match = 40.0 * (2 * N) + 12.0 * n_match + 29.0 * n_fixed
     bytes_search = 44.0 * NM + 40.0 * n_fixed + 64 + 12.0 * n_corr  # projective finder, per recompute
-    searches = timing["search_launches"] / args.steps
+    searches = sum(1 for v in kt["search_ms_by_round"] if v > 0.05)  # launches that found frames waiting (the others return at once)
     gbps_match = B * bytes_match / (ms_match * 1e-3) / 1e9
     gbps_search = B * bytes_search * searches / (ms_search * 1e-3) / 1e9 if ms_search > 0 else 0.0
     flops_gn = FLOP_PER_CORRESPONDENCE * n_corr * it_exec * B  # per step
     tflops_gn = flops_gn / (ms_gn * 1e-3) / 1e12 if ms_gn > 0 else 0.0
     evidence = profile_evidence(B, N)
+    roof_search = {
+        "kernel": "align_kernel<512, split, circle> (projective search: projection, cell-grid circle search, Hamming, candidate filter; all its launches of one step)",
+        "bound": "hbm", "achieved": gbps_search, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps_search / HBM_PEAK_GBPS,
+        "traffic": evidence["search"] if evidence else None, "traffic_unit": evidence["unit"] if evidence else None,
+        "traffic_source": evidence["source"] if evidence else None,
+        "ms_per_step": ms_search, "ms_by_round": kt["search_ms_by_round"], "launches_with_work_per_step": searches,
+        "algorithmic_bytes_per_frame_and_launch": bytes_search, "frames_per_launch": B,
+        "traffic_over_algorithmic": (evidence["search"] / (B * bytes_search * searches)) if evidence and searches > 0 else None,
+        "note": "not bandwidth-bound: ~65 % VALU-busy plus exposed latency at three 512-thread workgroups per CU (profiles/); frac prices the algorithmic bytes",
+    }
+    roof_gn = {
+        "kernel": "gn_kernel<SLOTS, stereo> (reprojection-error Gauss-Newton rounds: factor linearisation, fixed-shape H / b reduction, "
+                  "6x6 solve; all its launches of one step)",
+        "bound": "valu", "achieved": tflops_gn, "peak": FP32_VECTOR_TFLOPS, "unit": "TFLOP/s", "frac": tflops_gn / FP32_VECTOR_TFLOPS,
+        "traffic": evidence["gn"] if evidence else None, "traffic_unit": evidence["unit"] if evidence else None,
+        "traffic_source": evidence["source"] if evidence else None,
+        "ms_per_step": ms_gn, "ms_by_round": kt["gn_ms_by_round"], "algorithmic_flop_per_step": flops_gn,
+        "flop_per_correspondence_iteration": FLOP_PER_CORRESPONDENCE,
+        "note": "fp32 vector arithmetic, no MFMA: 6x6 normal equations are not a dense contraction; the kernel is bound by "
+                "VALU issue (VALU-busy fraction in profiles/), frac prices only the algorithmic flops",
+    }
+    roof_match = {
+        "kernel": "stereo_match5_kernel<%d> (the kernel BASELINE.json north_star prices; matcher + fused adaptor / triangulator epilogue)" % (1 if N <= 1024 else 2),
+        "bound": "hbm", "achieved": gbps_match, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps_match / HBM_PEAK_GBPS,
+        "traffic": evidence["matcher"] if evidence else None, "traffic_unit": evidence["unit"] if evidence else None,
+        "traffic_source": evidence["source"] if evidence else None,
+        "ms_per_launch": ms_match, "algorithmic_bytes_per_frame": bytes_match, "frames_per_launch": B,
+        "traffic_over_algorithmic": (evidence["matcher"] / (B * bytes_match)) if evidence else None,
+    }
+    dominant = max((ms_search, "search", roof_search), (ms_gn, "gn", roof_gn), (ms_match, "matcher", roof_match))
+    total_k = ms_match + ms_search + ms_gn
 
     out = {
         "metric": "tracked frames/sec on KITTI-00 stereo (1241x376, ~2k kp); SE(3) vs ref",
@@ -372,80 +558,56 @@ def main():
             "gn_iterations_executed_mean": it_exec,
             "aligner_success_fraction": status_ok,
         },
-        "roofline": {
-            "kernel": "gn_kernel<128, SLOTS, stereo> (reprojection-error Gauss-Newton rounds: factor linearisation, ordered H / b sums, "
-                      "6x6 solve; the time-dominant kernel, all its launches of one step)",
-            "bound": "valu",
-            "achieved": tflops_gn,
-            "peak": FP32_VECTOR_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": tflops_gn / FP32_VECTOR_TFLOPS,
-            "traffic": evidence["gn"] if evidence else None,
-            "traffic_unit": evidence["unit"] if evidence else None,
-            "traffic_source": evidence["source"] if evidence else None,
-            "ms_per_step": ms_gn,
-            "launches_per_step": timing["gn_launches"] / args.steps,
-            "algorithmic_flop_per_step": flops_gn,
-            "flop_per_correspondence_iteration": FLOP_PER_CORRESPONDENCE,
-            "note": "fp32 vector arithmetic, no MFMA: 6x6 normal equations are not a dense contraction; the kernel is bound by "
-                    "instruction issue (VALU-busy fraction in profiles/), frac prices only the algorithmic flops",
-        },
-        "roofline_search": {
-            "kernel": "align_kernel<512, split, circle> (projective search: projection, cell-grid circle search, Hamming, candidate filter)",
-            "bound": "hbm", "achieved": gbps_search, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps_search / HBM_PEAK_GBPS,
-            "traffic": evidence["search"] if evidence else None, "traffic_source": evidence["source"] if evidence else None,
-            "ms_per_step": ms_search, "launches_per_step": searches, "algorithmic_bytes_per_frame_and_launch": bytes_search, "frames_per_launch": B,
-            "traffic_over_algorithmic": (evidence["search"] / (B * bytes_search * searches)) if evidence and searches > 0 else None,
-        },
-        "roofline_matcher": {
-            "kernel": "stereo_match5_kernel<%d> (the kernel BASELINE.json north_star prices; matcher + fused adaptor / triangulator epilogue)" % (1 if N <= 1024 else 2),
-            "bound": "hbm",
-            "achieved": gbps_match,
-            "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s",
-            "frac": gbps_match / HBM_PEAK_GBPS,
-            "traffic": evidence["matcher"] if evidence else None,
-            "traffic_unit": evidence["unit"] if evidence else None,
-            "traffic_source": evidence["source"] if evidence else None,
-            "ms_per_launch": ms_match,
-            "algorithmic_bytes_per_frame": bytes_match,
-            "frames_per_launch": B,
-            "traffic_over_algorithmic": (evidence["matcher"] / (B * bytes_match)) if evidence else None,
-        },
-        "kernel_time_share": {"stereo_match5_kernel": ms_match / (ms_match + ms_align), "align_kernel (search)": ms_search / (ms_match + ms_align),
-                              "gn_kernel": ms_gn / (ms_match + ms_align)},
+        "roofline": dict(dominant[2], dominant_of="the three kernels of the step (%s)" % dominant[1]),
+        "roofline_search": roof_search,
+        "roofline_gn": roof_gn,
+        "roofline_matcher": roof_match,
+        "kernel_time_share": {"stereo_match5_kernel": ms_match / total_k, "align_kernel (search)": ms_search / total_k, "gn_kernel": ms_gn / total_k},
+        "kernel_timing": "HIP events on the launch stream in a separate pass of %d steps after the timed loop (the timed loop carries no events)" % max(args.timing_steps, 1),
     }
     if steady:
         out["steady_state"] = steady
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_frames > 0:
-        cpu_fps, cpu_s, poses = cpu_baseline(cfg, uniq, args.cpu_frames)
-        # the same run doubles as an end-to-end check of the device pipeline on the bench inputs
-        worst = 0.0
-        exact_corr = True
-        for u in range(min(len(uniq), B)):
-            Xr, c = poses[u]
-            worst = max(worst, float(np.linalg.norm(Xg[u] - Xr) / np.linalg.norm(Xr)))
-            gc = corr_g[u]
-            exact_corr = exact_corr and len(gc) == len(c) and bool(np.array_equal(gc["fixed_idx"], c["fixed_idx"])) and bool(np.array_equal(gc["moving_idx"], c["moving_idx"]))
+        cpu_fps, cpu_s, poses = cpu_baseline(cfg, w.uniq, args.cpu_frames)
         out["cpu_baseline"] = {
             "value": cpu_fps,
             "unit": "frames/s",
             "cores": 1,
             "kind": "port",
             "sample": "%d frames of the same synthetic workload (stereo match + assemble + triangulate + 100-iteration align), "
-                      "single-threaded oracle (-O2, no fast-math), %.1f s; host has %d cores" % (args.cpu_frames, cpu_s, os.cpu_count() or 0),
+                      "single-threaded CPU restatement (-O2, no fast-math), %.1f s; host has %d cores" % (args.cpu_frames, cpu_s, os.cpu_count() or 0),
         }
-        out["parity_on_bench_inputs"] = {"pose_rel_frobenius_max": worst, "correspondences_bit_exact": exact_corr,
-                                         "frames_checked": min(len(uniq), B)}
+        # the same run doubles as an end-to-end check of the device pipeline on the bench inputs
+        out["parity_on_bench_inputs"] = w.parity(snap, poses)
         n_workers = args.cpu_all_cores if args.cpu_all_cores >= 0 else min(os.cpu_count() or 1, 256)
         if n_workers > 0:
             total, ok, wall = cpu_all_cores(args, n_workers, 48)
             out["cpu_baseline_all_cores"] = {
                 "value": total, "unit": "frames/s", "cores": ok, "kind": "port",
-                "sample": "%d worker processes (one independent sequence each, 48 frames per worker) of the same oracle, "
+                "sample": "%d worker processes (one independent sequence each, 48 frames per worker) of the same CPU restatement, "
                           "sum of the per-worker rates, %.1f s wall" % (ok, wall),
             }
+    w.close()
+    del w
+    torch.cuda.empty_cache()
+
+    # ---- the other BASELINE configurations and the stateful loop, outside the headline timing (rank 0, single GPU) ----
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        small = min(B, 4608)
+        others = {}
+        for name, cname, kp, mv, mf, cidx in (("euroc", "euroc", 1000, 1000, 512, 2), ("tum", "tum", 1000, 1000, 1024, 3), ("kitti_n1000", "kitti", 1000, 1000, 512, 1)):
+            try:
+                others[name] = small_config_leg(name, configs.get(cname), kp, mv, mf, small, local_rank, syn.seed_for(cidx, 0) + 31)
+            except SystemExit as exc:  # a loud per-frame error of a side leg must not take the headline line with it
+                others[name] = {"error": str(exc)}
+        out["other_configs"] = others
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_tracking
+        cl = bench_tracking.run(batch=4096, frames=30, keypoints=N, check=0 if args.no_cpu_baseline else 1, device=local_rank)
+        out["closed_loop"] = {k: cl[k] for k in ("value", "unit", "ms_per_step", "config", "ms_per_stage", "map_points_mean", "aligner_correspondences_mean",
+                                                 "finder_retries_per_frame", "track_losses_per_frame", "drift_percent_of_path", "parity_vs_oracle_chain",
+                                                 "cpu_baseline") if k in cl}
     if rank == 0:
         print(json.dumps(out))
     sharding.shutdown()

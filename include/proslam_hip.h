@@ -81,6 +81,9 @@ PRS_API int prs_context_synchronize(prs_context* ctx);
  * rounds) with HIP events on the context's stream and accumulates their durations; enabling resets the sums */
 PRS_API int prs_context_enable_timing(prs_context* ctx, int32_t on);
 PRS_API int prs_context_get_align_timing(prs_context* ctx, double* search_ms, double* gn_ms, int64_t* search_launches, int64_t* gn_launches);
+/* the same sums by round of the batch: search_ms16[r] / gn_ms16[r] = total time of the r-th search / Gauss-Newton launch over
+ * `batches` timed batches (round 15 collects every later round) */
+PRS_API int prs_context_get_align_round_timing(prs_context* ctx, double* search_ms16, double* gn_ms16, int64_t* batches);
 PRS_API const char* prs_last_error(const prs_context* ctx);
 PRS_API const char* prs_status_string(int status);
 PRS_API int prs_version(void);

@@ -2197,6 +2197,7 @@ struct SplitJob {
   size_t lds_search = 0, lds_gn = 0;
   int total = 0, limit = 0;  // rounds launched so far / upper bound
   int ev_used = 0;
+  int rounds_timed = 0;
   bool stamps = false;
 };
 static int split_rounds(prs_context* ctx, SplitJob* job, int rounds);
@@ -2395,6 +2396,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   job->total       = 0;
   job->limit       = 2 * (aligner->max_iterations + inlier_run_length(*aligner)) + 8;
   job->ev_used     = 0;
+  job->rounds_timed = 0;
   job->stamps      = stamps_split;
   return split_rounds(ctx, job, rounds > 0 ? rounds : 5);
 }
@@ -2448,7 +2450,11 @@ int align_batch_finish(prs_context* ctx) {
         ctx->t_gn_ms += b;
         ++ctx->n_search;
         ++ctx->n_gn;
+        const int round = job->rounds_timed < 15 ? job->rounds_timed : 15;
+        ctx->t_search_round[round] += a;
+        ctx->t_gn_round[round] += b;
       }
+      ++job->rounds_timed;
     }
     job->ev_used = 0;
   };
@@ -2476,6 +2482,9 @@ int align_batch_finish(prs_context* ctx) {
     }
   }
   job->active = false;
+  if (ctx->timing) {
+    ++ctx->n_batches_timed;
+  }
   return PRS_OK;
 }
 

@@ -250,6 +250,22 @@ int prs_context_enable_timing(prs_context* ctx, int32_t on) {
   ctx->timing      = on != 0;
   ctx->t_search_ms = ctx->t_gn_ms = 0.0;
   ctx->n_search = ctx->n_gn = 0;
+  for (int i = 0; i < 16; ++i) {
+    ctx->t_search_round[i] = ctx->t_gn_round[i] = 0.0;
+  }
+  ctx->n_batches_timed = 0;
+  return PRS_OK;
+}
+
+int prs_context_get_align_round_timing(prs_context* ctx, double* search_ms16, double* gn_ms16, int64_t* batches) {
+  if (!ctx || !search_ms16 || !gn_ms16 || !batches) {
+    return PRS_ERR_NULL;
+  }
+  for (int i = 0; i < 16; ++i) {
+    search_ms16[i] = ctx->t_search_round[i];
+    gn_ms16[i]     = ctx->t_gn_round[i];
+  }
+  *batches = ctx->n_batches_timed;
   return PRS_OK;
 }
 

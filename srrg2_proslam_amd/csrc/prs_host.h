@@ -30,6 +30,8 @@ struct prs_context {
   bool timing           = false;
   double t_search_ms = 0.0, t_gn_ms = 0.0;
   long long n_search = 0, n_gn = 0;
+  double t_search_round[16] = {}, t_gn_round[16] = {};  // the same, by round of the batch (round 15 collects the rest)
+  long long n_batches_timed = 0;
   hipEvent_t timing_ev[3 * 64] = {};
   // the batch of the split aligner pipeline that has been enqueued and not yet finished (owned by align.hip)
   void* align_job               = nullptr;

@@ -78,6 +78,12 @@ class Context:
         _check(self, _lib.load().prs_context_get_align_timing(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "prs_context_get_align_timing")
         return {"search_ms": a.value, "gn_ms": b.value, "search_launches": c.value, "gn_launches": d.value}
 
+    def align_round_timing(self):
+        """-> (search_ms[16], gn_ms[16], batches): the timed launches by round of the batch (mean per batch = value / batches)"""
+        a, b, n = (C.c_double * 16)(), (C.c_double * 16)(), C.c_int64(0)
+        _check(self, _lib.load().prs_context_get_align_round_timing(self._h, a, b, C.byref(n)), "prs_context_get_align_round_timing")
+        return list(a), list(b), n.value
+
 
 def stereo_params(cfg_matcher, image_rows, image_cols=0):
     """image_cols is reserved (ignored)"""

@@ -89,3 +89,26 @@ def aggregate_throughput(units_this_rank, elapsed_this_rank, device=None):
     total = sum_over_ranks(units_this_rank, device)
     slowest = max_over_ranks(elapsed_this_rank, device)
     return total / slowest, slowest
+
+
+KITTI_SEQUENCE_FRAMES = (4541, 1101, 4661, 801, 271, 2761, 1101, 1101)  # sequences 00-07 (BASELINE.json config 5)
+
+
+def run_sequences_over_ranks(lengths, scale, run_sequence, reduce_device=None, min_frames=4):
+    """BASELINE.json config 5 as written: whole sequences (serial chains) are assigned to ranks longest-first, every rank runs
+    its own one after the other, and the job's rate is all tracked frames / the slowest rank's time.
+    run_sequence(sequence_index, n_frames) -> (tracked_frames, seconds) runs ONE sequence (on this rank's device) for n_frames =
+    round(scale * length).  Returns (frames/s over all ranks, seconds of the slowest rank, [(sequence, frames, seconds)] of this rank)."""
+    rank, world, _ = rank_world()
+    mine = balanced_sequences_of_rank(list(lengths), rank, world)
+    tracked, elapsed, parts = 0, 0.0, []
+    barrier()
+    for s in mine:
+        n = max(int(round(lengths[s] * scale)), min_frames)
+        got, seconds = run_sequence(s, n)
+        tracked += got
+        elapsed += seconds
+        parts.append((s, n, seconds))
+    barrier()
+    fps, slowest = aggregate_throughput(tracked, max(elapsed, 1e-9), reduce_device)
+    return fps, slowest, parts

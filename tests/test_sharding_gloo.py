@@ -64,6 +64,46 @@ def test_two_ranks_shard_sequences_without_overlap(tmp_path):
             assert len(corr) == int(n) and int(corr["moving_idx"].sum()) == int(chk)
 
 
+def _loop_worker(rank, world, port, out_dir):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
+    sharding.init_distributed("gloo")
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import bench_tracking as bt
+    from srrg2_proslam_amd import configs
+    cfg = configs.get("kitti")
+
+    def run_sequence(s, n_frames):
+        # the closed loop of tools/bench_tracking.py for one short sequence, on the CPU checker instead of the device
+        gt = bt.kitti00_poses(n_frames)
+        gt = np.linalg.inv(gt[0]) @ gt
+        seq = bt.make_sequences(cfg, 1, gt, 300, sharding.seed_of_sequence(1, s))[0]
+        poses, sizes, flags, seconds = bt.oracle_chain(cfg, seq, bt.split_schedule(gt), 2048, n_frames + 1, 1.0)
+        assert len(poses) == n_frames and all(f >= 0 for f in flags)
+        return n_frames - 2, 0.1 * (n_frames - 2) * (1 + rank)  # deterministic stand-in for the measured time
+
+    fps, slowest, parts = sharding.run_sequences_over_ranks(sharding.KITTI_SEQUENCE_FRAMES, 0.001, run_sequence, min_frames=3)
+    np.save(os.path.join(out_dir, "loop%d.npy" % rank), np.array([fps, slowest] + [v for p in parts for v in p[:2]], dtype=np.float64))
+    sharding.shutdown()
+
+
+def test_closed_loop_entry_on_two_ranks(tmp_path):
+    """bench.py --mode closed-loop under torch.distributed.run (BASELINE.json config 5): the same driver, sharding.run_sequences_over_ranks,
+    on two gloo ranks with the CPU checker's loop standing in for the device"""
+    world, port = 2, _free_port()
+    mp.spawn(_loop_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(os.path.join(str(tmp_path), "loop%d.npy" % k)) for k in range(world)]
+    seqs = [[int(x) for x in rr[2::2]] for rr in r]
+    assert sorted(seqs[0] + seqs[1]) == list(range(8)) and not set(seqs[0]) & set(seqs[1])
+    assert seqs[0] == sharding.balanced_sequences_of_rank(list(sharding.KITTI_SEQUENCE_FRAMES), 0, 2)
+    frames = [[int(x) for x in rr[3::2]] for rr in r]
+    tracked = [sum(n - 2 for n in f) for f in frames]
+    slowest = max(0.1 * tracked[0] * 1, 0.1 * tracked[1] * 2)
+    for rr in r:  # every rank holds the job's figures: all frames / the slowest rank's time
+        assert abs(rr[1] - slowest) < 1e-9 and abs(rr[0] - sum(tracked) / slowest) < 1e-6
+
+
 def test_sharding_is_a_partition():
     for world in (1, 2, 3, 4, 8):
         parts = [sharding.sequences_of_rank(11, r, world) for r in range(world)]

@@ -162,7 +162,7 @@ def unroll(local_poses, splits):
     return out
 
 
-def run(batch=4096, frames=60, unique=4, keypoints=2000, cap=6144, check=1, prior_info=1.0, trajectory="", max_fixed=1024):
+def run(batch=4096, frames=60, unique=4, keypoints=2000, cap=6144, check=1, prior_info=1.0, trajectory="", max_fixed=1024, device=0, seed_offset=0):
     import torch
     from bench_merge import merger_params
     from srrg2_proslam_amd import configs, ops, synthetic as syn
@@ -174,10 +174,10 @@ def run(batch=4096, frames=60, unique=4, keypoints=2000, cap=6144, check=1, prio
     gt = np.linalg.inv(gt[0]) @ gt  # the first camera is the first local map's origin
     splits = split_schedule(gt)
     longest = max(np.diff([0] + sorted(splits) + [K])) + 2
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", device)
     idx = torch.arange(B, device=dev) % unique
-    seqs = make_sequences(cfg, unique, gt, N, syn.seed_for(1, 0) + 500000)
-    stage = ops.StereoFrames(0, len(seqs), N, epilogue=False)
+    seqs = make_sequences(cfg, unique, gt, N, syn.seed_for(1, 0) + 500000 + seed_offset)
+    stage = ops.StereoFrames(device, len(seqs), N, epilogue=False)
     inputs = []
     for k in range(K):  # per-frame inputs of every sequence, resident in HBM
         for u, fr_list in enumerate(seqs):
@@ -185,13 +185,13 @@ def run(batch=4096, frames=60, unique=4, keypoints=2000, cap=6144, check=1, prio
             stage.upload(u, fr["uv_left"], fr["desc_left"], fr["uv_right"], fr["desc_right"])
         inputs.append(tuple(t.index_select(0, idx).contiguous() for t in (stage.left_kp, stage.left_desc, stage.right_kp, stage.right_desc, stage.n_left, stage.n_right)))
     del stage
-    sf = ops.StereoFrames(0, B, N, epilogue=True)
+    sf = ops.StereoFrames(device, B, N, epilogue=True)
     max_meas = int(longest) + 1
-    maps = ops.MapBatch(0, B, cap, max_meas, max_meas + 1, N, N)
+    maps = ops.MapBatch(device, B, cap, max_meas, max_meas + 1, N, N)
     maps.measurement, maps.measurement_desc, maps.n_measured = sf.fixed_uvuv, sf.fixed_desc, sf.n_fixed
-    clip = ops.ClipScenes(0, B, cap)
+    clip = ops.ClipScenes(device, B, cap)
     clip.scene_xyzw, clip.scene_desc, clip.n_scene, clip.scene_n_opt = maps.coords, maps.desc, maps.n_points, maps.n_opt
-    af = ops.AlignFrames(0, B, N, cap)
+    af = ops.AlignFrames(device, B, N, cap)
     af.fixed, af.fixed_desc, af.n_fixed = sf.fixed_uvuv, sf.fixed_desc, sf.n_fixed
     af.moving, af.moving_desc, af.n_moving = clip.clipped_xyzw, clip.clipped_desc, clip.n_clipped
     af.max_fixed = max_fixed  # stereo matches per frame the aligner is sized for (<= 1024: search / GN pipeline); more is a loud per-frame error
@@ -199,7 +199,7 @@ def run(batch=4096, frames=60, unique=4, keypoints=2000, cap=6144, check=1, prio
     zero_corr = torch.zeros((B,), dtype=torch.int32, device=dev)
     eye = torch.eye(4, dtype=torch.float32, device=dev).repeat(B, 1, 1).contiguous()
     pose, prev, pred, tmp_a, tmp_b = eye.clone(), eye.clone(), eye.clone(), eye.clone(), eye.clone()
-    ctx = ops.Context(0)
+    ctx = ops.Context(device)
     sp, tp = ops.stereo_params(cfg["stereo_matcher"], cam["rows"]), ops.triangulator_params(cfg)
     pp = ops.pcf_params(cfg)
     apar = ops.aligner_params(cfg)
