@@ -9,7 +9,7 @@ i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" \
            "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 2 --warmup 1 --batch 6144 --no-cpu-baseline > $OUT/p$i.log 2>&1
+  timeout 200 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 2 --warmup 1 --batch 6144 --no-cpu-baseline --no-steady-state --no-other-configs --timing-steps 1 > $OUT/p$i.log 2>&1
   echo "pass $i ($set) rc=$?"
 done
 python3 - <<PY
