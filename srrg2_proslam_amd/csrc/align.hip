@@ -5,8 +5,8 @@
 // for `batch` independent frames (sequences) per launch.  Two forms, bit-identical:
 //   * the split pipeline (default for PRS_MODE_ALIGN): align_kernel<512, true, pattern> performs ONE projective
 //     search for every frame that waits for it (three workgroups per CU), gn_kernel runs Gauss-Newton iterations
-//     until the finder needs the next search (two waves per frame, eight frames per CU); the host alternates
-//     them, five rounds ahead of a 4-byte readback;
+//     until the finder needs the next search (two waves per frame, eight frames per CU); the host enqueues five
+//     rounds (align_batch_launch) and confirms completion with one 4-byte readback (align_batch_finish);
 //   * the fused kernel align_kernel<256, false, -1>: one 256-thread workgroup owns a frame for the whole loop
 //     (finder-only mode, frames whose fixed cloud exceeds the split pipeline's bound, PRS_FUSED_ALIGN=1, phase stamps).
 //
@@ -23,9 +23,10 @@
 //
 // Determinism / parity: candidates are reduced with order-independent LDS atomicMin on
 // (response, insertion order) keys, correspondences are emitted in ascending fixed index, and the
-// 21+6+2 normal-equation sums are accumulated in correspondence order by one lane each (the
-// upstream factor loop is sequential), so correspondences AND poses are bit-identical to the
-// sequential float evaluation.
+// 21+6+2 normal-equation sums are fixed-shape reductions (128 interleaved leaves, seven pairwise levels:
+// include/proslam_hip.h at prs_align_result) that every entry point evaluates with the same code
+// (factor_accumulate + wave_sum_slots), so correspondences AND poses are bit-identical to the CPU
+// checker's evaluation of the same definition.
 #include "prs_device.h"
 #include "prs_host.h"
 #include "prs_se3.h"
@@ -2335,7 +2336,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
       return ctx_fail_hip(ctx, e, "prs_align_batch_run launch");
     }
     if (g.stamps) {
-      ctx_report_stamps(ctx, batch->batch, 10, "align (fused, 256 threads): finder | linearize | sequential sums | GN solve || of finder: lattice build | projection+search | staging (keys, fixed rows -> LDS) | filter | commit");
+      ctx_report_stamps(ctx, batch->batch, 10, "align (fused, 256 threads): finder | linearize + in-wave reduction | cross-wave sum | GN solve || of finder: lattice build | projection+search | staging (keys, fixed rows -> LDS) | filter | commit");
     }
     return PRS_OK;
   }
