@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--keypoints", type=int, default=2000, help="keypoints per image (KITTI config: ~2000)")
     ap.add_argument("--moving", type=int, default=2000, help="local-map points per frame")
     ap.add_argument("--max-fixed", type=int, default=896, help="LDS sizing bound on stereo matches per frame")
-    ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames generated on the host and tiled")
+    ap.add_argument("--unique", type=int, default=256, help="distinct synthetic frames generated on the host and tiled over the batch")
     ap.add_argument("--cpu-frames", type=int, default=1024, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-steady-state", action="store_true", help="skip the steady-state leg (profiles of the headline workload alone)")
