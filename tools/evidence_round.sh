@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/evidence_$TAG
 mkdir -p $OUT
 cd $R
 {
-  echo "Randomised parity sweeps, GPU path vs CPU checker (MI355X, $TAG, commit $(cat .git_head 2>/dev/null))"
+  echo "Randomised parity sweeps, GPU path vs CPU checker (MI355X, $TAG)"
   echo "tools/fuzz_align.py 600 3131; tools/fuzz_matcher.py 500 31; tools/fuzz_merge.py 200 313; tools/fuzz_rows.py 200 3"
   timeout 1500 python tools/fuzz_align.py 600 3131 2>&1 | tail -3
   timeout 900 python tools/fuzz_matcher.py 500 31 2>&1 | tail -2
