@@ -1094,10 +1094,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
           second[i]  = kNoneU32;
         }
         for (int i = tid; i < 2 * nF; i += T) {
-          // coalesced 16 B/lane; the rows are re-read ~10x per query from LDS.  A 32-byte row starts on one of only eight bank
-          // groups, so the two halves of every second group of eight rows are stored swapped: the first-half reads of a wave
-          // (random rows) then spread over all sixteen 16-byte bank quads instead of eight
-          fdesc[i ^ ((i >> 4) & 1)] = gfd[i];
+          fdesc[i] = gfd[i];  // coalesced 16 B/lane; the rows are re-read ~10x per query from LDS
         }
         if (!lattice) {
           for (int i = tid; i < nF; i += T) {
@@ -1194,8 +1191,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                   const float2 c = fuv[fi];
                   const float du = c.x - u, dv = c.y - v;
                   if (du * du + dv * dv < r2f) {
-                    const int sw       = (fi >> 3) & 1;
-                    const uint32_t d   = (uint32_t) hamming_regs(fdesc[2 * fi + sw], fdesc[2 * fi + 1 - sw], q0, q1);
+                    const uint32_t d   = (uint32_t) hamming_regs(fdesc[2 * fi], fdesc[2 * fi + 1], q0, q1);
                     const uint32_t key = (float) d < max_dd ? ((d << 16) | (uint32_t) fi) : kNoneU32;
                     bestk              = key < bestk ? key : bestk;
                   }
@@ -1244,8 +1240,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                 };
                 auto score = [&](const uint2 e) {
                   const int fi     = (int) (e.y & 0xffffu);
-                  const int sw     = (fi >> 3) & 1;  // (see the staging loop: halves of every second group of eight rows are swapped)
-                  const uint32_t d = (uint32_t) hamming_regs(fdesc[2 * fi + sw], fdesc[2 * fi + 1 - sw], q0, q1);
+                  const uint32_t d = (uint32_t) hamming_regs(fdesc[2 * fi], fdesc[2 * fi + 1], q0, q1);
                   // best / second best (circle_impl.cpp:64-72) as min / second-min of unique keys
                   const uint32_t key = (d << 16) | (e.y >> 16);
                   const uint32_t hi  = key > bestk ? key : bestk;
