@@ -1875,7 +1875,8 @@ __global__ __launch_bounds__(128, 4) void gn_kernel(const AlignArgs g) {
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
           const int c0 = k * THREADS;
-          if (k == 0 || c0 < nc) {
+          // a wave whose 64 lanes are all past the end skips the pass (its terms would all be +-0)
+          if (k == 0 || c0 + 64 * wave < nc) {
             const int c = c0 + tid;
             float4 z, p;
             if (k < LS) {

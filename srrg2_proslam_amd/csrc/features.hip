@@ -618,29 +618,136 @@ __device__ int std_partition_wave(uint32_t* v, const int first, const int last, 
   }
 }
 
-// __final_insertion_sort restricted to a range of <= 16 items that no item enters or leaves (everything left of a partition
-// cut compares "not after" everything right of it): a stable sort by decreasing response, one lane per item
-__device__ __forceinline__ void std_leaf_sort_wave(uint32_t* v, const int first, const int last, const int lane) {
-  const int s      = last - first;
-  const uint32_t x = lane < s ? v[first + lane] : 0u;
+// The whole subtree of __introsort_loop below a range of <= 64 items, in registers: lane i holds item i, every lane carries the
+// bounds and the depth budget of the range ("segment") its item is in, and all segments of a level are partitioned at once.
+// One __unguarded_partition_pivot in closed form: with l_0 < l_1 < .. the left stops (items that do not compare before the
+// pivot) and r_0 > r_1 > .. the right stops (items the pivot does not compare before, the pivot's own position included), the
+// serial loop swaps the pairs k < K, K = number of k with l_k < r_k, and returns min(l_K, r_(K-1)) (the scans stop at swapped
+// items; see std_partition_wave).  Lane first + k collects pair k (ds_permute), a stop fetches its partner's position from
+// there (ds_bpermute) and then its partner's item.  Segments that run out of depth go through LDS for the heapsort on one
+// lane; segments of <= 16 items end with their share of the final insertion sort (stable, decreasing response).
+__device__ void std_sort_small_wave(uint32_t* v, const int first, const int n, const int depth, const int lane) {
+  uint32_t x = lane < n ? v[first + lane] : 0u;
+  int sf = 0, sl = n, sd = depth;
+  bool heaped = false;
+  const unsigned long long bit = 1ull << lane, below = bit - 1ull, above = ~(below | bit);
+  for (;;) {
+    const bool open = lane < n && !heaped && sl - sf > 16;
+    if (!__ballot(open)) {
+      break;
+    }
+    const bool dry = open && sd == 0;
+    if (__ballot(dry)) {
+      unsigned long long heads = __ballot(dry && lane == sf);
+      if (dry) {
+        v[first + lane] = x;
+      }
+      wave_sync_lds();
+      while (heads) {
+        const int h = (int) __ffsll((long long) heads) - 1;
+        heads &= heads - 1ull;
+        const int l = __builtin_amdgcn_readlane(sl, h);
+        if (lane == 0) {
+          std_heapsort(v + first + h, l - h);
+        }
+      }
+      wave_sync_lds();
+      if (dry) {
+        x      = v[first + lane];
+        heaped = true;  // heap-sorted: the final insertion pass finds nothing to move
+      }
+    }
+    const bool act = open && !dry;
+    if (!__ballot(act)) {
+      continue;
+    }
+    // __move_median_to_first(first, first + 1, mid, last - 1)
+    const int a = act ? sf + 1 : lane, b = act ? sf + ((sl - sf) >> 1) : lane, c = act ? sl - 1 : lane;
+    const uint32_t xa = (uint32_t) __shfl((int) x, a, 64), xb = (uint32_t) __shfl((int) x, b, 64), xc = (uint32_t) __shfl((int) x, c, 64);
+    const uint32_t x0 = (uint32_t) __shfl((int) x, act ? sf : lane, 64);
+    int pick;
+    uint32_t xp;
+    if (scomp(xa, xb)) {
+      const bool bc = scomp(xb, xc), ac = scomp(xa, xc);
+      pick = bc ? b : (ac ? c : a);
+      xp   = bc ? xb : (ac ? xc : xa);
+    } else {
+      const bool ac = scomp(xa, xc), bc = scomp(xb, xc);
+      pick = ac ? a : (bc ? c : b);
+      xp   = ac ? xa : (bc ? xc : xb);
+    }
+    if (act) {
+      x = lane == sf ? xp : (lane == pick ? x0 : x);
+    }
+    const uint32_t pr = xp & 0xffu, r = x & 0xffu;
+    const bool fl = act && lane > sf && !(r > pr);
+    const bool fr = act && !(pr > r);
+    const unsigned long long upto = sl >= 64 ? ~0ull : ((1ull << sl) - 1ull);
+    const unsigned long long seg  = act ? (upto & ~((1ull << sf) - 1ull)) : 0ull;
+    const unsigned long long SL = __ballot(fl) & seg, SR = __ballot(fr) & seg;
+    const int kl = __popcll(SL & below), kr = __popcll(SR & above);
+    const int nl = __popcll(SL), nr = __popcll(SR);
+    const int m  = nl < nr ? nl : nr;
+    // lane sf + k receives l_k and r_k; everybody else sends to a lane nobody reads (the segment's last lane can only be
+    // the destination of a stop when every item of the segment is one; a lane outside the open segments sends to itself)
+    const int idle = act ? sl - 1 : lane;
+    const int TL   = __builtin_amdgcn_ds_permute((fl ? sf + kl : idle) << 2, lane);
+    const int TR   = __builtin_amdgcn_ds_permute((fr ? sf + kr : idle) << 2, lane);
+    const bool uncrossed = act && lane - sf < m && TL < TR;
+    const int K          = __popcll(__ballot(uncrossed) & seg);  // pairs the serial loop swaps
+    const int partner_l  = __shfl(TR, act ? sf + kl : lane, 64);
+    const int partner_r  = __shfl(TL, act ? sf + kr : lane, 64);
+    const int lK         = __shfl(TL, act && K < nl ? sf + K : lane, 64);
+    const int rK1        = __shfl(TR, act && K > 0 ? sf + K - 1 : lane, 64);
+    int src = lane;
+    if (fl && kl < K) {
+      src = partner_l;
+    } else if (fr && kr < K) {
+      src = partner_r;
+    }
+    x = (uint32_t) __shfl((int) x, src, 64);
+    if (act) {
+      int cut = 1 << 20;
+      cut     = K < nl && lK < cut ? lK : cut;
+      cut     = K > 0 && rK1 < cut ? rK1 : cut;
+      if (lane < cut) {
+        sl = cut;
+      } else {
+        sf = cut;
+      }
+      --sd;
+    }
+  }
+  // __final_insertion_sort inside every segment (nothing enters or leaves one): stable sort by decreasing response
   const uint32_t r = x & 0xffu;
   int rank         = 0;
-  for (int j = 0; j < s; ++j) {
-    const uint32_t rj = (uint32_t) __shfl((int) r, j) ;
-    rank += (rj > r || (rj == r && j < lane)) ? 1 : 0;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int j       = sf + t;
+    const uint32_t rj = (uint32_t) __shfl((int) r, j < 64 ? j : 63, 64);
+    rank += (j < sl && (rj > r || (rj == r && j < lane))) ? 1 : 0;
   }
   wave_sync_lds();
-  if (lane < s) {
-    v[first + rank] = x;
+  if (lane < n) {
+    v[first + (heaped ? lane : sf + rank)] = x;
   }
   wave_sync_lds();
 }
 
-// One WAVE replays GNU libstdc++'s std::sort of one region: __introsort_loop with the recursion on an explicit stack (the right
-// part is pushed, the loop continues on the left; the parts are disjoint, so the order in which they are finished does not
-// change the result), every partition by the whole wave, heapsort (depth limit) on one lane, and the final insertion sort per
-// leaf.  q: 256 ints of LDS owned by this wave (tl | tr | stack).
-__device__ void std_sort_desc_wave(uint32_t* v, const int n, const int lane, int* q) {
+// GNU libstdc++'s std::sort of every region, replayed by ALL waves of the workgroup: the ranges __introsort_loop recurses into
+// are disjoint, so the order in which they are finished does not change the result.  Ranges of more than 64 items wait in one
+// LIFO of the workgroup (a private stack of the wave takes over when it is full); a wave takes a range, partitions it (whole
+// wave, std_partition_wave), hands the right part over and continues on the left one; heapsort (depth limit) runs on one lane;
+// a range of <= 64 items is finished in registers (std_sort_small_wave).  `remaining` counts the items that are not in a
+// finished range yet: the waves leave when it reaches zero.
+constexpr int kSortQueueCap  = 1024;
+constexpr int kSortSpinLimit = 1 << 20;  // polls of an empty queue before a wave gives up (a legitimate wait is a few hundred)
+struct SortQueue {
+  int lock, top, remaining, failed;
+  uint2 e[kSortQueueCap];  // first | depth << 16, last
+};
+
+__device__ __forceinline__ void sort_queue_seed(SortQueue& sq, const int first, const int n) {  // one thread, before the barrier
   if (n <= 1) {
     return;
   }
@@ -648,54 +755,144 @@ __device__ void std_sort_desc_wave(uint32_t* v, const int n, const int lane, int
   for (int m = n; m > 1; m >>= 1) {
     ++lg;
   }
+  sq.e[sq.top++] = make_uint2((uint32_t) first | ((uint32_t) (2 * lg) << 16), (uint32_t) (first + n));
+  sq.remaining += n;
+}
+
+// the queue's spin lock, taken by one lane of a wave; every access to top / e[] happens between lock and unlock
+__device__ __forceinline__ bool sort_queue_lock(SortQueue& sq) {
+  for (int tries = 0; __hip_atomic_exchange(&sq.lock, 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; ++tries) {
+    if (tries > kSortSpinLimit) {
+      __hip_atomic_store(&sq.failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return true;
+}
+__device__ __forceinline__ void sort_queue_unlock(SortQueue& sq) {
+  __hip_atomic_store(&sq.lock, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ void std_sort_worker(uint32_t* v, SortQueue& sq, const int lane, int* q) {
   int* tl    = q;
   int* tr    = q + 64;
-  int* stack = q + 128;  // (first, last, depth) triples; at most 2 lg + 1 <= 31 of them
+  int* stack = q + 128;  // private (first, last, depth) triples: the right siblings along this wave's path, at most 2 lg + 1 <= 31
   int sp     = 0;
-  if (lane == 0) {
-    stack[0] = 0;
-    stack[1] = n;
-    stack[2] = 2 * lg;
-  }
-  sp = 1;
-  wave_sync_lds();
-  while (sp > 0) {
-    --sp;
-    const int first = stack[3 * sp];
-    int last = stack[3 * sp + 1], depth = stack[3 * sp + 2];
-    wave_sync_lds();
-    bool leaf = true;
-    while (last - first > 16) {
+  for (;;) {
+    int first, last, depth;
+    if (sp > 0) {
+      --sp;
+      first = stack[3 * sp];
+      last  = stack[3 * sp + 1];
+      depth = stack[3 * sp + 2];
+      wave_sync_lds();
+    } else {
+      int got = 0;
+      uint2 e = make_uint2(0u, 0u);
+      if (lane == 0) {
+        for (int polls = 0;; ++polls) {
+          if (__hip_atomic_load(&sq.remaining, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= 0 ||
+              __hip_atomic_load(&sq.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
+            got = -1;
+            break;
+          }
+          if (polls > kSortSpinLimit) {  // cannot happen; a loud per-image error instead of a hung device if it ever does
+            __hip_atomic_store(&sq.failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            got = -1;
+            break;
+          }
+          if (__hip_atomic_load(&sq.top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > 0) {
+            if (sort_queue_lock(sq)) {
+              const int t = __hip_atomic_load(&sq.top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (t > 0) {
+                e = sq.e[t - 1];
+                __hip_atomic_store(&sq.top, t - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                got = 1;
+              }
+              sort_queue_unlock(sq);
+            }
+            if (got) {
+              break;
+            }
+          }
+          __builtin_amdgcn_s_sleep(4);
+        }
+      }
+      got = __builtin_amdgcn_readfirstlane(got);
+      if (got < 0) {
+        return;
+      }
+      const uint32_t ex = (uint32_t) __builtin_amdgcn_readfirstlane((int) e.x);
+      first             = (int) (ex & 0xffffu);
+      depth             = (int) (ex >> 16);
+      last              = __builtin_amdgcn_readfirstlane((int) e.y);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // the items of the range were written by another wave
+    }
+    int finished = 0;  // items of ranges this chain has finished
+    for (;;) {
+      const int size = last - first;
+      if (size <= 64) {
+        if (size > 1) {
+          std_sort_small_wave(v, first, size, depth, lane);
+        }
+        finished += size;
+        break;
+      }
       if (depth == 0) {
         if (lane == 0) {
-          std_heapsort(v + first, last - first);
+          std_heapsort(v + first, size);
         }
         wave_sync_lds();
-        leaf = false;  // heap-sorted: the final insertion pass finds nothing to move
+        finished += size;  // heap-sorted: the final insertion pass finds nothing to move
         break;
       }
       --depth;
-      const int cut = std_partition_wave(v, first, last, lane, tl, tr);
-      if (lane == 0) {
-        stack[3 * sp]     = cut;
-        stack[3 * sp + 1] = last;
-        stack[3 * sp + 2] = depth;
+      const int cut   = std_partition_wave(v, first, last, lane, tl, tr);
+      const int rsize = last - cut;
+      if (rsize <= 64) {
+        if (rsize > 1) {
+          std_sort_small_wave(v, cut, rsize, depth, lane);
+        }
+        finished += rsize;
+      } else {
+        int pushed = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the items of the right part, for the wave that takes it
+        if (lane == 0 && sort_queue_lock(sq)) {
+          const int t = __hip_atomic_load(&sq.top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (t < kSortQueueCap) {
+            sq.e[t] = make_uint2((uint32_t) cut | ((uint32_t) depth << 16), (uint32_t) last);
+            __hip_atomic_store(&sq.top, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            pushed = 1;
+          }
+          sort_queue_unlock(sq);
+        }
+        pushed = __builtin_amdgcn_readfirstlane(pushed);
+        if (!pushed) {
+          if (lane == 0) {
+            stack[3 * sp]     = cut;
+            stack[3 * sp + 1] = last;
+            stack[3 * sp + 2] = depth;
+          }
+          ++sp;
+          wave_sync_lds();
+        }
       }
-      ++sp;
-      wave_sync_lds();
       last = cut;
     }
-    if (leaf && last - first > 1) {
-      std_leaf_sort_wave(v, first, last, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) {
+      __hip_atomic_fetch_add(&sq.remaining, -finished, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
 }
 
-__global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const FeatureArgs a) {
+__global__ __launch_bounds__(kSelThreads, 8) void select_describe_kernel(const FeatureArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t keys[];  // [max_raw]
   __shared__ uint32_t count[kMaxRegions + 1];
   __shared__ uint32_t start[kMaxRegions + 1];
   __shared__ int wave_tot[kSelThreads / 64];
+  __shared__ SortQueue sortq;
   __shared__ uint16_t patch[(kSelThreads / 64) * kMaxCells];  // per wave: the smoothed pixels the pair table reads around the keypoint being described
   const int rows = a.b.rows, cols = a.b.cols;
   const int img  = blockIdx.x;
@@ -771,14 +968,25 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const Feat
       __syncthreads();
     }
   }
-  if (std_order) {  // one wave per region replays the reference's std::sort on the region's keypoints (wave-uniform branch)
-    int* q = reinterpret_cast<int*>(patch + wave * kMaxCells);  // (the descriptor phase's staging area is not in use yet)
-    for (int g = wave; g < a.regions; g += kSelThreads / 64) {
-      if (count[g] >= (uint32_t) a.target_per) {
-        std_sort_desc_wave(keys + start[g], (int) count[g], lane, q);
+  if (std_order) {  // the waves of the workgroup replay the reference's std::sort of every region that is sorted at all
+    if (tid == 0) {
+      sortq.lock = sortq.top = sortq.remaining = sortq.failed = 0;
+      for (int g = 0; g < a.regions; ++g) {
+        if (count[g] >= (uint32_t) a.target_per) {
+          sort_queue_seed(sortq, (int) start[g], (int) count[g]);
+        }
       }
     }
     __syncthreads();
+    std_sort_worker(keys, sortq, lane, reinterpret_cast<int*>(patch + wave * kMaxCells));  // (the descriptor phase's staging area is not in use yet)
+    __syncthreads();
+    if (sortq.failed) {  // a wave gave up waiting (std_sort_worker): loud per-image error
+      if (tid == 0) {
+        a.b.n_features[img] = 0;
+        a.b.status[img]     = PRS_ERR_HIP;
+      }
+      return;
+    }
   }
   // ---- selection + border filter + ordered output slots, 1024 sorted positions at a time ------------------------
   prs_kp2* __restrict__ out_kp   = a.b.keypoints + (size_t) img * a.b.stride;
