@@ -737,6 +737,14 @@ typedef struct {
 
 PRS_API int prs_extract_features_batch(prs_context* ctx, const prs_extractor_params* params, const prs_extract_batch* batch);
 
+/* The order in which the reference's selection leaves ONE region's keypoints (PRS_SELECT_LIBSTDCXX): the permutation GNU
+ * libstdc++'s std::sort produces for the comparator `a.response > b.response`
+ * (intensity_feature_extractor_binned.cpp:182-186) on keypoints whose responses are response[0..n), in detection order.
+ * order[k] = index of the keypoint that ends up at position k.  Host pointers; runs the same device code as the
+ * extractor's selection (work queue over the workgroup's waves, ranges of <= 64 items in registers, heapsort at the depth
+ * limit), synchronises.  Responses are 1..255 (a detected corner never scores 0: PRS_ERR_RANGE); n <= 32768. */
+PRS_API int prs_selection_order(prs_context* ctx, const uint8_t* response, int32_t n, int32_t* order);
+
 /* host pointers, one image: what an adapter's IntensityFeatureExtractorBase_::compute(const cv::Mat&) binds
  * (intensity_feature_extractor_binned.cpp:47-196): uploads the image, runs the three kernels, downloads the features,
  * synchronises.  image: rows x cols 8-bit pixels, `pitch` bytes between rows; keypoints [capacity][2] (u, v) floats,

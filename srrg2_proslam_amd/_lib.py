@@ -300,6 +300,7 @@ SYMBOLS = {
     "prs_bruteforce_match_batch": (C.c_int, [_vp, C.POINTER(BruteforceParams), C.POINTER(BruteforceBatch)]),
     "prs_bruteforce_match": (C.c_int, [_vp, C.POINTER(BruteforceParams), _vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
     "prs_extract_features_batch": (C.c_int, [_vp, C.POINTER(ExtractorParams), C.POINTER(ExtractBatch)]),
+    "prs_selection_order": (C.c_int, [_vp, _vp, C.c_int32, _vp]),
     "prs_extract_features": (C.c_int, [_vp, C.POINTER(ExtractorParams), _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int32, _i32p]),
     "prs_pose_compose_batch": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),
     "prs_motion_predict_batch": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),

@@ -732,6 +732,57 @@ int prs_extract_features_batch(prs_context* ctx, const prs_extractor_params* par
   return extract_features_launch(ctx, params, batch);
 }
 
+int prs_selection_order(prs_context* ctx, const uint8_t* response, int32_t n, int32_t* order) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  if (n < 0 || n > 32768) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_selection_order: more than 32768 keypoints in a region");
+  }
+  if (n == 0) {
+    return PRS_OK;
+  }
+  if (!response || !order) {
+    return ctx_fail(ctx, PRS_ERR_NULL, "prs_selection_order: responses / order not set");
+  }
+  for (int32_t i = 0; i < n; ++i) {
+    if (response[i] == 0) {
+      return ctx_fail(ctx, PRS_ERR_RANGE, "prs_selection_order: a response of 0 (a detected corner scores at least 1)");
+    }
+  }
+  (void) hipSetDevice(ctx->device);
+  const size_t b_resp = align256((size_t) n), b_order = align256((size_t) n * 4);
+  const size_t total  = b_resp + b_order + 256;
+  unsigned char* d    = static_cast<unsigned char*>(ctx_device_scratch(ctx, total));
+  unsigned char* h    = static_cast<unsigned char*>(ctx_pinned_scratch(ctx, total));
+  if (!d || !h) {
+    return ctx_fail(ctx, PRS_ERR_HIP, "prs_selection_order: scratch allocation failed");
+  }
+  memcpy(h, response, (size_t) n);
+  hipStream_t s = ctx->stream;
+  hipError_t e  = hipMemcpyAsync(d, h, (size_t) n, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_selection_order upload");
+  }
+  const int rc = selection_order_launch(ctx, d, n, reinterpret_cast<int32_t*>(d + b_resp), reinterpret_cast<int32_t*>(d + b_resp + b_order));
+  if (rc != PRS_OK) {
+    return rc;
+  }
+  e = hipMemcpyAsync(h + b_resp, d + b_resp, b_order + 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) {
+    e = hipStreamSynchronize(s);
+  }
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_selection_order download");
+  }
+  const int32_t status = *reinterpret_cast<const int32_t*>(h + b_resp + b_order);
+  if (status != PRS_OK) {
+    return ctx_fail(ctx, status, "prs_selection_order: the sort did not finish");
+  }
+  memcpy(order, h + b_resp, (size_t) n * 4);
+  return PRS_OK;
+}
+
 int prs_extract_features(prs_context* ctx,
                          const prs_extractor_params* params,
                          const uint8_t* image,

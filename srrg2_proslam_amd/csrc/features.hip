@@ -557,7 +557,7 @@ __device__ __forceinline__ void wave_sync_lds() {
 // stop it.  So 64 positions from each side are classified at once (ballot), the stops are ranked into tl[] / tr[], pair j is
 // swapped by lane j, and the first pair that has crossed gives the cut; memory is re-read after every round, which makes
 // swapped items act as the sentinels they are in the serial loop.  tl, tr: 64 ints of LDS each.
-__device__ int std_partition_wave(uint32_t* v, const int first, const int last, const int lane, int* tl, int* tr) {
+__device__ __forceinline__ int std_partition_wave(uint32_t* v, const int first, const int last, const int lane, int* tl, int* tr) {
   if (lane == 0) {  // __move_median_to_first(first, first + 1, mid, last - 1)
     const int a = first + 1, b = first + (last - first) / 2, c = last - 1;
     int pick;
@@ -626,7 +626,7 @@ __device__ int std_partition_wave(uint32_t* v, const int first, const int last, 
 // items; see std_partition_wave).  Lane first + k collects pair k (ds_permute), a stop fetches its partner's position from
 // there (ds_bpermute) and then its partner's item.  Segments that run out of depth go through LDS for the heapsort on one
 // lane; segments of <= 16 items end with their share of the final insertion sort (stable, decreasing response).
-__device__ void std_sort_small_wave(uint32_t* v, const int first, const int n, const int depth, const int lane) {
+__device__ __forceinline__ void std_sort_small_wave(uint32_t* v, const int first, const int n, const int depth, const int lane) {
   uint32_t x = lane < n ? v[first + lane] : 0u;
   int sf = 0, sl = n, sd = depth;
   bool heaped = false;
@@ -774,7 +774,7 @@ __device__ __forceinline__ void sort_queue_unlock(SortQueue& sq) {
   __hip_atomic_store(&sq.lock, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__device__ void std_sort_worker(uint32_t* v, SortQueue& sq, const int lane, int* q) {
+__device__ __forceinline__ void std_sort_worker(uint32_t* v, SortQueue& sq, const int lane, int* q) {
   int* tl    = q;
   int* tr    = q + 64;
   int* stack = q + 128;  // private (first, last, depth) triples: the right siblings along this wave's path, at most 2 lg + 1 <= 31
@@ -917,55 +917,126 @@ __global__ __launch_bounds__(kSelThreads, 8) void select_describe_kernel(const F
     n_sort <<= 1;
   }
   __syncthreads();
-  // ---- region of every keypoint (intensity_feature_extractor_binned.cpp:85-92) + region sizes ------------
-  for (int i = tid; i < n_sort; i += kSelThreads) {
-    uint32_t region = 0xffffffffu;
-    if (i < n) {
-      const uint32_t pix = raw[i] & 0xffffffu;
-      const int r = (int) (pix / (uint32_t) cols), c = (int) (pix - (uint32_t) r * (uint32_t) cols);
-      const int g = (int) floorf((float) r / a.rows_per) * a.p.number_of_detectors_horizontal + (int) ((float) c / a.cols_per);
-      region      = (uint32_t) (g < a.regions ? g : a.regions - 1);
-      atomicAdd(&count[region], 1u);
+  auto region_of = [&](const uint32_t pix) -> uint32_t {  // intensity_feature_extractor_binned.cpp:85-92
+    const int r = (int) (pix / (uint32_t) cols), c = (int) (pix - (uint32_t) r * (uint32_t) cols);
+    const int g = (int) floorf((float) r / a.rows_per) * a.p.number_of_detectors_horizontal + (int) ((float) c / a.cols_per);
+    return (uint32_t) (g < a.regions ? g : a.regions - 1);
+  };
+  if (std_order) {
+    // ---- libstdc++ order: every region's std::vector before its std::sort = its keypoints in detection order.  A stable
+    //      scatter by region: every wave owns a contiguous span of the detections, counts its share of every region, the counts
+    //      become offsets (regions x waves), and the wave writes its items behind those of the waves before it.
+    uint32_t* wcnt      = reinterpret_cast<uint32_t*>(patch) + wave * kMaxRegions;  // (the descriptor phase's staging area is not in use yet)
+    const int span      = (((n + kSelThreads / 64 - 1) / (kSelThreads / 64)) + 63) & ~63;
+    const int span_from = wave * span;
+    const int span_to   = span_from + span < n ? span_from + span : n;
+    for (int g = lane; g < a.regions; g += 64) {
+      wcnt[g] = 0;
     }
-    keys[i] = region;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    uint32_t run = 0;
-    for (int g = 0; g < a.regions; ++g) {
-      start[g] = run;
-      run += count[g];
-    }
-    start[a.regions] = run;
-  }
-  // ---- keys.  Canonical order: (region, sort field, detection order); a region below its target keeps detection order
-  //      (:174-178), the others are ordered by decreasing response (:179-195), ties by detection order.
-  //      libstdc++ order: (region, detection order | response) = the region's std::vector before its std::sort
-  for (int i = tid; i < n; i += kSelThreads) {
-    const uint32_t region = keys[i];
-    const uint32_t s      = raw[i] >> 24;
-    if (std_order) {
-      keys[i] = (region << 23) | ((uint32_t) i << 8) | s;
-    } else {
-      const uint32_t field = count[region] < (uint32_t) a.target_per ? 0u : 255u - s;
-      keys[i]              = (region << 23) | (field << 15) | (uint32_t) i;
-    }
-  }
-  __syncthreads();
-  // ---- bitonic sort of the keys in LDS -------------------------------------------------------------------
-  for (int size = 2; size <= n_sort; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < (n_sort >> 1); t += kSelThreads) {
-        const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
-        const int hi = lo + stride;
-        const bool up = (lo & size) == 0;
-        const uint32_t x = keys[lo], y = keys[hi];
-        if ((x > y) == up) {
-          keys[lo] = y;
-          keys[hi] = x;
+    wave_sync_lds();
+    for (int i0 = span_from; i0 < span_to; i0 += 64) {
+      const int i       = i0 + lane;
+      const bool valid  = i < span_to;
+      const uint32_t g  = valid ? region_of(raw[i] & 0xffffffu) : 0xffffffffu;
+      unsigned long long todo = __ballot(valid);
+      while (todo) {  // one trip per region present among these 64 detections (raster order: a handful)
+        const int leader           = (int) __ffsll((long long) todo) - 1;
+        const uint32_t gl          = (uint32_t) __shfl((int) g, leader, 64);
+        const unsigned long long b = __ballot(g == gl);
+        if (lane == leader) {
+          wcnt[gl] += (uint32_t) __popcll(b);
         }
+        todo &= ~b;
+        wave_sync_lds();
       }
-      __syncthreads();
+    }
+    __syncthreads();
+    for (int g = tid; g < a.regions; g += kSelThreads) {
+      uint32_t* col = reinterpret_cast<uint32_t*>(patch) + g;
+      uint32_t run  = 0;
+      for (int w = 0; w < kSelThreads / 64; ++w) {
+        const uint32_t t      = col[w * kMaxRegions];
+        col[w * kMaxRegions] = run;
+        run += t;
+      }
+      count[g] = run;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t run = 0;
+      for (int g = 0; g < a.regions; ++g) {
+        start[g] = run;
+        run += count[g];
+      }
+      start[a.regions] = run;
+    }
+    __syncthreads();
+    for (int i0 = span_from; i0 < span_to; i0 += 64) {
+      const int i       = i0 + lane;
+      const bool valid  = i < span_to;
+      const uint32_t rw = valid ? raw[i] : 0u;
+      const uint32_t g  = valid ? region_of(rw & 0xffffffu) : 0xffffffffu;
+      unsigned long long todo = __ballot(valid);
+      while (todo) {
+        const int leader           = (int) __ffsll((long long) todo) - 1;
+        const uint32_t gl          = (uint32_t) __shfl((int) g, leader, 64);
+        const unsigned long long b = __ballot(g == gl);
+        if (g == gl) {
+          const uint32_t rank = (uint32_t) __popcll(b & ((1ull << lane) - 1ull));
+          keys[start[gl] + wcnt[gl] + rank] = (gl << 23) | ((uint32_t) i << 8) | (rw >> 24);
+        }
+        wave_sync_lds();
+        if (lane == leader) {
+          wcnt[gl] += (uint32_t) __popcll(b);
+        }
+        todo &= ~b;
+        wave_sync_lds();
+      }
+    }
+    __syncthreads();
+  } else {
+    // ---- region of every keypoint (intensity_feature_extractor_binned.cpp:85-92) + region sizes ------------
+    for (int i = tid; i < n_sort; i += kSelThreads) {
+      uint32_t region = 0xffffffffu;
+      if (i < n) {
+        region = region_of(raw[i] & 0xffffffu);
+        atomicAdd(&count[region], 1u);
+      }
+      keys[i] = region;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t run = 0;
+      for (int g = 0; g < a.regions; ++g) {
+        start[g] = run;
+        run += count[g];
+      }
+      start[a.regions] = run;
+    }
+    // ---- keys.  Canonical order: (region, sort field, detection order); a region below its target keeps detection order
+    //      (:174-178), the others are ordered by decreasing response (:179-195), ties by detection order.
+    for (int i = tid; i < n; i += kSelThreads) {
+      const uint32_t region = keys[i];
+      const uint32_t s      = raw[i] >> 24;
+      const uint32_t field  = count[region] < (uint32_t) a.target_per ? 0u : 255u - s;
+      keys[i]               = (region << 23) | (field << 15) | (uint32_t) i;
+    }
+    __syncthreads();
+    // ---- bitonic sort of the keys in LDS -------------------------------------------------------------------
+    for (int size = 2; size <= n_sort; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int t = tid; t < (n_sort >> 1); t += kSelThreads) {
+          const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+          const int hi = lo + stride;
+          const bool up = (lo & size) == 0;
+          const uint32_t x = keys[lo], y = keys[hi];
+          if ((x > y) == up) {
+            keys[lo] = y;
+            keys[hi] = x;
+          }
+        }
+        __syncthreads();
+      }
     }
   }
   if (std_order) {  // the waves of the workgroup replay the reference's std::sort of every region that is sorted at all
@@ -1130,6 +1201,45 @@ static void fill_window_cells(const int8_t* pattern, FeatureArgs* a) {
     a->pair_first[t]  = (uint16_t) index[((int) pattern[4 * t + 1] + 13) * 27 + ((int) pattern[4 * t] + 13)];
     a->pair_second[t] = (uint16_t) index[((int) pattern[4 * t + 3] + 13) * 27 + ((int) pattern[4 * t + 2] + 13)];
   }
+}
+
+// ---- prs_selection_order: the permutation the reference's std::sort leaves for one region's responses ----------------
+__global__ __launch_bounds__(kSelThreads) void selection_order_kernel(const uint8_t* __restrict__ response, const int n, int32_t* __restrict__ order,
+                                                                      int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t keys[];  // [n]
+  __shared__ SortQueue sortq;
+  __shared__ int scratch[(kSelThreads / 64) * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < n; i += kSelThreads) {
+    keys[i] = ((uint32_t) i << 8) | (uint32_t) response[i];
+  }
+  if (tid == 0) {
+    sortq.lock = sortq.top = sortq.remaining = sortq.failed = 0;
+    sort_queue_seed(sortq, 0, n);
+  }
+  __syncthreads();
+  std_sort_worker(keys, sortq, lane, scratch + wave * 256);
+  __syncthreads();
+  for (int i = tid; i < n; i += kSelThreads) {
+    order[i] = (int32_t) (keys[i] >> 8);
+  }
+  if (tid == 0) {
+    *status = sortq.failed ? PRS_ERR_HIP : PRS_OK;
+  }
+}
+
+int selection_order_launch(prs_context* ctx, const uint8_t* response_dev, int n, int32_t* order_dev, int32_t* status_dev) {
+  const size_t lds = (size_t) (n > 0 ? n : 1) * sizeof(uint32_t);
+  hipError_t e     = hipFuncSetAttribute(reinterpret_cast<const void*>(selection_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_selection_order: LDS for the keys");
+  }
+  hipLaunchKernelGGL(selection_order_kernel, dim3(1), dim3(kSelThreads), lds, ctx->stream, response_dev, n, order_dev, status_dev);
+  e = hipGetLastError();
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_selection_order launch");
+  }
+  return PRS_OK;
 }
 
 int extract_features_launch(prs_context* ctx, const prs_extractor_params* params, const prs_extract_batch* batch) {

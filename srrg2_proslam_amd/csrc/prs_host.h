@@ -79,6 +79,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
 int align_batch_finish(prs_context* ctx);
 int gn_step_launch(prs_context* ctx, const float* dH, const float* db, float damping, float* dX, int* dok);
 int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* params, const prs_bruteforce_batch* batch);
+int selection_order_launch(prs_context* ctx, const uint8_t* response_dev, int n, int32_t* order_dev, int32_t* status_dev);
 int extract_features_launch(prs_context* ctx, const prs_extractor_params* params, const prs_extract_batch* batch);
 int pose_compose_launch(prs_context* ctx, int batch, const float* prediction, const float* X, float* pose_out);
 int motion_predict_launch(prs_context* ctx, int batch, const float* prev2, const float* prev1, float* pred);

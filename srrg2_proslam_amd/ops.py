@@ -842,6 +842,16 @@ def extract_features(ctx, params, image, capacity=4096):
     return uv[:k].copy(), inten[:k].copy(), desc[:k].copy()
 
 
+def selection_order(ctx, response):
+    """responses (1..255) of one region's keypoints in detection order -> the permutation the reference's std::sort leaves
+    (order[k] = keypoint at position k; intensity_feature_extractor_binned.cpp:182-186); host arrays, synchronises"""
+    r = np.ascontiguousarray(response, dtype=np.uint8)
+    order = np.zeros(len(r), dtype=np.int32)
+    rc = _lib.load().prs_selection_order(ctx._h, _p(r), len(r), _p(order))
+    _check(ctx, rc, "prs_selection_order")
+    return order
+
+
 def extract_features_batch(ctx, params, images, keypoints, descriptors, n_features, status, intensity=None):
     """images: uint8 device tensor [B, rows, cols(pitch)]; outputs are device tensors laid out like the stereo
     matcher's inputs (keypoints [B, stride, 2] f32, descriptors [B, stride, 32] u8, n_features [B] i32)."""

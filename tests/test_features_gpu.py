@@ -110,3 +110,37 @@ def test_host_pointer_entry_point_on_a_reference_image(oracle, hip_ctx):
     with pytest.raises(ops.ProslamHipError) as ei:
         ops.extract_features(hip_ctx, pg, img, capacity=100)
     assert ei.value.status == ops._lib.ERR_CAPACITY
+
+
+def test_selection_order_equals_libstdcxx_sort(oracle, hip_ctx):
+    """prs_selection_order (the device replay of std::sort the extractor's PRS_SELECT_LIBSTDCXX selection runs) against the
+    CPU restatement, which tests/test_oracle_features.py::test_F7 pins to g++'s own std::sort: random responses with many
+    ties, every small size (the in-register path and its <= 16 leaves), sizes around the 64-item hand-over, big regions
+    (work queue), sorted / reversed / constant runs and structured inputs that exhaust the depth limit (heapsort on one
+    lane, from the queue path and from inside the in-register path).  Bit-exact: the permutation itself is compared."""
+    rng = np.random.default_rng(11)
+    cases = []
+    for n in list(range(0, 70)) + [100, 127, 128, 129, 257, 1000, 1650, 6000, 20000, 32768]:
+        for vals in (2, 5, 30, 250):
+            cases.append(rng.integers(1, vals + 1, n))
+        cases += [np.arange(n) % 255 + 1, (np.arange(n)[::-1] % 255 + 1).copy(), np.full(n, 7)]
+    heap_cases = 0
+    for n in (40, 64, 200, 1000, 5000):
+        cases.append(np.concatenate([np.arange(0, n, 2), np.arange(1, n, 2)]) % 250 + 1)
+        for m in (3, 17, 101):
+            cases.append((np.arange(n) * 7919) % m + 1)
+        cases.append((np.abs(np.arange(n) - n // 2) + rng.integers(0, 2, n)) % 255 + 1)
+        cases.append(255 - (np.abs(np.arange(n) - n // 2) + rng.integers(0, 2, n)) % 255)
+    # median-of-three killers on small value ranges: long organ-pipe / sawtooth runs
+    for n in (48, 64, 90, 300, 3000):
+        k = np.arange(n)
+        cases.append(np.where(k % 2 == 0, k // 2 % 200 + 1, 201 + (k // 2) % 50))
+        cases.append(np.minimum(k, n - 1 - k) % 254 + 1)
+    for x in cases:
+        x = np.asarray(x, dtype=np.int64)
+        assert x.size == 0 or (x.min() >= 1 and x.max() <= 255)
+        want = of.std_sort_desc(x)
+        got = ops.selection_order(hip_ctx, x.astype(np.uint8))
+        assert np.array_equal(got, want), "n=%d" % len(x)
+    with pytest.raises(ops.ProslamHipError):
+        ops.selection_order(hip_ctx, np.array([3, 0, 5], dtype=np.uint8))  # a response of 0 does not exist
