@@ -133,6 +133,37 @@ __device__ __forceinline__ int hamming_regs(const au32x4& a0, const au32x4& a1, 
   return (int) d;
 }
 
+__device__ __forceinline__ int hamming_half(const au32x4& a0, const au32x4& b0) {
+  uint32_t d = (uint32_t) __popc(a0.x ^ b0.x);
+  d = popc_acc(a0.y ^ b0.y, d);
+  d = popc_acc(a0.z ^ b0.z, d);
+  d = popc_acc(a0.w ^ b0.w, d);
+  return (int) d;
+}
+
+// _filterCorrespondences accepts a fixed point's best candidate when response < dd and response / second-lowest < ratio
+// (correspondence_finder_projective_base_impl.cpp:57-99).  A candidate whose descriptor distance is >= B, B the smallest
+// integer with B >= dd and (largest acceptable response) / B < ratio (evaluated in float like the filter does), cannot win
+// (its response is not below dd) and, as a second-lowest response, cannot make the ratio test fail: whether such a candidate is
+// handed to the filter at all, and with which response, does not change the outcome.  The search may therefore drop every
+// candidate as soon as a PARTIAL distance reaches B.  Returns 0 when nothing can be dropped this way.
+__device__ __forceinline__ int irrelevant_distance(const float dd, const float ratio) {
+  if (!(dd > 0.0f) || !(ratio > 0.0f) || !(dd <= 256.0f)) {
+    return 0;
+  }
+  const int r_max = (int) ceilf(dd) - 1;  // responses are integers: the largest one below dd
+  if (r_max <= 0) {
+    return 1;
+  }
+  float guess = (float) r_max / ratio;
+  int b       = guess < 1024.0f ? (int) guess : 1024;
+  b           = b > r_max ? b : r_max + 1;
+  while (b < 2048 && !((float) r_max / (float) b < ratio)) {
+    ++b;
+  }
+  return b < 2048 ? b : 0;
+}
+
 // the pose the finder and the factors see: X, or sensor_in_robot^-1 * X for the ...WithSensor variants
 // (registration/aligner_slice_processor_projective.h:80-83,88-91); the perturbation stays on X
 __device__ __forceinline__ void pose_to_camera(const prs_aligner_params& a, const float* Sinv, const float* X, float* A) {
@@ -1119,6 +1150,10 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
           const float max_dd = g.f.maximum_descriptor_distance;
           const float r2f    = (float) (sh.radius * sh.radius);
           const int rad2     = rad * rad;
+          // candidates at or beyond this descriptor distance cannot change what the filter below accepts; only worth a
+          // separate pass while the bound is well below what half a random descriptor pair differs by (64 +- 6 bits)
+          const int irrelevant = irrelevant_distance(sh.dd, g.f.maximum_distance_ratio_to_second_best);
+          const int prune_at   = (lattice && irrelevant > 0 && irrelevant <= 54) ? irrelevant : 0;
           // the int16 row / column arithmetic of the reference cannot wrap on this canvas
           const bool circle_exact = rad < 8192 && R + rad < 32000 && (g.cell_ncx << g.cell_sx) + rad < 32000;
           int projected      = 0;
@@ -1238,28 +1273,64 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                     return dcol > col - width && dcol < col + width;
                   }
                 };
-                auto score = [&](const uint2 e) {
-                  const int fi     = (int) (e.y & 0xffffu);
+                auto score = [&](const uint32_t ey) {  // ey: fixed index | canonical lattice position << 16
+                  const int fi     = (int) (ey & 0xffffu);
                   const uint32_t d = (uint32_t) hamming_regs(fdesc[2 * fi], fdesc[2 * fi + 1], q0, q1);
                   // best / second best (circle_impl.cpp:64-72) as min / second-min of unique keys
-                  const uint32_t key = (d << 16) | (e.y >> 16);
+                  const uint32_t key = (d << 16) | (ey >> 16);
                   const uint32_t hi  = key > bestk ? key : bestk;
                   seck               = hi < seck ? hi : seck;
                   bestk              = key < bestk ? key : bestk;
                 };
-                for (int cy = r0 >> g.cell_sy; cy <= (r1 >> g.cell_sy); ++cy) {
-                  const int seg0 = cellstart[cy * g.cell_ncx + cx0];
-                  const int seg1 = cellstart[cy * g.cell_ncx + cx1 + 1];
-                  // two lattice entries per trip (the entry behind the last one of the segment is read but not used)
-                  for (int pos = seg0; pos < seg1; pos += 2) {
-                    const uint2 ea = db[pos], eb = db[pos + 1];
-                    const bool in_a = accepts(ea);
-                    const bool in_b = pos + 1 < seg1 && accepts(eb);
-                    if (in_a) {
-                      score(ea);
+                if (prune_at > 0) {
+                  // first half of the descriptor only; the few candidates whose partial distance stays below the
+                  // irrelevance bound (irrelevant_distance) are remembered and scored in full after the scan
+                  uint32_t kept = 0xffffffffu;  // canonical lattice positions of up to two such candidates (0xffff: none)
+                  auto prescore = [&](const uint32_t ey) {
+                    if (hamming_half(fdesc[2 * (int) (ey & 0xffffu)], q0) < prune_at) {
+                      const uint32_t evicted = kept >> 16;
+                      if (evicted != 0xffffu) {
+                        score((uint32_t) inv[evicted] | (evicted << 16));
+                      }
+                      kept = (kept << 16) | (ey >> 16);
                     }
-                    if (in_b) {
-                      score(eb);
+                  };
+                  for (int cy = r0 >> g.cell_sy; cy <= (r1 >> g.cell_sy); ++cy) {
+                    const int seg0 = cellstart[cy * g.cell_ncx + cx0];
+                    const int seg1 = cellstart[cy * g.cell_ncx + cx1 + 1];
+                    for (int pos = seg0; pos < seg1; pos += 2) {
+                      const uint2 ea = db[pos], eb = db[pos + 1];
+                      const bool in_a = accepts(ea);
+                      const bool in_b = pos + 1 < seg1 && accepts(eb);
+                      if (in_a) {
+                        prescore(ea.y);
+                      }
+                      if (in_b) {
+                        prescore(eb.y);
+                      }
+                    }
+                  }
+                  if ((kept & 0xffffu) != 0xffffu) {
+                    score((uint32_t) inv[kept & 0xffffu] | (kept << 16));
+                  }
+                  if ((kept >> 16) != 0xffffu) {
+                    score((uint32_t) inv[kept >> 16] | (kept & 0xffff0000u));
+                  }
+                } else {
+                  for (int cy = r0 >> g.cell_sy; cy <= (r1 >> g.cell_sy); ++cy) {
+                    const int seg0 = cellstart[cy * g.cell_ncx + cx0];
+                    const int seg1 = cellstart[cy * g.cell_ncx + cx1 + 1];
+                    // two lattice entries per trip (the entry behind the last one of the segment is read but not used)
+                    for (int pos = seg0; pos < seg1; pos += 2) {
+                      const uint2 ea = db[pos], eb = db[pos + 1];
+                      const bool in_a = accepts(ea);
+                      const bool in_b = pos + 1 < seg1 && accepts(eb);
+                      if (in_a) {
+                        score(ea.y);
+                      }
+                      if (in_b) {
+                        score(eb.y);
+                      }
                     }
                   }
                 }
