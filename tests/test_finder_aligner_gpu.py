@@ -324,3 +324,56 @@ def test_randomised_configurations_through_the_batched_pipeline(oracle, hip_ctx)
     bad, n_corr = fuzz_align.run(16, 20200304, ctx=hip_ctx, oracle=oracle, verbose=False)
     assert not bad, bad[:3]
     assert n_corr > 3000
+
+
+@pytest.mark.parametrize("ratio", [0.5, 0.8, 0.95])
+@pytest.mark.parametrize("min_dd", [10.0, 25.0, 40.0, 60.0])
+def test_search_prefilter_keeps_every_candidate_the_filter_can_see(oracle, hip_ctx, ratio, min_dd):
+    """The search kernel drops a candidate once its partial descriptor distance reaches the bound beyond which
+    _filterCorrespondences' outcome cannot depend on it (csrc/align.hip: irrelevant_distance).  Adversarial inputs for that
+    argument: a crowded image (several fixed points inside every search pattern), moving descriptors that are copies of
+    fixed ones with 0..90 flipped bits (distances on both sides of the bound, many exactly at it), duplicates of the same
+    fixed descriptor on neighbouring points (ties and second-lowest responses that decide the ratio test), over several
+    calls so that radius / threshold adaptation and the retry path are part of it.  min_dd = 60 puts the bound above the
+    kernel's cut-off for the separate pass (the plain path must give the same answers)."""
+    cfg = configs.get("kitti")
+    rng = np.random.default_rng(int(1000 * ratio + min_dd))
+    cam = cfg["camera"]
+    n = 700
+    # crowded: keypoints on a jittered grid of ~22 px pitch in a 500 x 300 window
+    gx, gy = np.meshgrid(np.arange(28), np.arange(25))
+    uv = np.stack([gx.ravel() * 18 + 300, gy.ravel() * 12 + 40], axis=1).astype(np.float32)[:n]
+    uv += rng.integers(-3, 4, uv.shape).astype(np.float32)
+    depth = rng.uniform(6.0, 40.0, n).astype(np.float32)
+    fx, fy, cx, cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+    xyz = np.stack([(uv[:, 0] - cx) / fx * depth, (uv[:, 1] - cy) / fy * depth, depth], axis=1).astype(np.float32)
+    disparity = (fx * cam["baseline_m"] / depth).astype(np.float32)
+    fixed = np.concatenate([uv, uv - np.stack([disparity, np.zeros(n, np.float32)], axis=1)], axis=1).astype(np.float32)
+    base = syn.random_descriptors(rng, 40)  # few distinct descriptors: neighbours share them
+    dfix = base[rng.integers(0, 40, n)].copy()
+    flips = rng.integers(0, 12, n)
+    for i in range(n):
+        for b in rng.choice(256, flips[i], replace=False):
+            dfix[i, b // 8] ^= np.uint8(1 << (b % 8))
+    # the local map: the same points (identity motion) in shuffled order, descriptors = fixed ones with 0..90 flipped bits
+    order = rng.permutation(n)
+    dmov = dfix[order].copy()
+    flips = rng.choice([0, 3, 8, 12, 16, 20, 24, 28, 31, 32, 33, 40, 48, 52, 53, 54, 55, 60, 75, 90], n)
+    for i in range(n):
+        for b in rng.choice(256, flips[i], replace=False):
+            dmov[i, b // 8] ^= np.uint8(1 << (b % 8))
+    mp = {"xyz": xyz[order].copy(), "desc": dmov}
+    kw = dict(maximum_distance_ratio_to_second_best=ratio, minimum_descriptor_distance=min_dd, maximum_descriptor_distance=max(75.0, min_dd + 15.0))
+    of, gf = _finders(oracle, hip_ctx, cfg, fixed, dfix, mp, **kw)
+    T = np.eye(4, dtype=np.float32)
+    total = 0
+    for call in range(10):
+        Tk = syn.perturb(rng, T, 0.02 / (1 + call), 0.001 / (1 + call)) if call < 6 else T
+        of.set_local_map_in_sensor(Tk)
+        gf.set_local_map_in_sensor(Tk)
+        rc, rflags = of.compute()
+        gc, gflags = gf.compute()
+        assert corr_equal(rc, gc), "call %d: %d vs %d correspondences" % (call, len(rc), len(gc))
+        assert rflags == gflags and _same_state(of, gf), "call %d" % call
+        total += len(rc)
+    assert total > 100
