@@ -36,10 +36,7 @@ constexpr uint32_t kG0 = 18, kG1 = 34, kG2 = 49, kG3 = 55;
 struct FeatureArgs {
   prs_extractor_params p;
   prs_extract_batch b;
-  uint32_t* tilelist;  // [batch][max_raw] response << 24 | pixel index, tile by tile (raster order inside a tile)
-  uint32_t* rowinfo;   // [batch][rows][tiles_x] first entry in tilelist | entries << 16 of one pixel row of one tile
-  int32_t* fill;       // [batch] entries in tilelist (zeroed before the tile kernel)
-  int tiles_x;
+  uint8_t* score;     // [batch][rows][cols]
   uint8_t* blur;      // [batch][rows][cols] smoothed image (defined 3 px inside the border; ORB reads >= 18 px inside)
   uint32_t* raw;      // [batch][max_raw] response << 24 | pixel index, raster order
   int32_t* n_raw;     // [batch]
@@ -75,10 +72,6 @@ __device__ __forceinline__ uint32_t bytes_even(uint32_t x) { return x & 0x00ff00
 __device__ __forceinline__ uint32_t bytes_odd(uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0c030c01u); }  // bytes 1, 3 -> lanes
 __device__ __forceinline__ int lanes_below(uint64_t m, int base) {  // base + number of set bits of m below this lane
   return (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, (uint32_t) base));
-}
-
-__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t w) {  // bit j <=> byte j of the word is non-zero
-  return ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u) | ((w & 0xff0000u) ? 4u : 0u) | ((w & 0xff000000u) ? 8u : 0u);
 }
 
 constexpr int kTileWords  = kTilePitch / 4;   // 18 words per tile row
@@ -121,7 +114,7 @@ __device__ __forceinline__ int arc_best(const uint8_t* c, bool dark) {
 // lane; the separable 7x7 Gaussian of the tile on the side (packed 16-bit horizontal pass, 32-bit vertical pass).
 template <bool BORDER>
 __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* tile32, uint32_t* resp32, uint64_t* hsum64, uint16_t (*list)[kListCap],
-                                              uint16_t (*second)[kSecondCap], int* list_n, int* comp) {
+                                              uint16_t (*second)[kSecondCap], int* list_n) {
   const int rows = a.b.rows, cols = a.b.cols, pitch = a.b.pitch;
   const int img = blockIdx.z;
   const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
@@ -335,10 +328,10 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
     }
   }
   __syncthreads();
-  // ---- non-maximum suppression (strictly greater than the 8 neighbours), four pixels per lane, and the tile's survivors in
-  // raster order.  A non-zero response never sits on the outermost 3 pixels, so the ring values are real responses of real pixels.
+  // ---- non-maximum suppression (strictly greater than the 8 neighbours) and the response map, four pixels per lane.
+  // A non-zero response never sits on the outermost 3 pixels, so the ring values are real responses of real pixels.
+  uint8_t* __restrict__ score = a.score + (size_t) img * rows * cols;
   const bool nms = a.p.enable_non_maximum_suppression != 0;
-  uint32_t outw[kTileH / 16];
 #pragma unroll
   for (int k = 0; k < kTileH / 16; ++k) {
     const int ly = r0 + 16 * k, gy = y0 + ly, gx = x0 + 4 * w1;
@@ -360,68 +353,13 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
       }
       out = kept[0] | (kept[1] << 8);
     }
-    if (BORDER) {  // pixels of the tile beyond the image
-      if (gy >= rows) {
-        out = 0u;
-      } else if (gx + 3 >= cols) {
-        const int inside = cols - gx;  // < 4
-        out              = inside <= 0 ? 0u : (out & (0xffffffffu >> (8 * (4 - inside))));
-      }
-    }
-    outw[k] = out;
-  }
-  // Ordered compaction over (pass k, wave, lane) = raster order of the tile: thread t owns word t & 15 of row (t >> 4) + 16 k.
-  // The counts 0..4 of a word are ranked with three ballots; one barrier for the 16 (pass, wave) totals, one for the tile's
-  // place in the image's list (a single atomic per tile; the list is put into raster order by raster_merge_kernel).
-  int excl[kTileH / 16];
-  uint32_t rowcnt[kTileH / 16];
-#pragma unroll
-  for (int k = 0; k < kTileH / 16; ++k) {
-    const int c = __popc(nonzero_bytes(outw[k]));
-    const unsigned long long b0 = __ballot((c & 1) != 0), b1 = __ballot((c & 2) != 0), b2 = __ballot((c & 4) != 0);
-    excl[k] = lanes_below(b0, 0) + 2 * lanes_below(b1, 0) + 4 * lanes_below(b2, 0);
-    const int sh = lane & 48;  // the 16 lanes of this thread's pixel row
-    rowcnt[k]    = (uint32_t) (__popc((uint32_t) (b0 >> sh) & 0xffffu) + 2 * __popc((uint32_t) (b1 >> sh) & 0xffffu) + 4 * __popc((uint32_t) (b2 >> sh) & 0xffffu));
-    if (lane == 0) {
-      comp[k * (kFastThreads / 64) + wave] = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-    }
-  }
-  __syncthreads();
-  int before[kTileH / 16];
-  int tile_total = 0;
-#pragma unroll
-  for (int k = 0; k < kTileH / 16; ++k) {
-    before[k] = tile_total;
-#pragma unroll
-    for (int w = 0; w < kFastThreads / 64; ++w) {
-      const int t = comp[k * (kFastThreads / 64) + w];
-      before[k] += w < wave ? t : 0;
-      tile_total += t;
-    }
-  }
-  if (tid == 0) {
-    comp[(kTileH / 16) * (kFastThreads / 64)] = tile_total > 0 ? atomicAdd(&a.fill[img], tile_total) : 0;
-  }
-  __syncthreads();
-  const int tile_base = comp[(kTileH / 16) * (kFastThreads / 64)];
-  uint32_t* __restrict__ tl = a.tilelist + (size_t) img * a.max_raw;
-  uint32_t* __restrict__ ri = a.rowinfo + (size_t) img * rows * a.tiles_x;
-#pragma unroll
-  for (int k = 0; k < kTileH / 16; ++k) {
-    const int ly = r0 + 16 * k, gy = y0 + ly, gx = x0 + 4 * w1;
-    int slot = tile_base + before[k] + excl[k];
-    if (w1 == 0 && (!BORDER || gy < rows)) {
-      ri[(size_t) gy * a.tiles_x + blockIdx.x] = (uint32_t) (slot < 0xffff ? slot : 0xffff) | (rowcnt[k] << 16);
-    }
-    if (outw[k]) {
+    if (!BORDER) {
+      __builtin_memcpy(score + (size_t) gy * cols + gx, &out, 4);
+    } else if (gy < rows) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const uint32_t sc = (outw[k] >> (8 * j)) & 0xffu;
-        if (sc) {
-          if (slot < a.max_raw) {
-            tl[slot] = (sc << 24) | (uint32_t) (gy * cols + gx + j);
-          }
-          ++slot;
+        if (gx + j < cols) {
+          score[(size_t) gy * cols + gx + j] = (uint8_t) (out >> (8 * j));
         }
       }
     }
@@ -435,68 +373,127 @@ __global__ __launch_bounds__(kFastThreads) void fast_blur_kernel(const FeatureAr
   __shared__ uint16_t list[kFastThreads / 64][kListCap];
   __shared__ uint16_t second[kFastThreads / 64][kSecondCap];
   __shared__ int list_n[kFastThreads / 64];
-  __shared__ int comp[(kTileH / 16) * (kFastThreads / 64) + 1];
   const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
   // a tile whose halo lies inside the image needs no coordinate checks at all (block-uniform)
   if (x0 >= 4 && x0 + kTileW + 4 <= a.b.cols && y0 >= 4 && y0 + kTileH + 4 <= a.b.rows) {
-    fast_blur_tile<false>(a, tile32, resp32, hsum64, list, second, list_n, comp);
+    fast_blur_tile<false>(a, tile32, resp32, hsum64, list, second, list_n);
   } else {
-    fast_blur_tile<true>(a, tile32, resp32, hsum64, list, second, list_n, comp);
+    fast_blur_tile<true>(a, tile32, resp32, hsum64, list, second, list_n);
   }
 }
 
-// The image's detections in raster order: the tile kernel left them tile by tile (raster order inside a tile) together with,
-// for every pixel row of every tile, where that row's entries start and how many they are.  One workgroup per image scans the
-// counts in (row, tile) order and copies every run to its place: ~30 KB of row records + the list itself instead of two
-// passes over a response map of the image's size.
-__global__ __launch_bounds__(kNmsThreads) void raster_merge_kernel(const FeatureArgs a) {
+// raster-order compaction of the (already suppressed) response map.
+// Every wave owns a contiguous range of the image; it counts its survivors, the 16 counts are scanned once,
+// then the wave rescans its range (response map still in L2) and writes at its offset: two barriers per image.
+// A lane takes 16 pixels per load, four loads in flight; survivors are the non-zero bytes.
+typedef uint32_t px16 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t w) {  // bit j <=> byte j of the word is non-zero
+  return ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u) | ((w & 0xff0000u) ? 4u : 0u) | ((w & 0xff000000u) ? 8u : 0u);
+}
+
+__global__ __launch_bounds__(kNmsThreads) void nms_compact_kernel(const FeatureArgs a) {
   __shared__ int wave_tot[kNmsThreads / 64];
-  const int img = blockIdx.x;
+  constexpr int kPerLane = 16, kChunk = 64 * kPerLane, kInFlight = 4;
+  const int rows = a.b.rows, cols = a.b.cols;
+  const int img  = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int total = a.fill[img];
-  if (total > a.max_raw) {  // more detections than the selection can hold: loud per-image error (select_describe_kernel)
-    if (tid == 0) {
-      a.n_raw[img] = -1;
+  const uint8_t* __restrict__ score = a.score + (size_t) img * rows * cols;
+  uint32_t* __restrict__ raw        = a.raw + (size_t) img * a.max_raw;
+  const int n_pix = rows * cols;
+  const int n_chunks = (n_pix + kChunk - 1) / kChunk;
+  const int per_wave = (n_chunks + kNmsThreads / 64 - 1) / (kNmsThreads / 64);
+  const int c_begin = wave * per_wave, c_end = min(c_begin + per_wave, n_chunks);
+  auto load16 = [&](int ch) -> px16 {
+    px16 r     = {0u, 0u, 0u, 0u};
+    const int i = ch * kChunk + kPerLane * lane;
+    if (ch < c_end && i < n_pix) {
+      if (i + kPerLane <= n_pix) {
+        __builtin_memcpy(&r, score + i, kPerLane);  // any alignment
+      } else {  // the last pixels of the image
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        for (int j = 0; i + j < n_pix; ++j) {
+          w[j >> 2] |= (uint32_t) score[i + j] << (8 * (j & 3));
+        }
+        r = px16{w[0], w[1], w[2], w[3]};
+      }
     }
-    return;
-  }
-  const uint32_t* __restrict__ ri = a.rowinfo + (size_t) img * a.b.rows * a.tiles_x;
-  const uint32_t* __restrict__ tl = a.tilelist + (size_t) img * a.max_raw;
-  uint32_t* __restrict__ raw      = a.raw + (size_t) img * a.max_raw;
-  const int n_entries = a.b.rows * a.tiles_x;
-  const int per       = (n_entries + kNmsThreads - 1) / kNmsThreads;
-  const int e_begin = tid * per, e_end = min(e_begin + per, n_entries);
+    return r;
+  };
   int mine = 0;
-  for (int e = e_begin; e < e_end; ++e) {
-    mine += (int) (ri[e] >> 16);
-  }
-  int incl = mine;
+  for (int ch = c_begin; ch < c_end; ch += kInFlight) {
+    px16 px[kInFlight];
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_up(incl, o, 64);
-    if (lane >= o) {
-      incl += v;
+    for (int u = 0; u < kInFlight; ++u) {
+      px[u] = load16(ch + u);
+    }
+#pragma unroll
+    for (int u = 0; u < kInFlight; ++u) {
+      if (px[u].x | px[u].y | px[u].z | px[u].w) {
+        mine += __popc(nonzero_bytes(px[u].x) | (nonzero_bytes(px[u].y) << 4) | (nonzero_bytes(px[u].z) << 8) | (nonzero_bytes(px[u].w) << 12));
+      }
     }
   }
-  if (lane == 63) {
-    wave_tot[wave] = incl;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mine += __shfl_xor(mine, o, 64);
+  }
+  if (lane == 0) {
+    wave_tot[wave] = mine;
   }
   __syncthreads();
-  int offset = incl - mine;
+  int offset = 0, total = 0;
 #pragma unroll
   for (int w = 0; w < kNmsThreads / 64; ++w) {
     offset += w < wave ? wave_tot[w] : 0;
+    total += wave_tot[w];
   }
-  for (int e = e_begin; e < e_end; ++e) {
-    const uint32_t info = ri[e];
-    const int cnt = (int) (info >> 16), from = (int) (info & 0xffffu);
-    for (int j = 0; j < cnt; ++j) {
-      raw[offset + j] = tl[from + j];
+  if (total <= a.max_raw) {
+    for (int ch0 = c_begin; ch0 < c_end; ch0 += kInFlight) {
+      px16 px[kInFlight];
+#pragma unroll
+      for (int u = 0; u < kInFlight; ++u) {
+        px[u] = load16(ch0 + u);
+      }
+#pragma unroll
+      for (int u = 0; u < kInFlight; ++u) {
+        const int i          = (ch0 + u) * kChunk + kPerLane * lane;
+        const uint32_t wd[4] = {px[u].x, px[u].y, px[u].z, px[u].w};
+        const bool any       = (wd[0] | wd[1] | wd[2] | wd[3]) != 0u;
+        if (__ballot(any) == 0ull) {
+          continue;  // nothing in these 1024 pixels (wave-uniform)
+        }
+        const uint32_t keep = any ? nonzero_bytes(wd[0]) | (nonzero_bytes(wd[1]) << 4) | (nonzero_bytes(wd[2]) << 8) | (nonzero_bytes(wd[3]) << 12) : 0u;
+        const int cnt = __popc(keep);
+        int incl      = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int v = __shfl_up(incl, o, 64);
+          if (lane >= o) {
+            incl += v;
+          }
+        }
+        int slot = offset + incl - cnt;
+        if (any) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {  // raster order within the lane's 16 pixels
+            if (wd[q]) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const uint32_t s = (wd[q] >> (8 * j)) & 0xffu;
+                if (s) {
+                  raw[slot++] = (s << 24) | (uint32_t) (i + 4 * q + j);
+                }
+              }
+            }
+          }
+        }
+        offset += __shfl(incl, 63, 64);
+      }
     }
-    offset += cnt;
   }
   if (tid == 0) {
-    a.n_raw[img] = total;
+    a.n_raw[img] = total > a.max_raw ? -1 : total;
   }
 }
 
@@ -1280,17 +1277,12 @@ int extract_features_launch(prs_context* ctx, const prs_extractor_params* params
   a.p = *params;
   a.b = *batch;
   const size_t npix = (size_t) batch->rows * batch->cols;
-  a.tiles_x = (batch->cols + kTileW - 1) / kTileW;
-  const size_t n_rowinfo = (size_t) batch->rows * a.tiles_x;
-  uint32_t* lists = static_cast<uint32_t*>(ctx_device_scratch_slot(ctx, 0, (size_t) batch->batch * ((size_t) max_raw + n_rowinfo + 1) * 4));
+  a.score = static_cast<uint8_t*>(ctx_device_scratch_slot(ctx, 0, (size_t) batch->batch * npix));
   a.blur  = static_cast<uint8_t*>(ctx_device_scratch_slot(ctx, 1, (size_t) batch->batch * npix));
   uint32_t* rawbuf = static_cast<uint32_t*>(ctx_device_scratch_slot(ctx, 2, (size_t) batch->batch * ((size_t) max_raw + 1) * 4));
-  if (!lists || !a.blur || !rawbuf) {
+  if (!a.score || !a.blur || !rawbuf) {
     return ctx_fail(ctx, PRS_ERR_HIP, "prs_extract_features_batch: scratch allocation failed");
   }
-  a.tilelist = lists;
-  a.rowinfo  = lists + (size_t) batch->batch * max_raw;
-  a.fill     = reinterpret_cast<int32_t*>(a.rowinfo + (size_t) batch->batch * n_rowinfo);
   a.raw   = rawbuf;
   a.n_raw   = reinterpret_cast<int32_t*>(rawbuf + (size_t) batch->batch * max_raw);
   a.max_raw = max_raw;
@@ -1301,14 +1293,10 @@ int extract_features_launch(prs_context* ctx, const prs_extractor_params* params
   a.target_per = (int) ((float) params->target_number_of_keypoints / (float) regions);  // :72-76
   hipStream_t stream = ctx_stream(ctx);
   const dim3 tiles((batch->cols + kTileW - 1) / kTileW, (batch->rows + kTileH - 1) / kTileH, batch->batch);
-  hipError_t e = hipMemsetAsync(a.fill, 0, (size_t) batch->batch * sizeof(int32_t), stream);
-  if (e != hipSuccess) {
-    return ctx_fail_hip(ctx, e, "prs_extract_features_batch: list counters");
-  }
   hipLaunchKernelGGL(fast_blur_kernel, tiles, dim3(kFastThreads), 0, stream, a);
-  hipLaunchKernelGGL(raster_merge_kernel, dim3(batch->batch), dim3(kNmsThreads), 0, stream, a);
+  hipLaunchKernelGGL(nms_compact_kernel, dim3(batch->batch), dim3(kNmsThreads), 0, stream, a);
   const size_t lds_keys = (size_t) max_raw * sizeof(uint32_t);
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_describe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_keys);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_describe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_keys);
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_extract_features_batch: LDS for the selection sort");
   }
