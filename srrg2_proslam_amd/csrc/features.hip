@@ -238,25 +238,21 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
   if (lane == 0) {
     list_n[wave] = n_mine;
   }
-  // ---- 7x7 Gaussian, horizontal pass: tile rows -3 .. kTileH+2, four sums per lane on packed 16-bit lanes.  The taps are
-  // symmetric: 55 c + 49 (l1 + r1) + 34 (l2 + r2) + 18 (l3 + r3) <= 257 * 255 = 65535 fits the lane exactly.
+  // ---- 7x7 Gaussian, horizontal pass: tile rows -3 .. kTileH+2, four sums per lane, stored as packed 16-bit lanes:
+  // 55 c + 49 (l1 + r1) + 34 (l2 + r2) + 18 (l3 + r3) <= 257 * 255 = 65535 fits the lane exactly.
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     const int h = r0 + 16 * k;
     if (h < kTileH + 6) {
       const int wi      = (h + 1) * kTileWords + 1 + w1;
       const uint32_t C = tile32[wi], L = tile32[wi - 1], R = tile32[wi + 1];
-      const uint32_t l3 = __builtin_amdgcn_alignbyte(C, L, 1), l2 = __builtin_amdgcn_alignbyte(C, L, 2), l1 = __builtin_amdgcn_alignbyte(C, L, 3);
-      const uint32_t r1 = __builtin_amdgcn_alignbyte(R, C, 1), r2 = __builtin_amdgcn_alignbyte(R, C, 2), r3 = __builtin_amdgcn_alignbyte(R, C, 3);
-      uint32_t sum[2];
-#pragma unroll
-      for (int par = 0; par < 2; ++par) {
-        auto lanes = [&](uint32_t x) { return par ? bytes_odd(x) : bytes_even(x); };
-        const us2 s1 = __builtin_bit_cast(us2, pk_add(lanes(l1), lanes(r1))), s2 = __builtin_bit_cast(us2, pk_add(lanes(l2), lanes(r2)));
-        const us2 s3 = __builtin_bit_cast(us2, pk_add(lanes(l3), lanes(r3))), c = __builtin_bit_cast(us2, lanes(C));
-        const us2 acc = c * (us2) ((unsigned short) kG3) + s1 * (us2) ((unsigned short) kG2) + s2 * (us2) ((unsigned short) kG1) + s3 * (us2) ((unsigned short) kG0);
-        sum[par]      = __builtin_bit_cast(uint32_t, acc);
-      }
+      // pixel x = 4 w + j: bytes x-3 .. x against (18, 34, 49, 55) and bytes x+1 .. x+4 against (49, 34, 18, 0), two v_dot4_u32_u8
+      constexpr uint32_t kTapsLeft = kG0 | (kG1 << 8) | (kG2 << 16) | (kG3 << 24), kTapsRight = kG2 | (kG1 << 8) | (kG0 << 16);
+      const uint32_t s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, L, 1), kTapsLeft, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 1), kTapsRight, 0u, false), false);
+      const uint32_t s1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, L, 2), kTapsLeft, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 2), kTapsRight, 0u, false), false);
+      const uint32_t s2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, L, 3), kTapsLeft, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 3), kTapsRight, 0u, false), false);
+      const uint32_t s3 = __builtin_amdgcn_udot4(C, kTapsLeft, __builtin_amdgcn_udot4(R, kTapsRight, 0u, false), false);
+      const uint32_t sum[2] = {s0 | (s2 << 16), s1 | (s3 << 16)};
       hsum64[h * 16 + w1] = ((uint64_t) sum[1] << 32) | sum[0];  // lanes: pixel 0 | pixel 2 , pixel 1 | pixel 3
     }
   }
@@ -306,14 +302,24 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
     const uint64_t* h = hsum64 + ly * 16 + w1;  // row ly of the tile is horizontal row ly + 3: rows ly .. ly + 6
     uint32_t acc[4] = {1u << 15, 1u << 15, 1u << 15, 1u << 15};
     constexpr uint32_t taps[7] = {kG0, kG1, kG2, kG3, kG2, kG1, kG0};
+    // two rows per step: the same pixel of rows i and i + 1 side by side (v_perm), one v_dot2_u32_u16 against (tap i, tap i + 1)
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const uint64_t hv = h[16 * i];
+    for (int i = 0; i < 6; i += 2) {
+      const uint64_t ha = h[16 * i], hb = h[16 * (i + 1)];
+      const uint32_t ea = (uint32_t) ha, oa = (uint32_t) (ha >> 32), eb = (uint32_t) hb, ob = (uint32_t) (hb >> 32);
+      const us2 tp = __builtin_bit_cast(us2, taps[i] | (taps[i + 1] << 16));
+      acc[0] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(eb, ea, 0x05040100u)), tp, acc[0], false);
+      acc[1] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(ob, oa, 0x05040100u)), tp, acc[1], false);
+      acc[2] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(eb, ea, 0x07060302u)), tp, acc[2], false);
+      acc[3] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(ob, oa, 0x07060302u)), tp, acc[3], false);
+    }
+    {
+      const uint64_t hv = h[16 * 6];
       const uint32_t ev = (uint32_t) hv, od = (uint32_t) (hv >> 32);
-      acc[0] += taps[i] * (ev & 0xffffu);
-      acc[1] += taps[i] * (od & 0xffffu);
-      acc[2] += taps[i] * (ev >> 16);
-      acc[3] += taps[i] * (od >> 16);
+      acc[0] += taps[6] * (ev & 0xffffu);
+      acc[1] += taps[6] * (od & 0xffffu);
+      acc[2] += taps[6] * (ev >> 16);
+      acc[3] += taps[6] * (od >> 16);
     }
     const uint32_t out = min(acc[0] >> 16, 255u) | (min(acc[1] >> 16, 255u) << 8) | (min(acc[2] >> 16, 255u) << 16) | (min(acc[3] >> 16, 255u) << 24);
     if (!BORDER) {
