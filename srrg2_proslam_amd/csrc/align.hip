@@ -58,6 +58,7 @@ struct AlignShared {
   float kd_range;   // KD-tree finder: the search radius _initializeDatabase last ran with (leaf range of the tree)
   int kd_nodes, kd_leaves, kd_open_next;  // KD-tree build counters
   unsigned long long radius, it;
+  unsigned long long stamp_acc[9], stamp_mark, stamp_sub;  // PRS_STAMPS phase timers of thread 0 (in LDS: no registers when they are off)
   int converged, config_changed, num_recomputes;
   int n_corr, n_filtered, n_projected, decision, flags, error;
   int n_inl, n_out, n_inv;
@@ -663,12 +664,17 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
     __syncthreads();
   }
 
-  unsigned long long acc_finder = 0, acc_lin = 0, acc_sum = 0, acc_solve = 0, t_mark = 0;
-  unsigned long long acc_db = 0, acc_search = 0, acc_pass2 = 0, acc_filter = 0, acc_commit = 0, t_sub = 0;
-#define SUB_MARK() (t_sub = (g.stamps && tid == 0) ? (unsigned long long) clock64() : 0ull)
-#define SUB_ACC(v) do { if (g.stamps && tid == 0) { const unsigned long long now_ = (unsigned long long) clock64(); v += now_ - t_sub; t_sub = now_; } } while (0)
-#define ALIGN_MARK() (t_mark = (g.stamps && tid == 0) ? (unsigned long long) clock64() : 0ull)
-#define ALIGN_ACC(v) do { if (g.stamps && tid == 0) { v += (unsigned long long) clock64() - t_mark; } } while (0)
+  enum { acc_finder = 0, acc_lin, acc_sum, acc_solve, acc_db, acc_search, acc_pass2, acc_filter, acc_commit };
+  if (g.stamps && tid == 0) {
+    for (int i = 0; i < 9; ++i) {
+      sh.stamp_acc[i] = 0;
+    }
+    sh.stamp_mark = sh.stamp_sub = 0;
+  }
+#define SUB_MARK() do { if (g.stamps && tid == 0) { sh.stamp_sub = (unsigned long long) clock64(); } } while (0)
+#define SUB_ACC(v) do { if (g.stamps && tid == 0) { const unsigned long long now_ = (unsigned long long) clock64(); sh.stamp_acc[v] += now_ - sh.stamp_sub; sh.stamp_sub = now_; } } while (0)
+#define ALIGN_MARK() do { if (g.stamps && tid == 0) { sh.stamp_mark = (unsigned long long) clock64(); } } while (0)
+#define ALIGN_ACC(v) do { if (g.stamps && tid == 0) { sh.stamp_acc[v] += (unsigned long long) clock64() - sh.stamp_mark; } } while (0)
   // PRS_MODE_ALIGN: max_iterations of finder + GN, then the inlier-only run (frozen correspondences, no finder)
   const int max_it = (g.mode == PRS_MODE_ALIGN && !sh.error) ? g.a.max_iterations + inlier_run_length(g.a) : (sh.error ? 0 : 1);
   if (split_search && sh.error && tid == 0) {
@@ -1241,19 +1247,18 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
               cb1 = cb1 > colmax ? colmax : cb1;
               if (r0 <= r1 && cb0 <= cb1) {
                 const int cx0 = cb0 >> g.cell_sx, cx1 = cb1 >> g.cell_sx;
-                // whether the lattice entry e lies inside the search pattern of this query
                 const uint32_t query_rc = ((uint32_t) row & 0xffffu) | ((uint32_t) col << 16);
-                auto accepts = [&](const uint2 e) -> bool {
-                  if (stype == PRS_SEARCH_CIRCLE && circle_exact) {
-                    // rows [row - r, row + r] (circle_impl.cpp:25-26,40-47) and col - w < dcol < col + w with
-                    // w = int(sqrt(r^2 - h^2) + 1) (:51-56) is |dc| <= isqrt(r^2 - h^2), i.e. the integer test
-                    // dc^2 + h^2 <= r^2 (which also implies |h| <= r): no width table, no row compare.
-                    // Both differences in one packed 16-bit subtract on the entry's (row | col << 16) word, their
-                    // squares summed by one dot product (no wrap: circle_exact bounds rows, columns and radius).
-                    typedef short i16x2 __attribute__((ext_vector_type(2)));
-                    const i16x2 d = __builtin_bit_cast(i16x2, e.x) - __builtin_bit_cast(i16x2, query_rc);
-                    return __builtin_amdgcn_sdot2(d, d, 0, false) <= rad2;
-                  }
+                // whether the lattice entry e lies inside the search pattern of this query.  Circle on a canvas where the int16
+                // arithmetic of the reference cannot wrap: rows [row - r, row + r] (circle_impl.cpp:25-26,40-47) and
+                // col - w < dcol < col + w with w = int(sqrt(r^2 - h^2) + 1) (:51-56) is |dc| <= isqrt(r^2 - h^2), i.e. the integer
+                // test dc^2 + h^2 <= r^2 (which also implies |h| <= r): no width table, no row compare.  Both differences in one
+                // packed 16-bit subtract on the entry's (row | col << 16) word, their squares summed by one dot product.
+                auto accepts_circle = [&](const uint2 e) -> bool {
+                  typedef short i16x2 __attribute__((ext_vector_type(2)));
+                  const i16x2 d = __builtin_bit_cast(i16x2, e.x) - __builtin_bit_cast(i16x2, query_rc);
+                  return __builtin_amdgcn_sdot2(d, d, 0, false) <= rad2;
+                };
+                auto accepts_any = [&](const uint2 e) -> bool {
                   const int drow = (int) (int16_t) (e.x & 0xffffu);
                   const int dcol = (int) (int16_t) (e.x >> 16);
                   if (drow < rmin || drow >= rmax) {
@@ -1273,6 +1278,25 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                     return dcol > col - width && dcol < col + width;
                   }
                 };
+                // the lattice scan: two entries per trip (the entry behind the last one of a segment is read but not used)
+                auto scan = [&](auto accepts, auto visit) {
+                  for (int cy = r0 >> g.cell_sy; cy <= (r1 >> g.cell_sy); ++cy) {
+                    const int seg0 = cellstart[cy * g.cell_ncx + cx0];
+                    const int seg1 = cellstart[cy * g.cell_ncx + cx1 + 1];
+                    for (int pos = seg0; pos < seg1; pos += 2) {
+                      const uint2 ea = db[pos], eb = db[pos + 1];
+                      const bool in_a = accepts(ea);
+                      const bool in_b = (pos + 1 < seg1) & accepts(eb);
+                      if (in_a) {
+                        visit(ea.y);
+                      }
+                      if (in_b) {
+                        visit(eb.y);
+                      }
+                    }
+                  }
+                };
+                const bool lean_circle = stype == PRS_SEARCH_CIRCLE && circle_exact;
                 auto score = [&](const uint32_t ey) {  // ey: fixed index | canonical lattice position << 16
                   const int fi     = (int) (ey & 0xffffu);
                   const uint32_t d = (uint32_t) hamming_regs(fdesc[2 * fi], fdesc[2 * fi + 1], q0, q1);
@@ -1295,20 +1319,10 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                       kept = (kept << 16) | (ey >> 16);
                     }
                   };
-                  for (int cy = r0 >> g.cell_sy; cy <= (r1 >> g.cell_sy); ++cy) {
-                    const int seg0 = cellstart[cy * g.cell_ncx + cx0];
-                    const int seg1 = cellstart[cy * g.cell_ncx + cx1 + 1];
-                    for (int pos = seg0; pos < seg1; pos += 2) {
-                      const uint2 ea = db[pos], eb = db[pos + 1];
-                      const bool in_a = accepts(ea);
-                      const bool in_b = pos + 1 < seg1 && accepts(eb);
-                      if (in_a) {
-                        prescore(ea.y);
-                      }
-                      if (in_b) {
-                        prescore(eb.y);
-                      }
-                    }
+                  if (lean_circle) {
+                    scan(accepts_circle, prescore);
+                  } else {
+                    scan(accepts_any, prescore);
                   }
                   if ((kept & 0xffffu) != 0xffffu) {
                     score((uint32_t) inv[kept & 0xffffu] | (kept << 16));
@@ -1316,23 +1330,10 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                   if ((kept >> 16) != 0xffffu) {
                     score((uint32_t) inv[kept >> 16] | (kept & 0xffff0000u));
                   }
+                } else if (lean_circle) {
+                  scan(accepts_circle, score);
                 } else {
-                  for (int cy = r0 >> g.cell_sy; cy <= (r1 >> g.cell_sy); ++cy) {
-                    const int seg0 = cellstart[cy * g.cell_ncx + cx0];
-                    const int seg1 = cellstart[cy * g.cell_ncx + cx1 + 1];
-                    // two lattice entries per trip (the entry behind the last one of the segment is read but not used)
-                    for (int pos = seg0; pos < seg1; pos += 2) {
-                      const uint2 ea = db[pos], eb = db[pos + 1];
-                      const bool in_a = accepts(ea);
-                      const bool in_b = pos + 1 < seg1 && accepts(eb);
-                      if (in_a) {
-                        score(ea.y);
-                      }
-                      if (in_b) {
-                        score(eb.y);
-                      }
-                    }
-                  }
+                  scan(accepts_any, score);
                 }
               }
               if (bestk != kNoneU32) {  // circle_impl.cpp:78-92 / kdtree_impl.cpp:72-78 (best only)
@@ -1719,15 +1720,9 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
     if (g.stamps) {
       unsigned long long* st = g.stamps + (size_t) frame * 16;
       st[0] = 0;
-      st[1] = acc_finder;
-      st[2] = acc_finder + acc_lin;
-      st[3] = acc_finder + acc_lin + acc_sum;
-      st[4] = acc_finder + acc_lin + acc_sum + acc_solve;
-      st[5] = st[4] + acc_db;
-      st[6] = st[5] + acc_search;
-      st[7] = st[6] + acc_pass2;
-      st[8] = st[7] + acc_filter;
-      st[9] = st[8] + acc_commit;
+      for (int i = 0; i < 9; ++i) {  // cumulative: finder, + linearise, + sums, + solve, + lattice, + search, + staging, + filter, + commit
+        st[i + 1] = st[i] + sh.stamp_acc[i];
+      }
     }
   }
 }
