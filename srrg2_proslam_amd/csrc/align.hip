@@ -1284,7 +1284,10 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                     const int seg0 = cellstart[cy * g.cell_ncx + cx0];
                     const int seg1 = cellstart[cy * g.cell_ncx + cx1 + 1];
                     for (int pos = seg0; pos < seg1; pos += 2) {
-                      const uint2 ea = db[pos], eb = db[pos + 1];
+                      // (whole entries at once: the fixed index of an accepted entry must not be a second, dependent LDS read)
+                      const unsigned long long wa = reinterpret_cast<const unsigned long long*>(db)[pos];
+                      const unsigned long long wb = reinterpret_cast<const unsigned long long*>(db)[pos + 1];
+                      const uint2 ea = make_uint2((uint32_t) wa, (uint32_t) (wa >> 32)), eb = make_uint2((uint32_t) wb, (uint32_t) (wb >> 32));
                       const bool in_a = accepts(ea);
                       const bool in_b = (pos + 1 < seg1) & accepts(eb);
                       if (in_a) {
