@@ -134,6 +134,13 @@ __device__ __forceinline__ int hamming_regs(const au32x4& a0, const au32x4& a1, 
   return (int) d;
 }
 
+// An opaque copy of a thread index for code that runs once per launch (or never): addresses and masks derived from it cannot be
+// hoisted to the top of the kernel, where they would sit in registers -- spilled ones -- across the whole search loop.
+__device__ __forceinline__ int cold_copy(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 __device__ __forceinline__ int hamming_half(const au32x4& a0, const au32x4& b0) {
   uint32_t d = (uint32_t) __popc(a0.x ^ b0.x);
   d = popc_acc(a0.y ^ b0.y, d);
@@ -509,6 +516,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
   const int tid   = threadIdx.x;
   const int lane  = tid & 63;
   const int wave  = tid >> 6;
+  const int tid_hot = tid;  // (cold blocks shadow tid / lane / wave with cold_copy(tid_hot))
   const int frame = blockIdx.x;
 
   int nF = g.b.n_fixed[frame];
@@ -777,6 +785,9 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
           db_built = true;
         }
         if (!db_built && !lattice) {
+          const int tid = cold_copy(tid_hot), lane = tid & 63, wave = tid >> 6;
+          (void) lane;
+          (void) wave;
           // _initializeDatabase of the KD-tree finder (kdtree_impl.cpp:8-26), level by level: the open clusters of a level get
           // their exact coordinate sums (LDS 64-bit atomics), one lane per cluster decides leaf / split, every point moves to
           // its child.  Node and leaf numbers depend on the scheduling, the tree does not.
@@ -989,6 +1000,9 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
           }
         }
         if (!db_built) {
+          const int tid = cold_copy(tid_hot), lane = tid & 63, wave = tid >> 6;
+          (void) lane;
+          (void) wave;
           // _initializeDatabase (square_impl.cpp:8-31).  The reference scans a row-sorted vector; its
           // scan position only matters for tie-breaks ("first wins"), so every fixed point gets its
           // CANONICAL position (stable row sort, ascending index inside a row) and the lattice itself
@@ -1126,24 +1140,27 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
         SUB_ACC(acc_db);
         // -- projection + candidate search (:165-166, :192-200)
         const int rad = (int) sh.radius;
-        for (int i = tid; i < nF; i += T) {
-          bestkey[i] = kNoneU32;
-          second[i]  = kNoneU32;
-        }
-        for (int i = tid; i < 2 * nF; i += T) {
-          fdesc[i] = gfd[i];  // coalesced 16 B/lane; the rows are re-read ~10x per query from LDS
-        }
-        if (!lattice) {
+        {
+          const int tid = cold_copy(tid_hot);
           for (int i = tid; i < nF; i += T) {
-            const float4 c = gfix[i];
-            fuv[i]         = make_float2(c.x, c.y);
+            bestkey[i] = kNoneU32;
+            second[i]  = kNoneU32;
           }
-        }
-        if (stype == PRS_SEARCH_CIRCLE) {
-          // width = int(sqrt(r^2 - h^2) + 1) per row offset h (circle_impl.cpp:51-53), exact in integers
-          for (int i = tid; i < 2 * rad + 1 && i < g.lut_cap; i += T) {
-            const int h = i - rad;
-            lut[i]      = (uint16_t) (isqrt_exact(rad * rad - h * h) + 1);
+          for (int i = tid; i < 2 * nF; i += T) {
+            fdesc[i] = gfd[i];  // coalesced 16 B/lane; the rows are re-read ~10x per query from LDS
+          }
+          if (!lattice) {
+            for (int i = tid; i < nF; i += T) {
+              const float4 c = gfix[i];
+              fuv[i]         = make_float2(c.x, c.y);
+            }
+          }
+          if (stype == PRS_SEARCH_CIRCLE) {
+            // width = int(sqrt(r^2 - h^2) + 1) per row offset h (circle_impl.cpp:51-53), exact in integers
+            for (int i = tid; i < 2 * rad + 1 && i < g.lut_cap; i += T) {
+              const int h = i - rad;
+              lut[i]      = (uint16_t) (isqrt_exact(rad * rad - h * h) + 1);
+            }
           }
         }
         __syncthreads();
@@ -1459,7 +1476,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
         }
         SUB_ACC(acc_filter);
         // -- commit: correspondences->swap(filtered) (:268) + per-correspondence operands for the factor
-        for (int f = tid; f < nF; f += T) {
+        for (int f = cold_copy(tid_hot); f < nF; f += T) {
           const uint32_t slot = second[f];
           if (slot != kNoneU32) {
             const uint32_t bk = bestkey[f];
