@@ -17,5 +17,5 @@ cd $R
 timeout 900 python tools/bench_tracking.py --batch 256 --frames 240 --check 2 > $OUT/closed_loop_kitti00_240frames.json 2> $OUT/cl240.err
 timeout 900 python tools/bench_tracking.py --batch 4096 --frames 60 --check 1 > $OUT/closed_loop_kitti00_4096x60.json 2> $OUT/cl4096.err
 timeout 2400 python tools/bench_tracking.py --batch 64 --frames 4541 --keypoints 1000 --check 2 > $OUT/closed_loop_kitti00_full_4541frames.json 2> $OUT/clfull.err
-tail -2 $OUT/*.err
+tail -n 2 $OUT/cl240.err $OUT/cl4096.err $OUT/clfull.err
 cat $OUT/fuzz_sweeps.txt
