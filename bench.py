@@ -508,8 +508,8 @@ def main():
         "ms_per_step": ms_search, "ms_by_round": kt["search_ms_by_round"], "launches_with_work_per_step": searches,
         "algorithmic_bytes_per_frame_and_launch": bytes_search, "frames_per_launch": B,
         "traffic_over_algorithmic": (evidence["search"] / (B * bytes_search * searches)) if evidence and searches > 0 else None,
-        "note": "not bandwidth-bound: vector ALU ~57 %, LDS pipe ~50 %, scalar unit ~43 % busy behind each other's latency at three 512-thread workgroups per CU "
-                "(profiles/r03/align_pmc.txt); frac prices the algorithmic bytes",
+        "note": "not bandwidth-bound: vector ALU ~60 % and LDS pipe ~50 % busy at three 512-thread workgroups per CU, HBM traffic at the inputs "
+                "(profiles/r03/align_pmc.txt, rocprof_summary.json); frac prices the algorithmic bytes",
     }
     roof_gn = {
         "kernel": "gn_kernel<SLOTS, stereo> (reprojection-error Gauss-Newton rounds: factor linearisation, fixed-shape H / b reduction, "
