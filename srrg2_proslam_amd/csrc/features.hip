@@ -345,18 +345,26 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
     const uint32_t Cm = resp32[wi];
     uint32_t out = Cm;
     if (nms) {
-      const uint32_t Ct = resp32[wi - kTileWords], Cb = resp32[wi + kTileWords];
-      const uint32_t Lt = __builtin_amdgcn_alignbyte(Ct, resp32[wi - kTileWords - 1], 3), Rt = __builtin_amdgcn_alignbyte(resp32[wi - kTileWords + 1], Ct, 1);
-      const uint32_t Lm = __builtin_amdgcn_alignbyte(Cm, resp32[wi - 1], 3), Rm = __builtin_amdgcn_alignbyte(resp32[wi + 1], Cm, 1);
-      const uint32_t Lb = __builtin_amdgcn_alignbyte(Cb, resp32[wi + kTileWords - 1], 3), Rb = __builtin_amdgcn_alignbyte(resp32[wi + kTileWords + 1], Cb, 1);
+      // per row: the even pixels (0, 2) and the odd ones (1, 3) as 16-bit lanes, plus the left neighbours of the even pixels
+      // (previous word's pixel 3, pixel 1) and the right neighbours of the odd ones (pixel 2, next word's pixel 0): one v_and and
+      // three v_perm per row instead of two byte alignments and six unpacks; the right neighbours of the even pixels are the odd
+      // lanes themselves, the left neighbours of the odd pixels the even lanes
+      auto row_lanes = [&](const int w, uint32_t& E, uint32_t& O, uint32_t& OL, uint32_t& ER) {
+        const uint32_t W = resp32[w], Pw = resp32[w - 1], Nw = resp32[w + 1];
+        E  = bytes_even(W);
+        O  = bytes_odd(W);
+        OL = __builtin_amdgcn_perm(Pw, W, 0x0c010c07u);  // (Pw.b3, W.b1)
+        ER = __builtin_amdgcn_perm(Nw, W, 0x0c040c02u);  // (W.b2, Nw.b0)
+      };
+      uint32_t Et, Ot, OLt, ERt, Em, Om, OLm, ERm, Eb, Ob, OLb, ERb;
+      row_lanes(wi - kTileWords, Et, Ot, OLt, ERt);
+      row_lanes(wi, Em, Om, OLm, ERm);
+      row_lanes(wi + kTileWords, Eb, Ob, OLb, ERb);
+      const uint32_t around_even = pk_max(pk_max(pk_max(OLt, Et), pk_max(Ot, OLm)), pk_max(pk_max(Om, OLb), pk_max(Eb, Ob)));
+      const uint32_t around_odd  = pk_max(pk_max(pk_max(Et, Ot), pk_max(ERt, Em)), pk_max(pk_max(ERm, Eb), pk_max(Ob, ERb)));
       uint32_t kept[2];
-#pragma unroll
-      for (int par = 0; par < 2; ++par) {
-        auto lanes = [&](uint32_t x) { return par ? bytes_odd(x) : bytes_even(x); };
-        const uint32_t around = pk_max(pk_max(pk_max(lanes(Lt), lanes(Ct)), pk_max(lanes(Rt), lanes(Lm))), pk_max(pk_max(lanes(Rm), lanes(Lb)), pk_max(lanes(Cb), lanes(Rb))));
-        const uint32_t s = lanes(Cm);
-        kept[par]        = s & pk_sign_fill(pk_sub(around, s));  // lane survives <=> largest neighbour < s
-      }
+      kept[0] = Em & pk_sign_fill(pk_sub(around_even, Em));  // lane survives <=> largest neighbour < s
+      kept[1] = Om & pk_sign_fill(pk_sub(around_odd, Om));
       out = kept[0] | (kept[1] << 8);
     }
     if (!BORDER) {
