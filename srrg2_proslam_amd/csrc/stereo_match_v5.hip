@@ -13,7 +13,8 @@
 //     backwards sweep over the <= 4 candidates); the serial cursor chain (one lane per row, 6 of 16
 //     waves) then needs one 4-byte read, one shift and one 2-byte write per left keypoint;
 //   * the right coordinates the epilogue needs are staged in LDS next to the descriptor rows.
-// Rows holding a window of more than four candidates are replayed by a second, rarely entered sweep that
+// A window of more than four candidates is scored into a pool of 16-bit entries (LDS left over by the layout) and the chain
+// compares those; rows with a window the pool has no room for are replayed by a second, rarely entered sweep that
 // re-scores those windows from global memory.
 #include <type_traits>
 
@@ -31,7 +32,8 @@ struct Args5 {
   int cap;     // padded sorted positions (multiple of 4); entries [cap, cap + 4) of every key array stay sentinels
   int nwords;  // 32-bit words covering cap positions
   uint32_t off_desc_r, off_kp_r, off_sorted_l, off_sorted_r, off_bucket, off_hist, off_rs, off_len, off_rowcnt, off_out, off_bits, off_misc,
-    off_tab;
+    off_tab, off_pool;
+  int pool_cap;  // 16-bit entries of the candidate pool (windows of more than four candidates), 0: none
   int best_lim;       // accept iff best < best_lim ...
   int16_t bmax[258];  // ... and best <= bmax[second] (257 = no second candidate), see fill_accept_table
   unsigned long long* stamps;
@@ -41,6 +43,9 @@ typedef unsigned int q32 __attribute__((ext_vector_type(4)));
 constexpr int kT                = 1024;
 constexpr uint32_t kNone        = 0xffffu;
 constexpr uint32_t kOverflow    = 1u << 31;
+constexpr uint32_t kPooled      = 1u << 30;  // ... and its candidates were scored into the pool: res[p].x = pool offset | candidates << 16
+// pool entry of one candidate: distance (0..256) | kept by the stereo adaptor << 12 | pruned by an earlier pass << 13
+constexpr uint32_t kPoolPruned  = 1u << 13;
 // candidate record of a sorted-left position (written by the scoring phase):
 //   res[p].x  = verdict[0..3], 4 bit each (bits 16..19 stay zero: "cursor beyond the window")
 //   res[p].y  = lo (13 bit: sorted position of the first in-window candidate) | more-than-four-candidates << 31
@@ -219,6 +224,7 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
   uint32_t* bitsR   = bitsL + nwords;                                       // right sorted position matched
   int* misc         = reinterpret_cast<int*>(smem + a.off_misc);            // [0] error, [1] pass matches, [2] pass kept
   int16_t* tab      = reinterpret_cast<int16_t*>(smem + a.off_tab);         // Lowe acceptance table
+  uint16_t* pool    = reinterpret_cast<uint16_t*>(smem + a.off_pool);       // scored candidates of the windows with more than four
 
   // persistent: grid = CUs, frames strided over the workgroups; the next frame's coordinates are
   // requested while this frame is scored, its descriptor rows when it starts (see stereo_match.hip)
@@ -295,8 +301,8 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
     for (int i = tid; i < 2 * nwords; i += kT) {
       bitsL[i] = 0;  // bitsL | bitsR
     }
-    if (tid < 4) {
-      misc[tid] = 0;
+    if (tid < 8) {
+      misc[tid] = 0;  // [4]: entries of the candidate pool in use
     }
     __syncthreads();
     PRS5_STAMP(1);
@@ -478,8 +484,33 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
           const int lo = rs + n_lo;
           const int n  = n_hi - n_lo;
           if (n > 4) {
+            // more than four candidates: their distances (and keep bits) go to the pool, so that the chain only compares;
+            // a window the pool has no room for is scored by the chain's second sweep from global memory
             r  = make_uint2(0u, (uint32_t) lo | kOverflow);
             d4 = keyL[k];
+            int poff = -1;
+            if (a.pool_cap > 0) {
+              const int got = atomicAdd(&misc[4], n);
+              poff          = got + n <= a.pool_cap ? got : -1;
+            }
+            if (poff >= 0) {
+              const q32 d0 = dL[2 * k], d1 = dL[2 * k + 1];
+              for (int j = 0; j < n; ++j) {
+                const int q    = lo + j;
+                uint32_t entry = kPoolPruned;
+                if (!(multipass && ((bitsR[q >> 5] >> (q & 31)) & 1u))) {
+                  const int idx_r = (int) (sortedR[q] & 0xffffu);
+                  entry           = hamming5(d0, d1, ldR[2 * idx_r], ldR[2 * idx_r + 1]);
+                  if (a.epilogue) {
+                    const prs_kp2 kr = ldKR[idx_r];
+                    const float hd = cL[k].u - kr.u, vd = cL[k].v - kr.v;
+                    entry |= (hd < 0.0f || vd < 0.0f) ? 0u : (1u << 12);
+                  }
+                }
+                pool[poff + j] = (uint16_t) entry;
+              }
+              r = make_uint2((uint32_t) poff | ((uint32_t) n << 16), (uint32_t) lo | kOverflow | kPooled);
+            }
           } else if (n > 0) {
             const q32 d0 = dL[2 * k], d1 = dL[2 * k + 1];
             // kNone: no such candidate, or pruned by an earlier pass (epipolar_impl.cpp:197-205)
@@ -554,7 +585,40 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
         for (int p = ls; p < le; ++p) {
           const uint2 w_next = res[p + 1];
           const int lo       = (int) (w.y & 0x1fffu);
-          if (kRescore && (w.y & kOverflow)) {
+          if (w.y & kPooled) {
+            // more than four in-window candidates, scored into the pool: best / second best from the cursor on
+            const uint32_t poff = w.x & 0xffffu;
+            const int hi        = lo + (int) (w.x >> 16);
+            uint32_t best = kNone, second = kNone, best_q = 0, best_keep = 0;
+            for (int q = c > lo ? c : lo; q < hi; ++q) {
+              const uint32_t e = pool[poff + (uint32_t) (q - lo)];
+              if (e & kPoolPruned) {
+                continue;
+              }
+              const uint32_t d = e & 0x1ffu;
+              if (d < best) {  // epipolar_impl.cpp:158-164
+                second    = best;
+                best      = d;
+                best_q    = (uint32_t) q;
+                best_keep = (e >> 12) & 1u;
+              } else if (d < second) {
+                second = d;
+              }
+            }
+            if (best != kNone && (int) best < best_lim && (int) best <= (int) tab[second == kNone ? 257u : second]) {
+              dist4[p] = (sortedR[best_q] & 0xffffu) | (best << 16);  // (res[p] keeps the pool reference: the row may be replayed)
+              outv[p]  = ((8u | best_keep) << 28) | kOutRescored | (kept << 12) | cnt;
+              ++cnt;
+              kept += best_keep;
+              c = (int) best_q + 1;  // epipolar_impl.cpp:181
+              if (multipass && (kRescore || !(flags & kOverflow))) {
+                atomicOr(&bitsL[p >> 5], 1u << (p & 31));
+                atomicOr(&bitsR[best_q >> 5], 1u << (best_q & 31));
+              }
+            } else {
+              outv[p] = 0;
+            }
+          } else if (kRescore && (w.y & kOverflow)) {
             // more than four in-window candidates: score them here, from the cursor on
             const uint32_t kl = dist4[p];
             const int col_l   = (int) (kl >> 16);
@@ -643,6 +707,9 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
           misc[3] = 0;  // the next pass starts clean (its scoring barrier publishes this)
         }
       }
+      if (tid == 0) {
+        misc[4] = 0;  // the pool is free again (published by the barriers of the emit phase)
+      }
       PRS5_STAMP(7);
 
       // ---- F: emit in sorted-left traversal order (one scan carries matches and kept matches) ---------
@@ -665,8 +732,9 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
           const uint2 rec = res[posL[k]];
           uint32_t idx_r, best;
           if (v & kOutRescored) {
-            idx_r = rec.x & 0xffffu;
-            best  = rec.x >> 16;
+            const uint32_t rx = (rec.y & kPooled) ? dist4[posL[k]] : rec.x;
+            idx_r             = rx & 0xffffu;
+            best              = rx >> 16;
           } else {
             const uint32_t j = (v >> 29) & 3u;
             best             = (dist4[posL[k]] >> (8 * j)) & 255u;
@@ -785,12 +853,17 @@ int stereo_match_v5_launch(prs_context* ctx, const prs_stereo_params* params, co
   a.off_rowcnt   = off; off = up16(off + rows2 * 4u);
   a.off_out      = off; off = up16(off + cap * 4u);
   a.off_bits     = off; off = up16(off + (uint32_t) a.nwords * 2u * 4u);
-  a.off_misc     = off; off = up16(off + 16u);
+  a.off_misc     = off; off = up16(off + 32u);
   a.off_tab      = off; off = up16(off + 258u * 2u);
-  const size_t lds = off;
-  if (lds > 160u * 1024u) {
+  if (off > 160u * 1024u) {
     return 1;
   }
+  // what is left of the 160 KB holds the scored candidates of crowded windows (two bytes each, at most 4096)
+  a.off_pool = off;
+  a.pool_cap = (int) (((160u * 1024u - off) / 2u) & ~3u);
+  a.pool_cap = a.pool_cap > 4096 ? 4096 : (a.pool_cap < 64 ? 0 : a.pool_cap);
+  off        = up16(off + (uint32_t) a.pool_cap * 2u);
+  const size_t lds = off;
   a.p        = *params;
   a.b        = *batch;
   a.epilogue = (batch->fixed_uvuv && batch->fixed_desc && batch->n_fixed && batch->fixed_xyz && batch->triangulator) ? 1 : 0;
