@@ -246,10 +246,13 @@ typedef struct {
   float image_cols, image_rows;           /* factor->setImageDim (:38-39) */
   float baseline_left_in_right_px[3];     /* K * t_left_in_right (:98-104), stereo only */
   float diagonal_info[3];                 /* param_diagonal_info_matrix (:47) */
-  float chi_threshold;                    /* RobustifierSaturated chi_threshold */
-  int32_t enable_inverse_depth_weighting; /* :107-112 */
+  float chi_threshold;                    /* RobustifierSaturated chi_threshold: a factor with chi > threshold is kernelised,
+                                             its Omega scaled by 1 / chi, its chi reported as the threshold (*) */
+  int32_t enable_inverse_depth_weighting; /* :107-112: translation columns of J scaled by min(0.01 + d / mean disparity, 1) (*) */
   float mean_disparity;                   /* bindFixed (:76-89); < 0 = compute it on the device */
-  float damping;                          /* IterationAlgorithmGN damping */
+  float damping;                          /* IterationAlgorithmGN damping: (H + damping diag(H)) dx = -b (*)
+                                             (*) srrg2_solver is not in the reference tree; these three readings are the family under
+                                             which every pose bound of the reference's gtests holds */
   int32_t max_iterations;                 /* MultiAligner3DQR max_iterations */
   int32_t min_num_inliers;
   int32_t min_num_correspondences;
@@ -400,7 +403,7 @@ PRS_API int prs_pcf_linearize(prs_pcf* h,
                               int32_t n_corr,
                               prs_align_result* result);
 
-/* (H + damping I) dx = -b, X <- X * exp(dx) on the device (same arithmetic as the fused loop) */
+/* (H + damping diag(H)) dx = -b, X <- X * exp(dx) on the device (same arithmetic as the fused loop) */
 PRS_API int prs_gn_step(prs_context* ctx, const float* H36, const float* b6, float damping, float* X16);
 
 /* host helper: information scale column from landmark ages

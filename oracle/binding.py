@@ -130,6 +130,12 @@ class AlignResult(C.Structure):
     ]
 
 
+class Variant(C.Structure):
+    """orc_variant: sweep switches for the BUILD-DEFINED arithmetic of rows a13 / a14 (tools/sweep_a13.py); all zero = shipped"""
+    _fields_ = [("kernel_form", C.c_int32), ("idw_form", C.c_int32), ("damping_form", C.c_int32), ("v_row", C.c_int32),
+                ("chi_compare", C.c_int32), ("bounds_form", C.c_int32)]
+
+
 def build(force=False):
     """compile the oracle with its committed Makefile (gcc, seconds)"""
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc")) or f == "Makefile"]
@@ -224,9 +230,18 @@ def lib():
         L.orc_motion_predict.argtypes = [vp, vp, vp]
         L.orc_bruteforce_match.restype = C.c_int
         L.orc_bruteforce_match.argtypes = [vp, C.c_int, vp, C.c_int, C.c_float, C.c_float, vp, C.c_int, i32p]
+        L.orc_set_variant.restype = None
+        L.orc_set_variant.argtypes = [C.POINTER(Variant)]
         _lib = L
         del fp, u8p
     return _lib
+
+
+def set_variant(**kw):
+    """sweep switches (see Variant); no arguments = the shipped definition"""
+    v = Variant(**kw)
+    lib().orc_set_variant(C.byref(v))
+    return v
 
 
 def _ptr(a):

@@ -1250,6 +1250,15 @@ static float orc_sum128_result(const orc_sum128* s) {
   return v[0] + 0.0f;
 }
 
+static orc_variant g_variant; /* sweep switches, all zero by default (proslam_oracle.h) */
+void orc_set_variant(const orc_variant* v) {
+  if (v) {
+    g_variant = *v;
+  } else {
+    memset(&g_variant, 0, sizeof(g_variant));
+  }
+}
+
 void orc_linearize(const orc_aligner_params* P,
                    const float* X,
                    const orc_corr* corr,
@@ -1322,14 +1331,18 @@ void orc_linearize_ex(const orc_aligner_params* P,
     const float iz     = 1.0f / hz;
     const float u_pred = hx * iz;
     const float v_pred = hy * iz;
-    if (u_pred < 0.0f || u_pred > P->image_cols || v_pred < 0.0f || v_pred > P->image_rows) {
+    if (g_variant.bounds_form == 0 && (u_pred < 0.0f || u_pred > P->image_cols || v_pred < 0.0f || v_pred > P->image_rows)) {
+      ++out->num_invalid;
+      continue;
+    }
+    if (g_variant.bounds_form == 2 && (u_pred < 0.0f || u_pred >= P->image_cols || v_pred < 0.0f || v_pred >= P->image_rows)) {
       ++out->num_invalid;
       continue;
     }
 
     float e[3];
     e[0]      = u_pred - z[0];
-    e[1]      = v_pred - z[1];
+    e[1]      = v_pred - (g_variant.v_row == 1 && dim == ORC_FACTOR_STEREO ? 0.5f * (z[1] + z[3]) : z[1]);
     e[2]      = 0.0f;
     float hrx = hx;
     if (dim == ORC_FACTOR_STEREO) {
@@ -1339,15 +1352,24 @@ void orc_linearize_ex(const orc_aligner_params* P,
       e[2] = hz - z[2];
     }
 
-    /* translation weight (inverse depth weighting, BUILD-DEFINED: clamp(d_i / mean, 0.01, 1)) */
-    float wt = 1.0f;
+    /* translation weight ("use normalized disparity as weight for translation contribution in jac: (0.01+d,1)*I",
+     * aligner_slice_processor_projective.cpp:107-112): wt = min(0.01 + d / mean disparity, 1).  The factor itself is external;
+     * this reading is the round-4 result of tools/sweep_a13.py (forms 1.. are the other readings it scored). */
+    float wt = 1.0f, w_omega = 1.0f;
     if (dim == ORC_FACTOR_STEREO && P->enable_inverse_depth_weighting) {
-      wt = (z[0] - z[2]) / P->mean_disparity;
-      if (wt < 0.01f) {
-        wt = 0.01f;
-      }
-      if (wt > 1.0f) {
-        wt = 1.0f;
+      const float dn = (z[0] - z[2]) / P->mean_disparity;
+      switch (g_variant.idw_form) {
+        case 0: /* shipped */
+          wt = 0.01f + dn;
+          wt = wt < 1.0f ? wt : 1.0f; /* NaN (0 / 0) -> 1 */
+          break;
+        case 1: wt = dn < 0.01f ? 0.01f : (dn > 1.0f ? 1.0f : dn); break;
+        case 2: wt = sqrtf(dn < 0.01f ? 0.01f : (dn > 1.0f ? 1.0f : dn)); break;
+        case 3: w_omega = dn < 0.01f ? 0.01f : (dn > 1.0f ? 1.0f : dn); break;
+        case 4: wt = 1.0f / dn; wt = wt < 0.01f ? 0.01f : (wt > 1.0f ? 1.0f : wt); break;
+        case 5: wt = dn < 0.01f ? 0.01f : dn; break;
+        case 6: wt = dn < 0.01f ? 0.01f : (dn > 1.0f ? 1.0f : dn); wt *= wt; break;
+        default: break; /* off */
       }
     }
 
@@ -1390,12 +1412,27 @@ void orc_linearize_ex(const orc_aligner_params* P,
     o[0] = P->diagonal_info[0] * s;
     o[1] = P->diagonal_info[1] * s;
     o[2] = edim == 3 ? P->diagonal_info[2] * s : 0.0f;
+    o[0] *= w_omega;
+    o[1] *= w_omega;
+    o[2] *= w_omega;
 
     /* chi2 + saturated kernel (landmark_estimator_pose_based_smoother_impl.cpp:77-84) */
     float chi = fmaf(o[2] * e[2], e[2], fmaf(o[1] * e[1], e[1], (o[0] * e[0]) * e[0]));
-    if (chi > P->chi_threshold) {
-      /* inlier-only run: a kernelised factor contributes nothing (weights * 0 keeps the +-0 terms in the sums) */
-      const float scale = inlier_only ? 0.0f : P->chi_threshold / chi;
+    if (chi > P->chi_threshold || (g_variant.chi_compare == 1 && chi == P->chi_threshold)) {
+        /* RobustifierSaturated (srrg2_solver, external): the kernelised factor is weighted by 1 / chi -- round-4 result of
+       * tools/sweep_a13.py; forms 1.. are the other readings (1 = the in-repo smoother's tau / chi,
+       * landmark_estimator_pose_based_smoother_impl.cpp:81-84) */
+      float scale = 1.0f / chi;
+      if (g_variant.kernel_form == 1) {
+        scale = P->chi_threshold / chi;
+      } else if (g_variant.kernel_form == 2) {
+        scale = sqrtf(P->chi_threshold / chi);
+      } else if (g_variant.kernel_form == 3) {
+        scale = 0.0f;
+      }
+      if (inlier_only) {
+        scale = 0.0f; /* inlier-only run: a kernelised factor contributes nothing (weights * 0 keeps the +-0 terms in the sums) */
+      }
       o[0] *= scale;
       o[1] *= scale;
       o[2] *= scale;
@@ -1446,7 +1483,8 @@ int orc_gn_step(const orc_linear_system* sys, float damping, float* X) {
   float L[6][6], inv[6];
   memset(L, 0, sizeof(L));
   for (int j = 0; j < 6; ++j) {
-    float s = sys->H[6 * j + j] + damping;
+    /* damping: H_jj <- H_jj + damping * H_jj (round-4 result of tools/sweep_a13.py; form 1 = H_jj + damping) */
+    float s = g_variant.damping_form == 1 ? sys->H[6 * j + j] + damping : fmaf(damping, sys->H[6 * j + j], sys->H[6 * j + j]);
     for (int k = 0; k < j; ++k) {
       s = fmaf(-L[j][k], L[j][k], s);
     }

@@ -231,6 +231,21 @@ void orc_info_scale_from_nopt(const uint32_t* n_opt, int n, float* scale);
 /* mean disparity over ALL fixed points, aligner_slice_processor_projective.cpp:80-88 */
 float orc_mean_disparity(const float* fixed_uvuv, int n);
 
+/* SWEEP SWITCHES -- readings of the BUILD-DEFINED arithmetic of rows a13 / a14 (the srrg2_solver factors, robustifier and
+ * damping are not in the reference tree).  Form 0 of every switch is what the oracle and the device implement: the ONE family
+ * under which every pose bound the reference's gtests assert on its own images holds (tools/sweep_a13.py, table in
+ * profiles/r04/sweep_a13_grid.txt).  Only the sweep sets anything else. */
+typedef struct {
+  int32_t kernel_form;  /* kernelised factor: 0 Omega / chi; 1 Omega * tau / chi; 2 Omega * sqrt(tau / chi); 3 Omega * 0 */
+  int32_t idw_form;     /* translation weight, dn = d / mean disparity: 0 min(0.01 + dn, 1); 1 clamp(dn, 0.01, 1); 2 sqrt of 1;
+                           3 form 1 on Omega instead of J; 4 clamp(1 / dn, 0.01, 1); 5 max(dn, 0.01); 6 square of 1; 7 off */
+  int32_t damping_form; /* 0 H + lambda diag(H); 1 H + lambda I */
+  int32_t v_row;        /* stereo row 1 measurement: 0 vL; 1 (vL + vR) / 2 */
+  int32_t chi_compare;  /* 0 kernel active when chi > tau; 1 when chi >= tau */
+  int32_t bounds_form;  /* 0 prediction must lie in [0, cols] x [0, rows]; 1 no image test; 2 [0, cols) x [0, rows) */
+} orc_variant;
+void orc_set_variant(const orc_variant* v);
+
 /* one linearization: H [36] row-major, b [6] (b = sum J^T Omega e), chi2 sum, counts.
  * fixed [n_f][factor_type], moving [n_m][3], info_scale [n_m]. */
 typedef struct {
@@ -268,7 +283,7 @@ void orc_add_motion_prior(const orc_aligner_params* p, const float* X, const flo
 /* constant-velocity prediction: pose_pred = pose_prev1 * (pose_prev2^-1 * pose_prev1) (MotionModelConstantVelocity3D) */
 void orc_motion_predict(const float* pose_prev2, const float* pose_prev1, float* pose_pred);
 
-/* (H + damping I) dx = -b; X <- X * exp(dx). returns 0 ok, 1 if the system was not SPD (X unchanged) */
+/* (H + damping diag(H)) dx = -b; X <- X * exp(dx). returns 0 ok, 1 if the system was not SPD (X unchanged) */
 int orc_gn_step(const orc_linear_system* sys, float damping, float* X);
 
 /* ---- a14: the per-frame loop MultiAligner3DQR::compute drives (external; restated minimal) ---- */

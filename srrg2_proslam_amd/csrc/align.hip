@@ -229,15 +229,10 @@ __device__ __forceinline__ bool pose_is_finite(const PoseRegs& X) {
 // DIM: the factor type as a compile-time constant (0 = read it from the parameters)
 // inverse-depth weight of a stereo measurement (aligner_slice_processor_projective.cpp:107-112): a function of the measurement and
 // the frame's mean disparity only, so callers that iterate over fixed correspondences evaluate it once (PRE_WT: z.w carries it)
+// "(0.01 + d, 1) * I": wt = min(0.01 + d / mean disparity, 1); NaN (0 / 0) -> 1 (round 4: tools/sweep_a13.py)
 __device__ __forceinline__ float inverse_depth_weight(const float4 z, const float mean_dsp) {
-  float wt = (z.x - z.z) / mean_dsp;
-  if (wt < 0.01f) {
-    wt = 0.01f;
-  }
-  if (wt > 1.0f) {
-    wt = 1.0f;
-  }
-  return wt;
+  const float wt = 0.01f + (z.x - z.z) / mean_dsp;
+  return wt < 1.0f ? wt : 1.0f;
 }
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kPairs = 16;  // the 29 sums + 3 class counts of one linearisation travel as 16 float pairs (32 "slots")
@@ -346,9 +341,10 @@ __device__ __forceinline__ void factor_accumulate(const prs_aligner_params& a, c
   float o1 = a.diagonal_info[1] * s;
   float o2 = dim == PRS_FACTOR_MONO ? 0.0f : a.diagonal_info[2] * s;
   float chi = fmaf(o2 * e2, e2, fmaf(o1 * e1, e1, (o0 * e0) * e0));
-  // saturated kernel: o *= threshold / chi (a factor of exactly 1 leaves the unsaturated weights untouched)
+  // saturated kernel: a kernelised factor is weighted 1 / chi (round 4: tools/sweep_a13.py; a factor of exactly 1 leaves the
+  // unsaturated weights untouched)
   const bool saturated = valid && chi > a.chi_threshold;
-  const float ratio    = inlier_only ? 0.0f : a.chi_threshold / chi;  // inlier-only run: kernelised factors are suppressed
+  const float ratio    = inlier_only ? 0.0f : 1.0f / chi;  // inlier-only run: kernelised factors are suppressed
   const float scale    = saturated ? ratio : 1.0f;
   o0 *= scale;
   o1 *= scale;
@@ -2008,7 +2004,7 @@ __global__ __launch_bounds__(128, 4) void gn_kernel(const AlignArgs g) {
           sh.n_out     = cc / (int) kClsOutUnit;
           sh.n_inv     = nc - sh.n_inl - sh.n_out;
         }
-        // ---- (H + damping I) dx = -b, X <- X * exp(dx) by the lanes of this wave: lane i < 6 owns row i of the system and
+        // ---- (H + damping diag(H)) dx = -b, X <- X * exp(dx) by the lanes of this wave: lane i < 6 owns row i of the system and
         // of the Cholesky factor, lane r < 3 row r of the pose; pivots, substitutions and the perturbation are uniform
         // (every lane evaluates them from broadcast values).  Every element goes through exactly the operations of
         // prs_se3.h's gn_step, in the same order, so the pose is bit-identical to the one-lane evaluation.
@@ -2065,7 +2061,7 @@ __global__ __launch_bounds__(128, 4) void gn_kernel(const AlignArgs g) {
           bool ok = true;
 #pragma unroll
           for (int j = 0; j < 6; ++j) {
-            float v = row == j ? h[j] + g.a.damping : h[j];
+            float v = row == j ? fmaf(g.a.damping, h[j], h[j]) : h[j];  // H + damping diag(H)
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
               if (k < j) {

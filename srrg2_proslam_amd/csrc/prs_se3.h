@@ -143,7 +143,7 @@ __device__ __forceinline__ void tnq2t(const float* v6, float* T) {
   T[15] = 1.0f;
 }
 
-// (H + damping I) dx = -b by dense Cholesky; X <- X * exp(dx).  H: full 6x6 row-major (lower part
+// (H + damping diag(H)) dx = -b by dense Cholesky (the damping form is a round-4 result of tools/sweep_a13.py); X <- X * exp(dx).  H: full 6x6 row-major (lower part
 // read), returns false (X untouched) when the system is not positive definite.
 __device__ __forceinline__ bool gn_step(const float* H, const float* b, float damping, float* X) {
   // dense Cholesky with fused multiply-subtracts and one reciprocal per pivot
@@ -151,7 +151,7 @@ __device__ __forceinline__ bool gn_step(const float* H, const float* b, float da
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    float s = H[6 * j + j] + damping;
+    float s = fmaf(damping, H[6 * j + j], H[6 * j + j]);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       if (k < j) {

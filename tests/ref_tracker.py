@@ -4,7 +4,8 @@ projective finder + aligner) -> merger, on the reference's own KITTI / ICL image
 `Tracker` is written against a small stage interface (`stages`) so that the CPU checker (tests/test_ref_tracker.py) and the
 HIP path (tests/test_ref_tracker_gpu.py) run the same loop; the scenarios and the bounds the reference asserts live here.
 robotInLocalMap of frame k = prediction * X^-1, X = local map in sensor as estimated by the aligner
-(multi_tracker: the measurement is the fixed cloud, the clipped local map the moving one)."""
+(multi_tracker: the measurement is the fixed cloud, the clipped local map the moving one).  The prediction is the constant-velocity
+one of the aligner's motion-model slice (kitti.conf:257-260,747-772; `use_prediction`, default since round 4: tools/sweep_a13.py)."""
 import numpy as np
 
 import ref_pins as rp
@@ -77,7 +78,7 @@ class Tracker:
          new_map(cfg, merger, capacity) -> map;  merge(map, pose, fixed, fixed_desc, corr, scene_indices) -> (n_merged, n_added)
          map_size(map), predict(prev, pose) -> pose, compose(guess, X) -> guess * X^-1, reset()"""
 
-    def __init__(self, stages, cfg, merger, capacity=4096, use_prediction=False, prior_info=0.0):
+    def __init__(self, stages, cfg, merger, capacity=4096, use_prediction=True, prior_info=0.0):
         self.s, self.cfg, self.prior_info, self.use_prediction = stages, cfg, prior_info, use_prediction
         stages.reset()  # a new tracker: new finder state
         self.map = stages.new_map(cfg, merger, capacity)
@@ -90,9 +91,16 @@ class Tracker:
         entry = dict(n_measured=len(fixed))
         corr, idx = None, None
         if self.frames > 0:
-            guess = s.predict(self.prev, self.pose) if self.use_prediction else self.pose
+            if self.use_prediction == "estimate":
+                # the scene is clipped at the last pose and the aligner's estimate starts at (last pose)^-1 * prediction, inverted
+                guess = self.pose
+                pred = s.predict(self.prev, self.pose)
+                X0 = np.linalg.inv(np.linalg.inv(np.asarray(self.pose, np.float64)) @ np.asarray(pred, np.float64)).astype(np.float32)
+            else:
+                guess = s.predict(self.prev, self.pose) if self.use_prediction else self.pose
+                X0 = I4
             xyzw, cdesc, idx = s.clip(self.cfg, guess, self.map)
-            X, corr, status, inliers = s.align(self.cfg, fixed, desc, xyzw, cdesc, I4, self.prior_info)
+            X, corr, status, inliers = s.align(self.cfg, fixed, desc, xyzw, cdesc, X0, self.prior_info)
             self.prev = self.pose
             self.pose = s.compose(guess, X)
             entry.update(status=status, inliers=inliers, n_corr=len(corr), n_clipped=len(xyzw))

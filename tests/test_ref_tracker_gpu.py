@@ -151,11 +151,11 @@ def test_same_frame_three_times(S, B, oracle, dataset):
 @pytest.mark.parametrize("no_merges", [True, False])
 @pytest.mark.parametrize("motion_model", [False, True])
 def test_kitti_00_to_04(S, B, oracle, no_merges, motion_model):
-    kw = dict(use_prediction=True, prior_info=1.0) if motion_model else {}
+    kw = dict(use_prediction=True, prior_info=1.0) if motion_model else dict(use_prediction=False)
     log, error = rt.kitti_00_to_04(S, B, no_merges, **kw)
     assert all(e["status"] == SUCCESS for e in log[1:])
-    bound = (0.25, 0.2, 0.7) if no_merges else (0.2, 0.2, 0.7)  # see tests/test_ref_tracker.py
-    assert np.all(np.abs(error[:3]) < bound) and np.all(np.abs(error[3:]) < 0.01), error
+    from test_ref_tracker import REFERENCE_BOUND
+    assert np.all(np.abs(error[:3]) < REFERENCE_BOUND) and np.all(np.abs(error[3:]) < 0.01), error
     ref, _ = rt.kitti_00_to_04(OracleStages(), OracleBackend(), no_merges, **kw)
     _same_as_checker(log, ref)
 
@@ -163,10 +163,10 @@ def test_kitti_00_to_04(S, B, oracle, no_merges, motion_model):
 @pytest.mark.parametrize("kind", ["ekf", "smoother", "bruteforce_ekf"])
 def test_kitti_00_to_04_other_mergers(S, B, oracle, kind):
     """tests/test_trackers.cpp:473-576, :578-682, :684-783 on the HIP path (bounds: tests/test_ref_tracker.py), frame by frame equal to the CPU checker"""
-    from test_ref_tracker import OTHER_MERGER_BOUNDS
+    from test_ref_tracker import REFERENCE_BOUND
     log, error = rt.kitti_00_to_04(S, B, False, kind)
     assert all(e["status"] == SUCCESS for e in log[1:])
-    assert np.all(np.abs(error[:3]) < OTHER_MERGER_BOUNDS[kind]) and np.all(np.abs(error[3:]) < 0.01), error
+    assert np.all(np.abs(error[:3]) < REFERENCE_BOUND) and np.all(np.abs(error[3:]) < 0.01), error
     ref, _ = rt.kitti_00_to_04(OracleStages(), OracleBackend(), False, kind)
     _same_as_checker(log, ref)
 
