@@ -10,6 +10,7 @@ All inputs are resident in HBM before the timed region.  Sequences are independe
 shard them with no data-path collective (weak scaling: per-GPU work is fixed).
 
     python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus N ...                     (no launcher: starts N ranks itself, one per device, RCCL rendezvous on 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line (contract in the task statement).  Besides the contract's fields:
@@ -75,6 +76,9 @@ def parse():
                     help="worker processes of the all-core CPU figure (one independent sequence per core, SURVEY 8d); "
                          "-1 = min(host cores, 256), 0 = skip")
     ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)  # internal: frames to time in a CPU-only child
+    ap.add_argument("--dry-run", action="store_true",
+                    help="control-flow check without a device (CPU tests of the N > 1 path): ranks rendezvous over gloo, a step is a fixed sleep, "
+                         "the line carries value 0 and data 'dry-run'")
     return ap.parse_args()
 
 
@@ -398,9 +402,13 @@ def closed_loop(args):
     sharding.init_distributed("gloo" if shared else "nccl", dev)
     red_dev = "cpu" if shared else torch.device("cuda", dev)
     batch = min(args.batch, 1024)
+    parity = []
 
     def run_sequence(s, n_frames):
-        o = bench_tracking.run(batch=batch, frames=n_frames, keypoints=min(args.keypoints, 1000), check=0, device=dev, seed_offset=1000 * s)
+        # the first sequence of every rank is replayed on the CPU checker (pose of every frame bit for bit), the others run unchecked
+        check = 1 if not parity and not args.no_cpu_baseline else 0
+        o = bench_tracking.run(batch=batch, frames=n_frames, keypoints=args.keypoints, check=check, device=dev, seed_offset=1000 * s)
+        parity.append({"sequence": s, "checked": bool(check), "parity_vs_oracle_chain": o.get("parity_vs_oracle_chain") if check else "not checked"})
         n = o["config"]["tracked_frames_timed"] * batch
         return n, n / o["value"]
 
@@ -410,11 +418,76 @@ def closed_loop(args):
     if rank == 0:
         out = {"metric": "tracked frames/sec on KITTI-00 stereo (1241x376, ~2k kp); SE(3) vs ref", "value": fps, "unit": "frames/s", "n_gpus": world,
                "ms_per_step": None,
-               "config": {"workload": "closed loop, KITTI sequences 00-07 (%s frames x %.3f) sharded over %d ranks longest-first, %d replicas per sequence; "
-                                      "trajectories follow KITTI 00 (the only ground truth shipped besides 01)" % (list(KITTI_SEQUENCE_FRAMES), args.frames_scale, world, batch),
-                          "sequences_of_rank_0": mine, "rank_0_parts": parts, "slowest_rank_seconds": slowest}}
+               "config": {"workload": "closed loop (BASELINE.json config 5), %d keypoints per image, KITTI sequences 00-07 (%s frames, the first %.1f %% of each: "
+                                      "%s frames) sharded over %d ranks longest-first, %d replicas per sequence; trajectories follow KITTI 00 (the only "
+                                      "ground truth shipped besides 01)" % (args.keypoints, list(KITTI_SEQUENCE_FRAMES), 100.0 * args.frames_scale,
+                                                                           [max(int(round(n * args.frames_scale)), 4) for n in KITTI_SEQUENCE_FRAMES], world, batch),
+                          "keypoints_per_image": args.keypoints, "frames_scale": args.frames_scale, "replicas_per_sequence": batch,
+                          "sequences_of_rank_0": mine, "rank_0_parts": parts, "slowest_rank_seconds": slowest, "parity_of_rank_0": parity},
+               "ranks": {"backend": "gloo (PRS_BENCH_SHARE_GPU=1: all ranks on device 0)" if shared else "nccl (RCCL)",
+                         "backend_world_size": sharding.backend_world_size()}}
         out.update(extra)
         print(json.dumps(out))
+    sharding.shutdown()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: this process (which makes no GPU call: device_count() does not initialise the
+    runtime) starts N fresh children of itself, one per device, with the environment torch.distributed.run would give them, waits,
+    and exits with the worst child's code.  Rank 0 prints the line.  Fewer visible devices than N is an error, never a 1-GPU run."""
+    import socket
+    import subprocess
+    n = args.gpus
+    shared = os.environ.get("PRS_BENCH_SHARE_GPU", "0") == "1"
+    if not (shared or args.dry_run):
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit("bench.py --gpus %d: only %d device(s) visible (PRS_BENCH_SHARE_GPU=1 puts all ranks on device 0)" % (n, have))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "PRS_BENCH_SPAWNED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = []
+    for pr in procs:
+        try:
+            codes.append(pr.wait(timeout=3600))
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            codes.append(124)
+    if any(codes):
+        raise SystemExit("bench.py --gpus %d: rank exit codes %s" % (n, codes))
+
+
+def dry_run(args):
+    """the N-rank control flow of main() (rendezvous, barriers, SUM / MAX over ranks, rank-0 line) with a sleep as the step"""
+    from srrg2_proslam_amd import sharding
+    rank, world, _ = sharding.rank_world()
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    sharding.init_distributed("gloo")
+    sharding.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (1 + rank))
+    sharding.barrier()
+    local = time.perf_counter() - t0
+    fps, elapsed = sharding.aggregate_throughput(args.batch * args.steps, local)
+    per_rank = sharding.gather_over_ranks(args.batch * args.steps / local)
+    if rank == 0:
+        print(json.dumps({"metric": "tracked frames/sec on KITTI-00 stereo (1241x376, ~2k kp); SE(3) vs ref", "value": 0.0, "unit": "frames/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry-run (no device work: control flow of the N-rank path only)",
+                          "config": {"workload": "dry run", "frames_per_step_per_gpu": args.batch},
+                          "ranks": {"backend": "gloo", "backend_world_size": sharding.backend_world_size(), "fps_per_rank": per_rank,
+                                    "stand_in_fps": fps}}))
     sharding.shutdown()
 
 
@@ -422,6 +495,12 @@ def main():
     args = parse()
     if args.cpu_worker > 0:
         cpu_worker(args)
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
+        return
+    if args.dry_run:
+        dry_run(args)
         return
     if args.mode == "closed-loop":
         closed_loop(args)
@@ -464,6 +543,7 @@ def main():
         barrier()
         elapsed_local = time.perf_counter() - t0
         fps, elapsed = sharding.aggregate_throughput(B * args.steps, elapsed_local, red_dev)
+        fps_per_rank = sharding.gather_over_ranks(B * args.steps / elapsed_local, red_dev)
         snap = w.snapshot()  # results of the timed configuration
         status_ok, it_exec = w.check(snap)
         kt = w.kernel_times(max(args.timing_steps, 1))  # per-kernel times: a separate pass, outside the timed region
@@ -566,6 +646,10 @@ def main():
         "kernel_time_share": {"stereo_match5_kernel": ms_match / total_k, "align_kernel (search)": ms_search / total_k, "gn_kernel": ms_gn / total_k},
         "kernel_timing": "HIP events on the launch stream in a separate pass of %d steps after the timed loop (the timed loop carries no events)" % max(args.timing_steps, 1),
     }
+    if world > 1:
+        out["ranks"] = {"backend": "gloo (PRS_BENCH_SHARE_GPU=1: all ranks on device 0)" if shared else "nccl (RCCL)",
+                        "backend_world_size": sharding.backend_world_size(), "fps_per_rank": fps_per_rank,
+                        "launcher": "bench.py itself" if os.environ.get("PRS_BENCH_SPAWNED") == "1" else "external (torch.distributed.run)"}
     if steady:
         out["steady_state"] = steady
 

@@ -84,6 +84,25 @@ def sum_over_ranks(value, device=None):
     return _reduce(value, dist.ReduceOp.SUM, device)
 
 
+def gather_over_ranks(value, device=None):
+    """[value of rank 0, value of rank 1, ...] on every rank (a one-element list when not distributed)"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    world = dist.get_world_size()
+    t = torch.zeros((world,), dtype=torch.float64, device=device)
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]
+
+
+def backend_world_size():
+    """the world size the initialised backend reports (1 when not distributed)"""
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
 def aggregate_throughput(units_this_rank, elapsed_this_rank, device=None):
     """whole-job throughput of the bench contract: units of ALL ranks / time of the SLOWEST rank -> (units/s, seconds)"""
     total = sum_over_ranks(units_this_rank, device)

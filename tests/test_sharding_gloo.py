@@ -123,3 +123,34 @@ def test_uneven_sequences_are_balanced():
         assert max(loads) <= max(max(lengths), -(-sum(lengths) // world) + max(lengths) // 2)
     two = [sum(lengths[s] for s in sharding.balanced_sequences_of_rank(lengths, r, 2)) for r in range(2)]
     assert abs(two[0] - two[1]) <= 300
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher: the parent starts two ranks of itself (gloo rendezvous on 127.0.0.1), rank 0 prints
+    ONE line with n_gpus 2, the world size the backend reported and one rate per rank.  --dry-run replaces the device step by a sleep
+    (no GPU here); the spawn, rendezvous, barrier and SUM / MAX code is the one the GPU run takes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--batch", "32", "--dry-run"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks"]["backend_world_size"] == 2 and len(line["ranks"]["fps_per_rank"]) == 2
+    assert line["value"] == 0.0 and line["data"].startswith("dry-run")  # never mistaken for a measurement
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """no silent 1-GPU run: --gpus 2 with fewer than two visible devices (none here) exits non-zero before any rank starts"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PRS_BENCH_SHARE_GPU")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "device(s) visible" in (out.stderr + out.stdout)
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
