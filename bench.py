@@ -59,7 +59,11 @@ def parse():
     ap.add_argument("--keypoints", type=int, default=2000, help="keypoints per image (KITTI config: ~2000)")
     ap.add_argument("--moving", type=int, default=2000, help="local-map points per frame")
     ap.add_argument("--max-fixed", type=int, default=896, help="LDS sizing bound on stereo matches per frame")
-    ap.add_argument("--unique", type=int, default=256, help="distinct synthetic frames generated on the host and tiled over the batch")
+    ap.add_argument("--unique", type=int, default=251,
+                    help="distinct synthetic frames generated on the host and tiled over the batch (frame b = unique frame b mod this).  A prime: "
+                         "workgroup b runs on XCD b mod 8 and with eight resident frames per CU, so a count that shares a factor with 8 or 256 "
+                         "pins every unique frame to one XCD / CU slot (measured in round 4 with 8 unique frames: the frames that need a fifth "
+                         "search round all sat on three XCDs, the other five idled, the GN time of the leg doubled)")
     ap.add_argument("--cpu-frames", type=int, default=1024, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-steady-state", action="store_true", help="skip the steady-state leg (profiles of the headline workload alone)")
@@ -346,7 +350,7 @@ class FrameWorkload:
 def small_config_leg(name, cfg, keypoints, moving, max_fixed, batch, device_index, seed, steps=3):
     """one of the other BASELINE configurations: a few steps, per-kernel times, parity of four frames against the CPU checker"""
     import torch
-    w = FrameWorkload(cfg, device_index, batch, keypoints, moving, max_fixed, 8, seed)
+    w = FrameWorkload(cfg, device_index, batch, keypoints, moving, max_fixed, 13, seed)  # a prime: see --unique
     stream = torch.cuda.Stream(device=w.dev)
     with torch.cuda.stream(stream):
         w.ctx.use_torch_stream()
@@ -369,6 +373,7 @@ def small_config_leg(name, cfg, keypoints, moving, max_fixed, batch, device_inde
                "with inlier-only runs", cfg["name"]),
            "value": batch * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "frames_per_step": batch, "steps": steps,
            "ms_per_kernel": {"stereo_match5_kernel": kt["matcher_ms"], "align_kernel (search)": kt["search_ms"], "gn_kernel": kt["gn_ms"]},
+           "search_ms_by_round": kt["search_ms_by_round"], "gn_ms_by_round": kt["gn_ms_by_round"],
            "fixed_points_per_frame": snap["n_fixed"], "aligner_correspondences_per_frame": snap["n_corr"],
            "aligner_success_fraction": ok, "gn_iterations_executed_mean": it_exec, "parity": w.parity(snap, poses)}
     w.close()

@@ -355,14 +355,20 @@ PRS_API int prs_align_batch_run(prs_context* ctx,
  * nothing else -- no host synchronisation, no readback; every launch skips the frames that are finished or not waiting for
  * it.  Once the context's scratch buffers exist (after a first batch of the same shape) the sequence allocates nothing and
  * can be captured in a HIP graph.  finish: one 4-byte readback; while frames are still pending (finder retries shift the
- * nominal schedule) four more rounds and another readback.  Between the two calls the context must not start another
- * aligner batch, and `batch`'s buffers must stay valid; the structs themselves are copied. */
+ * nominal schedule) four more rounds and another readback.  Between the two calls the context may run any OTHER operator
+ * (matcher, scene clipper, extractor, brute-force matcher, merger: the enqueued batch owns its working buffers), but must not
+ * start another aligner batch nor change its stream (PRS_ERR_UNSUPPORTED), and `batch`'s buffers must stay valid; the structs
+ * themselves are copied.  finish without an enqueued batch is a no-op.
+ * rearm: a HIP graph captured around enqueue replays the launches without passing through the host code; call rearm after
+ * each graph launch so that finish performs its completion check (and its extra rounds) for the replayed batch.  The graph
+ * bakes in the batch shape: a later enqueue with a larger batch may move the working buffers -- capture again after it. */
 PRS_API int prs_align_batch_enqueue(prs_context* ctx,
                                     const prs_pcf_params* finder,
                                     const prs_aligner_params* aligner,
                                     const prs_align_batch* batch,
                                     int32_t rounds);
 PRS_API int prs_align_batch_finish(prs_context* ctx);
+PRS_API int prs_align_batch_rearm(prs_context* ctx);
 
 /* ---- host, one frame: stateful finder handle mirroring the reference object -------------------
  * setFixed / setMoving / setLocalMapInSensor / compute (tests/test_correspondence_finders.cpp:314,

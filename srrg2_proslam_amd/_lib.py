@@ -280,6 +280,7 @@ SYMBOLS = {
     "prs_align_batch_run": (C.c_int, [_vp, C.POINTER(PcfParams), C.POINTER(AlignerParams), C.POINTER(AlignBatch), C.c_int32]),
     "prs_align_batch_enqueue": (C.c_int, [_vp, C.POINTER(PcfParams), C.POINTER(AlignerParams), C.POINTER(AlignBatch), C.c_int32]),
     "prs_align_batch_finish": (C.c_int, [_vp]),
+    "prs_align_batch_rearm": (C.c_int, [_vp]),
     "prs_pcf_create": (C.c_int, [_vp, C.POINTER(PcfParams), C.POINTER(_vp)]),
     "prs_pcf_destroy": (C.c_int, [_vp]),
     "prs_pcf_set_params": (C.c_int, [_vp, C.POINTER(PcfParams)]),

@@ -1798,6 +1798,10 @@ __device__ __forceinline__ bool gn_advance(const prs_aligner_params& a, const in
 // than 512 correspondences) are fetched from global memory at every iteration.  KEEP_CLS: the factor classes are remembered
 // (keep_only_inlier_correspondences).
 constexpr int kGnLdsSlots = 4;
+// ... plus the rows of ONE more wave (64 correspondences, 2 KB): a frame with a few correspondences more than 512 (the TUM-shaped
+// workload: 524) otherwise waits for a global-memory round trip in every one of its 200 iterations (round 4: 9.0 -> 4.6 ms per
+// 4608 frames).  8 frames x (16 + 2 + 0.7) KB = 150 KB of the CU's 160 KB.
+constexpr int kGnLdsRows = kGnLdsSlots * 128 + 64;
 template <int SLOTS, int DIM, bool KEEP_CLS>
 __global__ __launch_bounds__(128, 4) void gn_kernel(const AlignArgs g) {
   constexpr int THREADS = 128;
@@ -1862,11 +1866,12 @@ __global__ __launch_bounds__(128, 4) void gn_kernel(const AlignArgs g) {
   // operand rows of this thread's first correspondences: parked in LDS ([slot][thread]: consecutive lanes, consecutive 16 B)
   constexpr int LS = SLOTS < kGnLdsSlots ? SLOTS : kGnLdsSlots;
   float4* lz = reinterpret_cast<float4*>(smem + ((sizeof(GnShared) + 15) / 16) * 16);
-  float4* lp = lz + LS * THREADS;
+  constexpr int LROWS = SLOTS <= kGnLdsSlots ? SLOTS * THREADS : kGnLdsRows;  // rows parked in LDS
+  float4* lp = lz + LROWS;
 #pragma unroll
-  for (int k = 0; k < LS; ++k) {
+  for (int k = 0; k < LS + 1; ++k) {
     const int c = k * THREADS + tid;
-    if (k * THREADS < nc) {
+    if (k * THREADS < nc && c < LROWS) {
       float4 z = c < nc ? gops[2 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
       z.w      = inverse_depth_weight(z, mean_dsp);  // (the factors read x, y, z of the measurement only)
       lz[c]    = z;
@@ -1961,7 +1966,7 @@ __global__ __launch_bounds__(128, 4) void gn_kernel(const AlignArgs g) {
           if (k == 0 || c0 + 64 * wave < nc) {
             const int c = c0 + tid;
             float4 z, p;
-            if (k < LS) {
+            if (k < LS || (k == LS && c0 + 64 * wave < LROWS)) {  // (wave-uniform)
               z = lz[c];
               p = lp[c];
             } else {
@@ -2275,6 +2280,37 @@ static inline uint32_t align_up16(uint32_t v) {
 // an enqueued batch of the split pipeline (kept in the context between align_batch_launch and align_batch_finish)
 struct SplitJob {
   bool active = false;
+  // The job OWNS the buffers its launches read and write between enqueue and finish (frame control + pending counter, operand
+  // rows, lattice images): the context's shared scratch slots belong to whatever call runs next (scene clipper, extractor,
+  // brute-force matcher, merger), and a caller may run any of them between the two halves.  Grow-only; freed with the context.
+  void* own[3]        = {nullptr, nullptr, nullptr};
+  size_t own_bytes[3] = {0, 0, 0};
+  hipStream_t stream  = nullptr;  // the stream the rounds were enqueued on (finish synchronises this one)
+  ~SplitJob() {
+    for (void* p : own) {
+      if (p) {
+        (void) hipFree(p);
+      }
+    }
+  }
+  void* buffer(hipStream_t s, int i, size_t bytes) {
+    if (bytes <= own_bytes[i]) {
+      return own[i];
+    }
+    if (own[i]) {
+      (void) hipStreamSynchronize(s);
+      (void) hipFree(own[i]);
+      own[i]       = nullptr;
+      own_bytes[i] = 0;
+    }
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipMalloc(&own[i], want) != hipSuccess) {
+      own[i] = nullptr;
+      return nullptr;
+    }
+    own_bytes[i] = want;
+    return own[i];
+  }
   AlignArgs g, gs;                      // Gauss-Newton / search kernel arguments
   void (*search)(AlignArgs) = nullptr;  // kernel instantiations of this batch
   void (*gn)(AlignArgs)     = nullptr;
@@ -2405,6 +2441,10 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   hipError_t e;
   // diagnostic: PRS_STAMPS=1 times the phases of the fused kernel; with PRS_STAMPS_SPLIT=1 the split pipeline
   // runs instead and the finder phases of every search launch are reported
+  if (max_fixed >= (int) kClsOutUnit) {
+    // the class counts of a linearisation travel as ONE exact float code (#inliers + kClsOutUnit * #kernelised)
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_run: max_fixed must be below 2048");
+  }
   const bool stamps_split = g.stamps && ctx->stamps_split;
   const bool split = mode == PRS_MODE_ALIGN && !ctx_fused_align(ctx) && max_fixed <= kGnThreads * kGnSlots && (!g.stamps || stamps_split);
   if (!split) {
@@ -2425,10 +2465,16 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   }
   // ---- split pipeline: search kernel (512 threads/frame) and GN kernel (operands in registers,
   //      ~30 KB LDS, many frames per CU) alternate; every launch skips frames that do not wait for it.
+  SplitJob* job = static_cast<SplitJob*>(ctx->align_job);
+  if (!job) {
+    job                 = new SplitJob();
+    ctx->align_job      = job;
+    ctx->align_job_free = [](void* p) { delete static_cast<SplitJob*>(p); };
+  }
   const size_t ops_bytes = (size_t) batch->batch * (size_t) max_fixed * 2 * sizeof(float4);
   const size_t ctl_bytes = (size_t) batch->batch * sizeof(FrameCtl) + 256;
-  unsigned char* small   = static_cast<unsigned char*>(ctx_device_scratch_slot(ctx, 3, ctl_bytes));
-  g.ops                  = static_cast<float4*>(ctx_device_scratch_slot(ctx, 2, ops_bytes));
+  unsigned char* small   = static_cast<unsigned char*>(job->buffer(stream, 0, ctl_bytes));
+  g.ops                  = static_cast<float4*>(job->buffer(stream, 1, ops_bytes));
   if (!small || !g.ops) {
     return ctx_fail(ctx, PRS_ERR_HIP, "prs_align_batch_run: split-pipeline scratch allocation failed");
   }
@@ -2439,7 +2485,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   const size_t lds_search = carve(gs, false);
   // image of the lattice arrays (contiguous in LDS: db | inv | cellstart), kept per frame between search launches
   gs.db_blob = align_up16(gs.off_cellstart + cs_entries * 2) - gs.off_db;
-  gs.dbcache = static_cast<unsigned char*>(ctx_device_scratch_slot(ctx, 0, (size_t) batch->batch * gs.db_blob));
+  gs.dbcache = static_cast<unsigned char*>(job->buffer(stream, 2, (size_t) batch->batch * gs.db_blob));
   if (!gs.dbcache) {
     return ctx_fail(ctx, PRS_ERR_HIP, "prs_align_batch_run: lattice cache allocation failed");
   }
@@ -2451,7 +2497,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
                                                                      : align_kernel<kSearchThreads, true, PRS_SEARCH_KDTREE>));
   // two waves per frame (eight frames resident per CU: the kernel is bound by its single-wave phases and by
   // instruction issue, more independent frames fill the idle slots)
-  const size_t lds_gn  = ((sizeof(GnShared) + 15) / 16) * 16 + (size_t) kGnLdsSlots * kGnThreads * 2 * sizeof(float4);  // shared state + parked operand rows
+  const size_t lds_gn  = ((sizeof(GnShared) + 15) / 16) * 16 + (size_t) kGnLdsRows * 2 * sizeof(float4);  // shared state + parked operand rows
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(skernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_search);
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_align_batch_run attribute");
@@ -2464,13 +2510,8 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
                                          : (fast ? gn_kernel<8, PRS_FACTOR_STEREO, false> : gn_kernel<8, 0, true>);
   // The job lives in the context until align_batch_finish: the rounds are plain launches on the context's stream (no host
   // synchronisation here, the sequence can be captured in a HIP graph once the scratch buffers exist).
-  SplitJob* job = static_cast<SplitJob*>(ctx->align_job);
-  if (!job) {
-    job                 = new SplitJob();
-    ctx->align_job      = job;
-    ctx->align_job_free = [](void* p) { delete static_cast<SplitJob*>(p); };
-  }
   job->active      = true;
+  job->stream      = stream;
   job->g           = g;
   job->gs          = gs;
   job->search      = reinterpret_cast<void (*)(AlignArgs)>(skernel);
@@ -2487,7 +2528,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
 
 // `rounds` x (search launch, Gauss-Newton launch) over the frames that are still pending; every launch skips the others
 static int split_rounds(prs_context* ctx, SplitJob* job, int rounds) {
-  hipStream_t stream = ctx_stream(ctx);
+  hipStream_t stream = job->stream;
   auto tick = [&]() {  // measurement only (prs_context_enable_timing): one event per kernel boundary
     if (ctx->timing && job->ev_used < 3 * 64) {
       if (!ctx->timing_ev[job->ev_used]) {
@@ -2524,7 +2565,7 @@ int align_batch_finish(prs_context* ctx) {
   if (!job || !job->active) {
     return PRS_OK;
   }
-  hipStream_t stream = ctx_stream(ctx);
+  hipStream_t stream = job->stream;
   auto collect = [&]() {  // after a stream synchronisation: add up (search, GN) pairs of [e0, e1, e2] triples
     for (int i = 0; i + 2 < job->ev_used; i += 3) {
       float a = 0.f, b = 0.f;
@@ -2570,6 +2611,28 @@ int align_batch_finish(prs_context* ctx) {
     ++ctx->n_batches_timed;
   }
   return PRS_OK;
+}
+
+// a HIP graph captured around align_batch_launch replays the rounds without passing through the host code: re-arm the job so
+// that align_batch_finish checks completion (and adds rounds) for the replayed batch too
+int align_batch_rearm(prs_context* ctx) {
+  SplitJob* job = static_cast<SplitJob*>(ctx->align_job);
+  if (!job || !job->gn) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_rearm: no batch has been enqueued on this context");
+  }
+  if (job->active) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_rearm: the previous batch has not been finished");
+  }
+  job->active       = true;
+  job->total        = 5;
+  job->ev_used      = 0;
+  job->rounds_timed = 0;
+  return PRS_OK;
+}
+
+bool align_job_active(const prs_context* ctx) {
+  const SplitJob* job = static_cast<const SplitJob*>(ctx->align_job);
+  return job && job->active;
 }
 
 int gn_step_launch(prs_context* ctx, const float* dH, const float* db, float damping, float* dX, int* dok) {

@@ -284,6 +284,9 @@ int prs_context_set_stream(prs_context* ctx, void* hip_stream) {
   if (!ctx) {
     return PRS_ERR_NULL;
   }
+  if (align_job_active(ctx)) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_context_set_stream: an enqueued aligner batch has not been finished (prs_align_batch_finish)");
+  }
   ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = HIP's default (null) stream
   return PRS_OK;
 }
@@ -428,6 +431,13 @@ int prs_align_batch_finish(prs_context* ctx) {
   }
   (void) hipSetDevice(ctx->device);
   return align_batch_finish(ctx);
+}
+
+int prs_align_batch_rearm(prs_context* ctx) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  return align_batch_rearm(ctx);
 }
 
 int prs_triangulate_dev(prs_context* ctx, const prs_triangulator_params* params, const float* d_uvuv, int64_t n, float* d_xyz4) {

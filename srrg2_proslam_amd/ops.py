@@ -504,6 +504,12 @@ def align_batch_finish(ctx):
     """prs_align_batch_finish: wait for the enqueued batch, run more rounds for frames that are still pending"""
     rc = _lib.load().prs_align_batch_finish(ctx._h)
     _check(ctx, rc, "prs_align_batch_finish")
+
+
+def align_batch_rearm(ctx):
+    """prs_align_batch_rearm: after replaying a HIP graph captured around align_batch_enqueue, so that finish checks the replay"""
+    rc = _lib.load().prs_align_batch_rearm(ctx._h)
+    _check(ctx, rc, "prs_align_batch_rearm")
     return rc
 
 

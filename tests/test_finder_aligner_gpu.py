@@ -290,6 +290,18 @@ def test_enqueue_finish_overlaps_two_contexts_and_replays_from_a_graph(oracle):
     ops.align_batch_enqueue(cb, fp, ap, fb, rounds=1)   # one round: finish must add the others
     with pytest.raises(ops.ProslamHipError):            # a context has one batch in flight
         ops.align_batch_enqueue(ca, fp, ap, fa)
+    with pytest.raises(ops.ProslamHipError):            # ... whose launches sit on the stream it was enqueued on
+        ca.use_torch_stream()
+    # other operators of the SAME contexts between the two halves (they take the contexts' shared scratch slots, the enqueued
+    # batch owns its working buffers): host-pointer brute-force matcher (slots 0-3), scene clipper, stereo matcher
+    rng = np.random.default_rng(5)
+    d1, d2 = rng.integers(0, 256, (900, 32), dtype=np.uint8), rng.integers(0, 256, (1100, 32), dtype=np.uint8)
+    bf_want = oracle.bruteforce_match(d1, d2, 120.0, 0.95)[0]
+    for c in (ca, cb):
+        got_bf, _ = ops.bruteforce_match(c, ops.bruteforce_params(120.0, 0.95, 0.0), d1, d2)
+        assert corr_equal(got_bf, bf_want)
+        xyzw = np.concatenate([rng.uniform(-20, 20, (5000, 3)), np.ones((5000, 1))], axis=1).astype(np.float32)
+        ops.scene_clip(c, ops.projector_params(cfg), np.eye(4, dtype=np.float32), np.eye(4, dtype=np.float32), xyzw)
     ops.align_batch_finish(cb)
     ops.align_batch_finish(ca)
     assert same(outputs(fa), want) and same(outputs(fb), want)
@@ -309,6 +321,16 @@ def test_enqueue_finish_overlaps_two_contexts_and_replays_from_a_graph(oracle):
         side.synchronize()
         graph.replay()
         side.synchronize()
+        ops.align_batch_finish(ca)
+        assert same(outputs(fg), want)
+        # a second replay: the graph does not pass through the host code, prs_align_batch_rearm arms finish's completion check
+        for name in ("X", "state", "corr", "n_corr"):
+            getattr(fg, name).copy_(getattr(fresh, name))
+        side.synchronize()
+        graph.replay()
+        ops.align_batch_rearm(ca)
+        with pytest.raises(ops.ProslamHipError):  # armed twice
+            ops.align_batch_rearm(ca)
         ops.align_batch_finish(ca)
     assert same(outputs(fg), want)
     for c in (ref_ctx, ca, cb):

@@ -1,0 +1,18 @@
+"""One side configuration of bench.py (EuRoC / TUM / KITTI-1000 shaped) alone, with its per-round kernel times.
+    python tools/bench_leg.py tum [batch]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from srrg2_proslam_amd import configs, synthetic as syn  # noqa: E402
+
+LEGS = {"euroc": ("euroc", 1000, 1000, 512, 2), "tum": ("tum", 1000, 1000, 1024, 3), "kitti_n1000": ("kitti", 1000, 1000, 512, 1)}
+
+if __name__ == "__main__":
+    name = sys.argv[1] if len(sys.argv) > 1 else "tum"
+    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 4608
+    cname, kp, mv, mf, cidx = LEGS[name]
+    print(json.dumps(bench.small_config_leg(name, configs.get(cname), kp, mv, mf, batch, 0, syn.seed_for(cidx, 0) + 31)))

@@ -11,7 +11,7 @@ map management itself is outside SURVEY.md section 8, this is the harness's stan
 bench.py measures the hot path alone; `bench.py --mode closed-loop` calls run() below.  A number of sequences is
 replayed frame by frame on the CPU oracle and compared.
 
-    python tools/bench_tracking.py [--batch 4096] [--frames 60] [--unique 4] [--keypoints 2000] [--check 1]
+    python tools/bench_tracking.py [--batch 4096] [--frames 60] [--unique 5] [--keypoints 2000] [--check 1]
 prints one JSON line.
 """
 import argparse
@@ -162,7 +162,7 @@ def unroll(local_poses, splits):
     return out
 
 
-def run(batch=4096, frames=60, unique=4, keypoints=2000, cap=6144, check=1, prior_info=1.0, trajectory="", max_fixed=1024, device=0, seed_offset=0):
+def run(batch=4096, frames=60, unique=5, keypoints=2000, cap=6144, check=1, prior_info=1.0, trajectory="", max_fixed=1024, device=0, seed_offset=0):
     import torch
     from bench_merge import merger_params
     from srrg2_proslam_amd import configs, ops, synthetic as syn
@@ -326,7 +326,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--frames", type=int, default=60, help="frames per sequence along the KITTI-00 path (frames 0 and 1 are untimed)")
-    ap.add_argument("--unique", type=int, default=4, help="distinct sequences generated on the host and tiled")
+    ap.add_argument("--unique", type=int, default=5, help="distinct sequences generated on the host and tiled (odd: workgroup b runs on XCD b mod 8)")
     ap.add_argument("--keypoints", type=int, default=2000)
     ap.add_argument("--cap", type=int, default=6144, help="landmark capacity of a local map")
     ap.add_argument("--check", type=int, default=1, help="sequences replayed on the CPU oracle (0 = skip)")
