@@ -26,6 +26,8 @@ Rank 0 prints ONE JSON line (contract in the task statement).  Besides the contr
                     RGB-D (640x480, depth-projective path), KITTI at 1000 keypoints per image; a few steps each, with a parity check
   closed_loop       the stateful per-frame loop (matcher -> clipper -> finder / aligner + motion prior -> pose update -> merger) along
                     the KITTI-00 trajectory, checked frame by frame against the same loop on the CPU checker
+  latency_b1        ONE sequence, one frame at a time through the C++ plugin adapters (AoS clouds, gather timed) and through the bare
+                    C-ABI with host pointers (PCIe, launches, synchronisation included), the CPU checker on the same frames beside it
   cpu_baseline      the single-threaded CPU restatement ("port") timed on a bounded sample of the same frames on this box's host
                     cores (rank 0, N=1 only); cpu_baseline_all_cores: one independent sequence per core
 `--mode closed-loop` prints the closed-loop line alone; under torch.distributed.run it shards KITTI sequences 00-07 (BASELINE.json
@@ -173,8 +175,9 @@ def cpu_worker(args):
     from srrg2_proslam_amd import configs, synthetic as syn
     cfg = configs.get("kitti")
     frames = make_unique_frames(cfg, 4, args.keypoints, args.moving, syn.seed_for(1, 0) + 7000 + os.getpid() % 1000)
+    t_start = time.time()
     fps, dt, _ = cpu_baseline(cfg, frames, args.cpu_worker)
-    print(json.dumps({"fps": fps, "seconds": dt}))
+    print(json.dumps({"fps": fps, "seconds": dt, "frames": args.cpu_worker, "t_start": t_start, "t_end": time.time()}))
 
 
 def cpu_all_cores(args, n_workers, frames_each):
@@ -187,15 +190,21 @@ def cpu_all_cores(args, n_workers, frames_each):
     env["OMP_NUM_THREADS"] = "1"
     t0 = time.perf_counter()
     procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env) for _ in range(n_workers)]
-    total, ok = 0.0, 0
+    frames, ok, starts, ends = 0, 0, [], []
     for pr in procs:
         try:
             out, _ = pr.communicate(timeout=240)
-            total += json.loads(out.decode().strip().splitlines()[-1])["fps"]
+            r = json.loads(out.decode().strip().splitlines()[-1])
+            frames += r["frames"]
+            starts.append(r["t_start"])
+            ends.append(r["t_end"])
             ok += 1
         except Exception:
             pr.kill()
-    return total, ok, time.perf_counter() - t0
+    # wall clock of the region in which the workers compute (first start to last end: the start-up of the interpreters is outside,
+    # the contention for memory bandwidth and the stragglers are inside)
+    span = (max(ends) - min(starts)) if ok else 0.0
+    return (frames / span if span > 0 else 0.0), ok, span, time.perf_counter() - t0
 
 
 def profile_evidence(frames_per_launch, keypoints):
@@ -379,6 +388,76 @@ def small_config_leg(name, cfg, keypoints, moving, max_fixed, batch, device_inde
     w.close()
     del w
     torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# latency of the drop-in path: one sequence, one frame at a time, host pointers (tools/latency_b1.cpp)
+# ---------------------------------------------------------------------------------------------------------------------
+def latency_b1(cfg, frames, n_frames=64):
+    """one frame at a time through the C++ adapters of plugin/ (AoS clouds, gather included) and through the bare C-ABI (flat arrays),
+    PCIe and launch latency included; the CPU checker on the same frames beside it, poses compared"""
+    import struct
+    import subprocess
+    import tempfile
+    from oracle import binding as ob
+    exe = os.path.join(ROOT, "tools", "bin", "latency_b1")
+    if not os.path.exists(exe):
+        return {"error": "tools/bin/latency_b1 is not built (__graft_entry__.build())"}
+    cam, m, tri, f, al = cfg["camera"], cfg["stereo_matcher"], cfg["triangulator"], cfg["projective_finder"], cfg["aligner"]
+    par = [cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["cols"], cam["rows"], cam["baseline_m"], cfg["projector"]["range_min"], cfg["projector"]["range_max"],
+           m["maximum_descriptor_distance"], m["maximum_distance_ratio_to_second_best"], m["minimum_matching_ratio"], m["maximum_disparity_pixels"],
+           m["epipolar_line_thickness_pixels"], tri["minimum_disparity_pixels"], tri["infinity_depth_meters"],
+           f["maximum_descriptor_distance"], f["maximum_distance_ratio_to_second_best"], f["minimum_matching_ratio"], f["minimum_descriptor_distance"],
+           f["descriptor_distance_step_size_pixels"], f["maximum_search_radius_pixels"], f["minimum_search_radius_pixels"], f["search_radius_step_size_pixels"],
+           f["minimum_number_of_iterations"], f["maximum_estimate_change_norm_for_convergence"], f["number_of_solver_iterations_per_projection"],
+           al["diagonal_info"][0], al["diagonal_info"][1], al["diagonal_info"][2], al["chi_threshold"], al["enable_inverse_depth_weighting"], al["damping"],
+           al["max_iterations"], al["min_num_inliers"], al["min_num_correspondences"]]
+    seq = [frames[k % len(frames)] for k in range(n_frames)]
+    N, NM = seq[0]["fr"]["uv_left"].shape[0], seq[0]["mp"]["xyz"].shape[0]
+    warm = 4
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "frames.bin")
+        with open(path, "wb") as fh:
+            fh.write(struct.pack("<4i", n_frames, N, NM, len(par)))
+            fh.write(np.asarray(par, np.float32).tobytes())
+            for d in seq:
+                fr, mp = d["fr"], d["mp"]
+                for a, dt in ((fr["uv_left"], np.float32), (fr["desc_left"], np.uint8), (fr["uv_right"], np.float32), (fr["desc_right"], np.uint8),
+                              (mp["xyz"], np.float32), (mp["desc"], np.uint8), (mp["n_opt"], np.uint32), (d["X0"], np.float32)):
+                    fh.write(np.ascontiguousarray(a, dt).tobytes())
+        run = subprocess.run([exe, path, str(warm)], capture_output=True, text=True, timeout=600)
+        if run.returncode != 0:
+            return {"error": "latency_b1 exit %d: %s" % (run.returncode, run.stderr[-400:])}
+        out = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+        poses = np.fromfile(path + ".poses", np.float32).reshape(2, n_frames, 4, 4)
+    # the CPU checker, same frames, same order, ONE finder object across them (incl. the warm-up frames: its state carries over)
+    sp, tp, pp, ap = oracle_params(cfg)
+    finder = ob.ProjectiveFinder(pp)
+    worst, times = 0.0, []
+    for k in range(-warm, n_frames):
+        d = seq[(k + warm) % n_frames] if k < 0 else seq[k]
+        fr, mp = d["fr"], d["mp"]
+        t0 = time.perf_counter()
+        corr, _ = ob.stereo_match(fr["uv_left"], fr["desc_left"], fr["uv_right"], fr["desc_right"], sp)
+        fixed, src = ob.stereo_assemble(fr["uv_left"], fr["uv_right"], corr)
+        ob.triangulate(fixed, tp)
+        ap.mean_disparity = ob.mean_disparity(fixed)
+        finder.set_fixed(fixed, fr["desc_left"][src])
+        finder.set_moving(mp["xyz"], mp["desc"])
+        res, _ = ob.align_frame(finder, ap, fixed, mp["xyz"], ob.info_scale_from_nopt(mp["n_opt"]), d["X0"])
+        dt = time.perf_counter() - t0
+        if k >= 0:
+            times.append(dt * 1e3)
+            X = np.array(res.X, np.float32).reshape(4, 4)
+            for flavour in range(2):
+                worst = max(worst, float(np.linalg.norm(poses[flavour, k] - X) / np.linalg.norm(X)))
+    finder.close()
+    out["cpu_checker"] = {"ms_per_frame_mean": float(np.mean(times)), "fps": 1e3 / float(np.mean(times)), "cores": 1, "kind": "port"}
+    out["pose_rel_frobenius_max_vs_cpu_checker"] = worst
+    out["note"] = ("one sequence, one frame at a time, host pointers, PCIe + launch + synchronisation inside every call; finder object carried across "
+                   "frames; `adapters` = plugin/proslam_hip_plugin.hpp on array-of-structs clouds (gather / scatter timed), `c_abi` = flat arrays; the "
+                   "reference times frames the same way (apps/app_benchmark.cpp:345-353)")
     return out
 
 
@@ -670,17 +749,22 @@ def main():
         }
         # the same run doubles as an end-to-end check of the device pipeline on the bench inputs
         out["parity_on_bench_inputs"] = w.parity(snap, poses)
+        uniq_frames = w.uniq
         n_workers = args.cpu_all_cores if args.cpu_all_cores >= 0 else min(os.cpu_count() or 1, 256)
         if n_workers > 0:
-            total, ok, wall = cpu_all_cores(args, n_workers, 48)
+            total, ok, span, wall = cpu_all_cores(args, n_workers, 200)
             out["cpu_baseline_all_cores"] = {
                 "value": total, "unit": "frames/s", "cores": ok, "kind": "port",
-                "sample": "%d worker processes (one independent sequence each, 48 frames per worker) of the same CPU restatement, "
-                          "sum of the per-worker rates, %.1f s wall" % (ok, wall),
+                "sample": "%d worker processes (one independent sequence each, 200 frames per worker) of the same CPU restatement: all frames / "
+                          "wall clock from the first worker's start to the last worker's end (%.1f s; %.1f s incl. interpreter start-up)" % (ok, span, wall),
             }
+    else:
+        uniq_frames = None
     w.close()
     del w
     torch.cuda.empty_cache()
+    if uniq_frames is not None:
+        out["latency_b1"] = latency_b1(cfg, uniq_frames)
 
     # ---- the other BASELINE configurations and the stateful loop, outside the headline timing (rank 0, single GPU) ----
     if rank == 0 and world == 1 and not args.no_other_configs:
@@ -694,7 +778,8 @@ def main():
         out["other_configs"] = others
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_tracking
-        cl = bench_tracking.run(batch=4096, frames=30, keypoints=N, check=0 if args.no_cpu_baseline else 1, device=local_rank)
+        # 4096 sequences x 62 frames; all five distinct sequences replayed on the CPU checker (310 frames: parity of every pose + CPU rate)
+        cl = bench_tracking.run(batch=4096, frames=62, keypoints=N, check=0 if args.no_cpu_baseline else 5, device=local_rank)
         out["closed_loop"] = {k: cl[k] for k in ("value", "unit", "ms_per_step", "config", "ms_per_stage", "map_points_mean", "aligner_correspondences_mean",
                                                  "finder_retries_per_frame", "track_losses_per_frame", "drift_percent_of_path", "parity_vs_oracle_chain",
                                                  "cpu_baseline") if k in cl}
