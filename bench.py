@@ -22,7 +22,8 @@ Rank 0 prints ONE JSON line (contract in the task statement).  Besides the contr
                     the headline loop (per launch of every round), `traffic` comes from the committed PMC passes of the same command
   steady_state      the same step with the finder objects carried over from frame to frame (the reference's adaptive
                     radius / threshold schedule live) instead of fresh finders
-  other_configs     BASELINE.json configs 3 and 4 and the reference's own keypoint budget: EuRoC-shaped stereo (752x480), TUM-shaped
+  other_configs     (+ kitti_real: the reference's own KITTI stereo pairs through the device extractor: REAL ORB descriptors, tiled)
+                    BASELINE.json configs 3 and 4 and the reference's own keypoint budget: EuRoC-shaped stereo (752x480), TUM-shaped
                     RGB-D (640x480, depth-projective path), KITTI at 1000 keypoints per image; a few steps each, with a parity check
   closed_loop       the stateful per-frame loop (matcher -> clipper -> finder / aligner + motion prior -> pose update -> merger) along
                     the KITTI-00 trajectory, checked frame by frame against the same loop on the CPU checker
@@ -180,6 +181,32 @@ def cpu_worker(args):
     print(json.dumps({"fps": fps, "seconds": dt, "frames": args.cpu_worker, "t_start": t_start, "t_end": time.time()}))
 
 
+def usable_cores():
+    """cores this process may actually use: the scheduler affinity capped by the cgroup CPU quota (a container that shows 256 cores
+    can be limited to a handful; oversubscribing the quota only measures the throttle)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota:
+        n = max(1, min(n, int(quota + 0.999)))
+    return n, quota
+
+
 def cpu_all_cores(args, n_workers, frames_each):
     """the CPU checker on every host core at once, one independent sequence per process"""
     import subprocess
@@ -245,13 +272,14 @@ def profile_evidence(frames_per_launch, keypoints):
 # B independent frames of one configuration resident in HBM; step() = one pass of the hot path over all of them
 # ---------------------------------------------------------------------------------------------------------------------
 class FrameWorkload:
-    def __init__(self, cfg, device_index, batch, keypoints, moving, max_fixed, unique, seed, all_iterations=False):
+    def __init__(self, cfg, device_index, batch, keypoints, moving, max_fixed, unique, seed, all_iterations=False, frames=None):
         import torch
         from srrg2_proslam_amd import ops
         self.cfg, self.B, self.N, self.NM = cfg, batch, keypoints, moving
         self.stereo = cfg["aligner"]["factor_type"] == 4
         self.dev = torch.device("cuda", device_index)
-        self.uniq = make_unique_frames(cfg, unique, keypoints, moving, seed)
+        # `frames`: ready-made frames (the real-image leg) instead of `unique` synthetic ones; keypoints / moving are then the strides
+        self.uniq = frames if frames is not None else make_unique_frames(cfg, unique, keypoints, moving, seed)
         idx = (torch.arange(batch, device=self.dev) % len(self.uniq))
         self.aframes = ops.AlignFrames(device_index, batch, keypoints, moving)
         astage = ops.AlignFrames(device_index, len(self.uniq), 1 if self.stereo else keypoints, moving)
@@ -392,6 +420,78 @@ def small_config_leg(name, cfg, keypoints, moving, max_fixed, batch, device_inde
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# real descriptors: the reference's own KITTI stereo pairs (tests/golden/ref_kitti.npz), extracted on the device
+# ---------------------------------------------------------------------------------------------------------------------
+def kitti_real_frames(device_index, cfg, target):
+    """the 14 KITTI images the reference ships (city 00-04, highway 274 / 275) through the device extractor (FAST 15, 3 x 3 bins,
+    ORB-256, `target` keypoints per image, libstdc++ selection order) and the host-pointer matcher / triangulator -> five tracked frames
+    (01 <- 00, 02 <- 01, 03 <- 02, 04 <- 03, 275 <- 274): fixed = the frame's stereo measurements, moving = the previous frame's
+    triangulated points in ITS camera frame, guess = identity like the reference's aligner tests (tests/test_aligners.cpp:1239)"""
+    from srrg2_proslam_amd import ops
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ref_kitti.npz"))
+    ctx = ops.Context(device_index)
+    ep = ops.extractor_params(threshold=15, target=target, vertical=3, horizontal=3, selection_order=ops.SELECT_LIBSTDCXX)
+    sp, tp = ops.stereo_params(cfg["stereo_matcher"], cfg["camera"]["rows"]), ops.triangulator_params(cfg)
+    per_pair = []
+    for key, n in (("city", 5), ("highway", 2)):
+        for i in range(n):
+            uvl, _, dl = ops.extract_features(ctx, ep, z[key + "_left"][i], capacity=4096)
+            uvr, _, dr = ops.extract_features(ctx, ep, z[key + "_right"][i], capacity=4096)
+            corr, _ = ops.stereo_match(ctx, sp, uvl, dl, uvr, dr)
+            L, R = uvl[corr["fixed_idx"]], uvr[corr["moving_idx"]]
+            keep = (L[:, 0] - R[:, 0] >= 0) & (L[:, 1] - R[:, 1] >= 0)  # the stereo adaptor's test (raw_data_preprocessor_stereo_projective.cpp:120-128)
+            fixed = np.concatenate([L[keep], R[keep]], axis=1).astype(np.float32)
+            xyz, valid = ops.triangulate(ctx, tp, fixed)
+            valid = np.asarray(valid).astype(bool)
+            per_pair.append(dict(uvl=uvl, dl=dl, uvr=uvr, dr=dr, xyz=np.asarray(xyz)[valid], desc=dl[corr["fixed_idx"]][keep][valid], key=key))
+    ctx.close()
+    frames = []
+    for a, b in ((0, 1), (1, 2), (2, 3), (3, 4), (5, 6)):
+        prev, cur = per_pair[a], per_pair[b]
+        frames.append({"fr": {"uv_left": cur["uvl"], "desc_left": cur["dl"], "uv_right": cur["uvr"], "desc_right": cur["dr"]},
+                       "mp": {"xyz": prev["xyz"].astype(np.float32), "desc": prev["desc"], "n_opt": np.zeros(len(prev["xyz"]), np.uint32)},
+                       "X0": np.eye(4, dtype=np.float32), "T": np.eye(4, dtype=np.float32)})
+    return frames
+
+
+def kitti_real_leg(device_index, cfg, batch, target=2000, steps=3):
+    """matcher + projective search + GN on REAL ORB descriptors (correlated rows, real keypoint distribution), tiled to `batch`; the CPU
+    checker on the same five frames beside it"""
+    import torch
+    frames = kitti_real_frames(device_index, cfg, target)
+    stride = 64 * ((max(max(len(f["fr"]["uv_left"]), len(f["fr"]["uv_right"]), len(f["mp"]["xyz"])) for f in frames) + 63) // 64)
+    w = FrameWorkload(cfg, device_index, batch, stride, stride, 1024, len(frames), 0, frames=frames)
+    stream = torch.cuda.Stream(device=w.dev)
+    with torch.cuda.stream(stream):
+        w.ctx.use_torch_stream()
+        w.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            w.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        snap = w.snapshot()
+        ok, it_exec = w.check(snap)
+        kt = w.kernel_times(2)
+    _, cpu_s, poses = cpu_baseline(cfg, frames, len(frames))
+    out = {"workload": "the reference's own KITTI stereo pairs (tests/golden/ref_kitti.npz: city 00-04, highway 274 / 275): device extractor (FAST 15, 3 x 3 bins, "
+                       "%d keypoints per image, ORB-256) -> epipolar matcher + triangulator -> projective circle finder against the previous frame's "
+                       "triangulated points + stereo GN aligner from an identity guess, kitti.conf parameters; 5 tracked frames tiled to %d" % (target, batch),
+           "keypoints_per_image": [int(len(f["fr"]["uv_left"])) for f in frames], "local_map_points": [int(len(f["mp"]["xyz"])) for f in frames],
+           "value": batch * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "frames_per_step": batch,
+           "ms_per_kernel": {"stereo_match5_kernel": kt["matcher_ms"], "align_kernel (search)": kt["search_ms"], "gn_kernel": kt["gn_ms"]},
+           "search_ms_by_round": kt["search_ms_by_round"], "gn_ms_by_round": kt["gn_ms_by_round"],
+           "stereo_matches_per_frame": snap.get("n_match"), "fixed_points_per_frame": snap["n_fixed"], "aligner_correspondences_per_frame": snap["n_corr"],
+           "aligner_success_fraction": ok, "gn_iterations_executed_mean": it_exec, "parity": w.parity(snap, poses),
+           "cpu_checker_fps": len(frames) / cpu_s}
+    w.close()
+    del w
+    torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # latency of the drop-in path: one sequence, one frame at a time, host pointers (tools/latency_b1.cpp)
 # ---------------------------------------------------------------------------------------------------------------------
 def latency_b1(cfg, frames, n_frames=64):
@@ -412,7 +512,7 @@ def latency_b1(cfg, frames, n_frames=64):
            f["descriptor_distance_step_size_pixels"], f["maximum_search_radius_pixels"], f["minimum_search_radius_pixels"], f["search_radius_step_size_pixels"],
            f["minimum_number_of_iterations"], f["maximum_estimate_change_norm_for_convergence"], f["number_of_solver_iterations_per_projection"],
            al["diagonal_info"][0], al["diagonal_info"][1], al["diagonal_info"][2], al["chi_threshold"], al["enable_inverse_depth_weighting"], al["damping"],
-           al["max_iterations"], al["min_num_inliers"], al["min_num_correspondences"]]
+           al["max_iterations"], al["min_num_inliers"], al["min_num_correspondences"], -cam["fx"] * cam["baseline_m"]]
     seq = [frames[k % len(frames)] for k in range(n_frames)]
     N, NM = seq[0]["fr"]["uv_left"].shape[0], seq[0]["mp"]["xyz"].shape[0]
     warm = 4
@@ -434,7 +534,7 @@ def latency_b1(cfg, frames, n_frames=64):
     # the CPU checker, same frames, same order, ONE finder object across them (incl. the warm-up frames: its state carries over)
     sp, tp, pp, ap = oracle_params(cfg)
     finder = ob.ProjectiveFinder(pp)
-    worst, times = 0.0, []
+    worst, times = [0.0, 0.0], []
     for k in range(-warm, n_frames):
         d = seq[(k + warm) % n_frames] if k < 0 else seq[k]
         fr, mp = d["fr"], d["mp"]
@@ -451,10 +551,10 @@ def latency_b1(cfg, frames, n_frames=64):
             times.append(dt * 1e3)
             X = np.array(res.X, np.float32).reshape(4, 4)
             for flavour in range(2):
-                worst = max(worst, float(np.linalg.norm(poses[flavour, k] - X) / np.linalg.norm(X)))
+                worst[flavour] = max(worst[flavour], float(np.linalg.norm(poses[flavour, k] - X) / np.linalg.norm(X)))
     finder.close()
     out["cpu_checker"] = {"ms_per_frame_mean": float(np.mean(times)), "fps": 1e3 / float(np.mean(times)), "cores": 1, "kind": "port"}
-    out["pose_rel_frobenius_max_vs_cpu_checker"] = worst
+    out["pose_rel_frobenius_max_vs_cpu_checker"] = {"adapters": worst[0], "c_abi": worst[1]}
     out["note"] = ("one sequence, one frame at a time, host pointers, PCIe + launch + synchronisation inside every call; finder object carried across "
                    "frames; `adapters` = plugin/proslam_hip_plugin.hpp on array-of-structs clouds (gather / scatter timed), `c_abi` = flat arrays; the "
                    "reference times frames the same way (apps/app_benchmark.cpp:345-353)")
@@ -750,13 +850,16 @@ def main():
         # the same run doubles as an end-to-end check of the device pipeline on the bench inputs
         out["parity_on_bench_inputs"] = w.parity(snap, poses)
         uniq_frames = w.uniq
-        n_workers = args.cpu_all_cores if args.cpu_all_cores >= 0 else min(os.cpu_count() or 1, 256)
+        cores, quota = usable_cores()
+        n_workers = args.cpu_all_cores if args.cpu_all_cores >= 0 else min(cores, 256)
         if n_workers > 0:
             total, ok, span, wall = cpu_all_cores(args, n_workers, 200)
             out["cpu_baseline_all_cores"] = {
                 "value": total, "unit": "frames/s", "cores": ok, "kind": "port",
                 "sample": "%d worker processes (one independent sequence each, 200 frames per worker) of the same CPU restatement: all frames / "
-                          "wall clock from the first worker's start to the last worker's end (%.1f s; %.1f s incl. interpreter start-up)" % (ok, span, wall),
+                          "wall clock from the first worker's start to the last worker's end (%.1f s; %.1f s incl. interpreter start-up); the host shows "
+                          "%d cores, the cgroup CPU quota is %s: = %.1f x the one-core rate" % (ok, span, wall, os.cpu_count() or 0,
+                                                                                              ("%.1f cores" % quota) if quota else "none", total / max(cpu_fps, 1e-9)),
             }
     else:
         uniq_frames = None
@@ -775,6 +878,10 @@ def main():
                 others[name] = small_config_leg(name, configs.get(cname), kp, mv, mf, small, local_rank, syn.seed_for(cidx, 0) + 31)
             except SystemExit as exc:  # a loud per-frame error of a side leg must not take the headline line with it
                 others[name] = {"error": str(exc)}
+        try:
+            others["kitti_real"] = kitti_real_leg(local_rank, cfg, small)
+        except (SystemExit, OSError, KeyError) as exc:
+            others["kitti_real"] = {"error": str(exc)}
         out["other_configs"] = others
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_tracking

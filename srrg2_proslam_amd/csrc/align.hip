@@ -89,6 +89,7 @@ struct AlignArgs {
   prs_aligner_params a;
   prs_align_batch b;
   int mode;
+  int no_prefilter;  // diagnostic (PRS_NO_PREFILTER=1)
   int rows_table;  // R = projector canvas rows (lattice row table extent)
   int lut_cap;     // entries of the circle width table
   int cell_sy, cell_sx, cell_ncx, cell_ncy, ncells;  // 2-D cell grid over the canvas (cells of 2^sy rows x 2^sx cols)
@@ -1172,7 +1173,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
           // candidates at or beyond this descriptor distance cannot change what the filter below accepts; only worth a
           // separate pass while the bound is well below what half a random descriptor pair differs by (64 +- 6 bits)
           const int irrelevant = irrelevant_distance(sh.dd, g.f.maximum_distance_ratio_to_second_best);
-          const int prune_at   = (lattice && irrelevant > 0 && irrelevant <= 54) ? irrelevant : 0;
+          const int prune_at   = (lattice && irrelevant > 0 && irrelevant <= 54 && !g.no_prefilter) ? irrelevant : 0;
           // the int16 row / column arithmetic of the reference cannot wrap on this canvas
           const bool circle_exact = rad < 8192 && R + rad < 32000 && (g.cell_ncx << g.cell_sx) + rad < 32000;
           int projected      = 0;
@@ -2355,6 +2356,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   g.a          = *aligner;
   g.b          = *batch;
   g.mode       = mode;
+  g.no_prefilter = ctx->no_prefilter ? 1 : 0;
   g.prior_mean = batch->prior_mean;
   g.rows_table = finder->projector.canvas_rows;
   const int max_fixed = batch->max_fixed > 0 && batch->max_fixed < batch->fixed_stride ? batch->max_fixed : batch->fixed_stride;

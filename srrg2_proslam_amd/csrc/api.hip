@@ -199,6 +199,8 @@ int prs_context_create(int device_id, prs_context** out) {
   ctx->stamps_enabled  = stamps && stamps[0] == '1';
   const char* ssplit   = getenv("PRS_STAMPS_SPLIT");
   ctx->stamps_split    = ssplit && ssplit[0] == '1';
+  const char* nopre    = getenv("PRS_NO_PREFILTER");
+  ctx->no_prefilter    = nopre && nopre[0] == '1';
   const char* mfused   = getenv("PRS_MERGE_FUSED");
   ctx->merge_fused     = mfused && mfused[0] == '1';
   *out                 = ctx;

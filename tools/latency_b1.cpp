@@ -80,6 +80,7 @@ int main(int argc, char** argv) {
               f_rstep = par[k++], f_minit = par[k++], f_eps = par[k++], f_every = par[k++];
   const float a_i0 = par[k++], a_i1 = par[k++], a_i2 = par[k++], a_chi = par[k++], a_idw = par[k++], a_damp = par[k++], a_maxit = par[k++],
               a_mininl = par[k++], a_mincorr = par[k++];
+  const float b_lr_x = par[k++];  // K * t_left_in_right, x (the caller's value: a float product here would round differently from the host's double one)
   const float K9[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1};
 
   ContextPtr ctx(new Context(0));
@@ -131,7 +132,7 @@ int main(int argc, char** argv) {
     aligner.param_diagonal_info_matrix[1]        = a_i1;
     aligner.param_diagonal_info_matrix[2]        = a_i2;
     aligner.param_enable_inverse_depth_weighting = a_idw != 0.f;
-    aligner.baseline_left_in_right_pixels[0]     = -fx * baseline_m;
+    aligner.baseline_left_in_right_pixels[0]     = b_lr_x;
 
     // the clouds as the reference holds them: array of structs (built outside the timed region: they are the pipeline's data)
     std::vector<Cloud3> L((size_t) n_frames), R((size_t) n_frames), M((size_t) n_frames);
@@ -214,7 +215,7 @@ int main(int argc, char** argv) {
     prs_aligner_params ap;
     std::memset(&ap, 0, sizeof(ap));
     ap.factor_type = PRS_FACTOR_STEREO, ap.fx = fx, ap.fy = fy, ap.cx = cx, ap.cy = cy, ap.image_cols = cols, ap.image_rows = rows;
-    ap.baseline_left_in_right_px[0] = -fx * baseline_m;
+    ap.baseline_left_in_right_px[0] = b_lr_x;
     ap.diagonal_info[0] = a_i0, ap.diagonal_info[1] = a_i1, ap.diagonal_info[2] = a_i2;
     ap.chi_threshold = a_chi, ap.enable_inverse_depth_weighting = a_idw != 0.f, ap.mean_disparity = -1.0f, ap.damping = a_damp;
     ap.max_iterations = (int32_t) a_maxit, ap.min_num_inliers = (int32_t) a_mininl, ap.min_num_correspondences = (int32_t) a_mincorr;
