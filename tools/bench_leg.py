@@ -1,5 +1,5 @@
 """One side configuration of bench.py (EuRoC / TUM / KITTI-1000 shaped) alone, with its per-round kernel times.
-    python tools/bench_leg.py tum [batch]"""
+    python tools/bench_leg.py tum|euroc|kitti_n1000|kitti_real [batch]"""
 import json
 import os
 import sys
@@ -14,5 +14,8 @@ LEGS = {"euroc": ("euroc", 1000, 1000, 512, 2), "tum": ("tum", 1000, 1000, 1024,
 if __name__ == "__main__":
     name = sys.argv[1] if len(sys.argv) > 1 else "tum"
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 4608
-    cname, kp, mv, mf, cidx = LEGS[name]
-    print(json.dumps(bench.small_config_leg(name, configs.get(cname), kp, mv, mf, batch, 0, syn.seed_for(cidx, 0) + 31)))
+    if name == "kitti_real":
+        print(json.dumps(bench.kitti_real_leg(0, configs.get("kitti"), batch)))
+    else:
+        cname, kp, mv, mf, cidx = LEGS[name]
+        print(json.dumps(bench.small_config_leg(name, configs.get(cname), kp, mv, mf, batch, 0, syn.seed_for(cidx, 0) + 31)))

@@ -8,7 +8,7 @@ from srrg2_proslam_amd import configs, ops, synthetic as syn
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
-uniq = 64
+uniq = 61  # a prime: frame b runs on XCD b mod 8 (see bench.py --unique)
 cfg = configs.get("kitti")
 frames = ops.StereoFrames(0, B, N, epilogue=True)
 t0 = time.time()
