@@ -278,26 +278,26 @@ __device__ __forceinline__ void factor_accumulate(const prs_aligner_params& a, c
   const float iz_r = 1.0f / pcz;
   const float u_r = hx_r * iz_r, v_r = hy_r * iz_r;
   const bool valid = active && pcz > 0.0f && !(u_r < 0.0f || u_r > a.image_cols || v_r < 0.0f || v_r > a.image_rows);
-  // the stand-in of an invalid / inactive correspondence (any finite values do: its information is zero)
+  // the stand-in of an invalid / inactive correspondence: inverse depth 0 and information 0.  With iz = 0 the predicted image
+  // point, D = d(image point) / d(point in camera) and hence Q and J are all zeros (hx_r, hy_r, the measurement and the weight are
+  // finite), so every product below is +-0 without further selects (round 4: a v_cndmask costs two issue slots on gfx950,
+  // profiles/r04/valu_issue_rates.txt; seven of them per correspondence went away).  The point itself is still replaced: a
+  // non-finite map point is "behind the camera" for the reference, and 0 * NaN would poison the sums.
   const float px = valid ? p_in.x : 0.0f, py = valid ? p_in.y : 0.0f, pz = valid ? p_in.z : 0.0f;
-  const float u_pred = valid ? u_r : 0.0f, v_pred = valid ? v_r : 0.0f;
   const float iz = valid ? iz_r : 0.0f;
+  const float u_pred = hx_r * iz, v_pred = hy_r * iz;  // = u_r, v_r of a valid correspondence (same operations), 0 otherwise
   float e0 = u_pred - z.x, e1 = v_pred - z.y, e2 = 0.0f;
   float ur = 0.0f;  // predicted column in the right image
   if (dim == PRS_FACTOR_STEREO) {
-    const float hrx = (valid ? hx_r : 0.0f) + a.baseline_left_in_right_px[0];
+    const float hrx = hx_r + a.baseline_left_in_right_px[0];
     e2              = fmaf(hrx, iz, -z.z);
     ur              = hrx * iz;
   } else if (dim == PRS_FACTOR_DEPTH) {
-    e2 = pcz - z.z;
+    e2 = (valid ? pcz : 0.0f) - z.z;
   }
-  e0 = valid ? e0 : 0.0f;
-  e1 = valid ? e1 : 0.0f;
-  e2 = valid ? e2 : 0.0f;
   float wt = 1.0f;
   if (dim == PRS_FACTOR_STEREO && a.enable_inverse_depth_weighting) {
-    wt = PRE_WT ? z.w : inverse_depth_weight(z, mean_dsp);
-    wt = valid ? wt : 1.0f;
+    wt = PRE_WT ? z.w : inverse_depth_weight(z, mean_dsp);  // finite: min(.., 1) maps NaN and +inf to 1
   }
   auto fma2 = [](f2 x, f2 y, f2 z2) -> f2 { return __builtin_elementwise_fma(x, y, z2); };
   // Q = D * R, rows as (pair of columns 0 1, column 2)
