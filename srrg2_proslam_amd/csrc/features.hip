@@ -76,8 +76,14 @@ __device__ __forceinline__ int lanes_below(uint64_t m, int base) {  // base + nu
 
 constexpr int kTileWords  = kTilePitch / 4;   // 18 words per tile row
 constexpr int kTileRows   = kTileH + 8;       // 4-px halo above and below
-constexpr int kListCap    = 1216;             // compass survivors one wave can collect (5 x 256 px is never reached: see the item map)
-constexpr int kSecondCap  = 1152;             // entries one wave can re-examine with the other polarity (18 trips x 64 lanes)
+// Survivor lists are sized for what images hold, not for the worst case (round 4): a wave collects at most 608 compass survivors
+// (an image tile has ~150-400 per wave; a wave examines at most 1216 pixels) and re-examines at most 128 pixels with the other polarity;
+// a survivor that finds its list full is scored on the spot by its own lane instead (same arithmetic, same result, divergent but
+// rare).  With the Gaussian's horizontal sums in the same LDS bytes once the lists are dead the workgroup needs 19.4 KB instead of
+// 38.3 KB: EIGHT workgroups per CU instead of four = eight waves per SIMD, which retire ~36 % more vector instructions per cycle
+// than four (profiles/r04/valu_issue_rates.txt; the kernel is bound by vector issue).
+constexpr int kListCap    = 608;
+constexpr int kSecondCap  = 128;
 constexpr uint32_t kBrightFlag = 0x4000u, kDarkFlag = 0x8000u, kIdMask = 0x1fffu;
 
 // FAST-9 score of one polarity at the pixel `c` (LDS tile pointer): the largest arc minimum of s * (circle - centre)
@@ -170,10 +176,26 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
   // the two ring columns follow pixel by pixel.  Entry = tile byte offset | polarity flags.
   int n_mine         = 0;  // wave-uniform
   uint16_t* my_list  = list[wave];
+  // the response of one survivor, scored by its own lane (list overflow): bright first, dark only if bright failed
+  auto score_now = [&](const uint32_t entry) {
+    const int id = (int) (entry & kIdMask);
+    int best     = (entry & kBrightFlag) ? arc_best(tile8 + id, false) : arc_best(tile8 + id, true);
+    if (best <= t && (entry & (kBrightFlag | kDarkFlag)) == (kBrightFlag | kDarkFlag)) {
+      best = arc_best(tile8 + id, true);
+    }
+    if (best > t) {
+      resp8[id] = (uint8_t) (best - 1);
+    }
+  };
   auto push = [&](uint32_t entry, bool ok) {
     const uint64_t m = __ballot(ok);
     if (ok) {
-      my_list[lanes_below(m, n_mine)] = (uint16_t) entry;
+      const int pos = lanes_below(m, n_mine);
+      if (pos < kListCap) {
+        my_list[pos] = (uint16_t) entry;
+      } else {
+        score_now(entry);
+      }
     }
     n_mine += __popcll(m);
   };
@@ -236,25 +258,7 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
     push((uint32_t) id | (bright ? kBrightFlag : 0u) | (dark ? kDarkFlag : 0u), ok && (bright || dark));
   }
   if (lane == 0) {
-    list_n[wave] = n_mine;
-  }
-  // ---- 7x7 Gaussian, horizontal pass: tile rows -3 .. kTileH+2, four sums per lane, stored as packed 16-bit lanes:
-  // 55 c + 49 (l1 + r1) + 34 (l2 + r2) + 18 (l3 + r3) <= 257 * 255 = 65535 fits the lane exactly.
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int h = r0 + 16 * k;
-    if (h < kTileH + 6) {
-      const int wi      = (h + 1) * kTileWords + 1 + w1;
-      const uint32_t C = tile32[wi], L = tile32[wi - 1], R = tile32[wi + 1];
-      // pixel x = 4 w + j: bytes x-3 .. x against (18, 34, 49, 55) and bytes x+1 .. x+4 against (49, 34, 18, 0), two v_dot4_u32_u8
-      constexpr uint32_t kTapsLeft = kG0 | (kG1 << 8) | (kG2 << 16) | (kG3 << 24), kTapsRight = kG2 | (kG1 << 8) | (kG0 << 16);
-      const uint32_t s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, L, 1), kTapsLeft, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 1), kTapsRight, 0u, false), false);
-      const uint32_t s1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, L, 2), kTapsLeft, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 2), kTapsRight, 0u, false), false);
-      const uint32_t s2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, L, 3), kTapsLeft, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 3), kTapsRight, 0u, false), false);
-      const uint32_t s3 = __builtin_amdgcn_udot4(C, kTapsLeft, __builtin_amdgcn_udot4(R, kTapsRight, 0u, false), false);
-      const uint32_t sum[2] = {s0 | (s2 << 16), s1 | (s3 << 16)};
-      hsum64[h * 16 + w1] = ((uint64_t) sum[1] << 32) | sum[0];  // lanes: pixel 0 | pixel 2 , pixel 1 | pixel 3
-    }
+    list_n[wave] = n_mine < kListCap ? n_mine : kListCap;
   }
   __syncthreads();
   // ---- arc minima on dense lanes: entry j of the concatenated lists ----
@@ -280,10 +284,19 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
     }
     const uint64_t m = __ballot(again);  // every lane of the wave takes part
     if (again) {
-      my_second[lanes_below(m, n_second)] = (uint16_t) again_id;
+      const int pos = lanes_below(m, n_second);
+      if (pos < kSecondCap) {
+        my_second[pos] = (uint16_t) again_id;
+      } else {  // list full: the lane looks at the dark arcs itself
+        const int best = arc_best(tile8 + again_id, true);
+        if (best > t) {
+          resp8[again_id] = (uint8_t) (best - 1);
+        }
+      }
     }
     n_second += __popcll(m);
   }
+  n_second = n_second < kSecondCap ? n_second : kSecondCap;
   for (int base = 0; base < n_second; base += 64) {  // this wave's own list: LDS operations of a wave complete in order
     const int j = base + lane;
     if (j < n_second) {
@@ -294,6 +307,26 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
       }
     }
   }
+  __syncthreads();  // the lists are dead: their bytes hold the horizontal sums from here on
+  // ---- 7x7 Gaussian, horizontal pass: tile rows -3 .. kTileH+2, four sums per lane, stored as packed 16-bit lanes:
+  // 55 c + 49 (l1 + r1) + 34 (l2 + r2) + 18 (l3 + r3) <= 257 * 255 = 65535 fits the lane exactly.
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int h = r0 + 16 * k;
+    if (h < kTileH + 6) {
+      const int wi      = (h + 1) * kTileWords + 1 + w1;
+      const uint32_t C = tile32[wi], L = tile32[wi - 1], R = tile32[wi + 1];
+      // pixel x = 4 w + j: bytes x-3 .. x against (18, 34, 49, 55) and bytes x+1 .. x+4 against (49, 34, 18, 0), two v_dot4_u32_u8
+      constexpr uint32_t kTapsLeft = kG0 | (kG1 << 8) | (kG2 << 16) | (kG3 << 24), kTapsRight = kG2 | (kG1 << 8) | (kG0 << 16);
+      const uint32_t s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, L, 1), kTapsLeft, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 1), kTapsRight, 0u, false), false);
+      const uint32_t s1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, L, 2), kTapsLeft, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 2), kTapsRight, 0u, false), false);
+      const uint32_t s2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, L, 3), kTapsLeft, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 3), kTapsRight, 0u, false), false);
+      const uint32_t s3 = __builtin_amdgcn_udot4(C, kTapsLeft, __builtin_amdgcn_udot4(R, kTapsRight, 0u, false), false);
+      const uint32_t sum[2] = {s0 | (s2 << 16), s1 | (s3 << 16)};
+      hsum64[h * 16 + w1] = ((uint64_t) sum[1] << 32) | sum[0];  // lanes: pixel 0 | pixel 2 , pixel 1 | pixel 3
+    }
+  }
+  __syncthreads();
   // ---- Gaussian, vertical pass, straight to memory: (sum + 2^15) >> 16, saturated (the taps sum to 257 / 256) ----
   uint8_t* __restrict__ blur = a.blur + (size_t) img * rows * cols;
 #pragma unroll
@@ -380,12 +413,16 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
   }
 }
 
-__global__ __launch_bounds__(kFastThreads) void fast_blur_kernel(const FeatureArgs a) {
+__global__ __launch_bounds__(kFastThreads, 8) void fast_blur_kernel(const FeatureArgs a) {  // 8 workgroups of 4 waves per CU
   __shared__ __attribute__((aligned(16))) uint32_t tile32[kTileRows * kTileWords];
   __shared__ __attribute__((aligned(16))) uint32_t resp32[kTileRows * kTileWords];  // same geometry as the tile
-  __shared__ __attribute__((aligned(16))) uint64_t hsum64[(kTileH + 6) * 16];       // horizontal 7-tap sums, four u16 per item
-  __shared__ uint16_t list[kFastThreads / 64][kListCap];
-  __shared__ uint16_t second[kFastThreads / 64][kSecondCap];
+  // the survivor lists (compass -> arc passes) and the Gaussian's horizontal sums (horizontal -> vertical pass) share their bytes
+  constexpr size_t kListBytes = sizeof(uint16_t) * (kFastThreads / 64) * (kListCap + kSecondCap);
+  constexpr size_t kHsumBytes = sizeof(uint64_t) * (kTileH + 6) * 16;
+  __shared__ __attribute__((aligned(16))) unsigned char shared_bytes[kListBytes > kHsumBytes ? kListBytes : kHsumBytes];
+  uint64_t* hsum64 = reinterpret_cast<uint64_t*>(shared_bytes);  // horizontal 7-tap sums, four u16 per item
+  uint16_t (*list)[kListCap]     = reinterpret_cast<uint16_t (*)[kListCap]>(shared_bytes);
+  uint16_t (*second)[kSecondCap] = reinterpret_cast<uint16_t (*)[kSecondCap]>(shared_bytes + sizeof(uint16_t) * (kFastThreads / 64) * kListCap);
   __shared__ int list_n[kFastThreads / 64];
   const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
   // a tile whose halo lies inside the image needs no coordinate checks at all (block-uniform)
