@@ -245,7 +245,7 @@ constexpr int kPairs = 16;  // the 29 sums + 3 class counts of one linearisation
 //   12..15  H22 H23 H24 H25             16  -            17..19  H33 H34 H35
 //   20..21  H44 H45                     22  -            23      H55
 //   24..29  b0..b5                      30  chi (inliers only)   31  chi (all, kernelised ones saturated)
-constexpr float kClsOutUnit = 2048.0f;  // > the largest number of correspondences of a frame handled here (1024)
+constexpr float kClsOutUnit = 2048.0f;  // > the largest number of correspondences of a frame (align_batch_launch refuses max_fixed >= 2048)
 constexpr int kSlotCls = 6, kSlotUnusedA = 16, kSlotUnusedB = 22;
 
 // One correspondence of SE3{,Depth,RectifiedStereo}ProjectiveErrorFactor::errorAndJacobian + saturated robustifier,
