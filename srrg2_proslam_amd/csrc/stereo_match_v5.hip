@@ -93,6 +93,19 @@ __device__ __forceinline__ int below(const q32& q, uint32_t bound) {
   return __popc(below_bits(0u, q, bound));
 }
 
+// inclusive prefix sum over the 64 lanes of a wave on the DPP network (round 4; was six ds_bpermute round trips): Hillis-Steele inside
+// every row of 16 lanes (row_shr 1, 2, 4, 8, lanes shifted in from outside a row read 0), then lane 15 of rows 0 / 2 onto rows 1 / 3
+// (row_bcast:15) and lane 31 onto the upper half (row_bcast:31)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, true);  // row_shr:1
+  v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, true);  // row_shr:2
+  v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, true);  // row_shr:4
+  v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, true);  // row_shr:8
+  v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
+  v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 // ONE wave: start[r] = sum over r' < r of the count rounded up to a multiple of four, len[r] = count
 __device__ __forceinline__ void wave_padded_scan(const uint32_t* hist, uint16_t* start, uint16_t* len, int n) {
   const int lane  = threadIdx.x & 63;
@@ -113,15 +126,8 @@ __device__ __forceinline__ void wave_padded_scan(const uint32_t* hist, uint16_t*
       sum += r < n ? ((hist[r] + 3u) & ~3u) : 0u;
     }
   }
-  uint32_t incl = sum;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t o = __shfl_up(incl, d, 64);
-    if (lane >= d) {
-      incl += o;
-    }
-  }
-  uint32_t run = incl - sum;
+  const uint32_t incl = wave_inclusive_scan(sum);
+  uint32_t run        = incl - sum;
   if (chunk <= 8) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -165,15 +171,8 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t* cnt, int n) {
       sum += r < n ? cnt[r] : 0u;
     }
   }
-  uint32_t incl = sum;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t o = __shfl_up(incl, d, 64);
-    if (lane >= d) {
-      incl += o;
-    }
-  }
-  uint32_t run = incl - sum;
+  const uint32_t incl = wave_inclusive_scan(sum);
+  uint32_t run        = incl - sum;
   if (chunk <= 8) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
