@@ -102,9 +102,9 @@ template <int KIND>
 static void run(const char* name, uint32_t* out, long long* cyc, int cus) {
   const int iters = 2048;
   printf("%-18s", name);
-  for (int waves_per_simd : {1, 2, 4, 8}) {
+  for (int waves_per_simd : {1, 2, 3, 4, 5, 6, 8}) {
     const int waves_per_cu  = 4 * waves_per_simd;
-    const int blocks_per_cu = waves_per_cu > 16 ? 2 : 1;
+    const int blocks_per_cu = waves_per_cu > 16 ? 2 : 1;  // (two workgroups per CU beyond 1024 threads)
     const int threads       = 64 * waves_per_cu / blocks_per_cu;
     hipMemset(cyc, 0, sizeof(long long) * cus * 2);
     hipLaunchKernelGGL(probe<KIND>, dim3(cus * blocks_per_cu), dim3(threads), 0, 0, out, cyc, iters);
@@ -127,7 +127,7 @@ int main() {
   hipMalloc(&out, sizeof(uint32_t) * 1024 * cus * 2);
   hipMalloc(&cyc, sizeof(long long) * cus * 2);
   printf("gfx950, %d CUs: wave64 vector instructions per clock64 tick and CU (eight independent chains per wave, all CUs busy)\n", cus);
-  printf("%-18s  1 w/SIMD  2      4      8\n", "instruction");
+  printf("%-18s  1 w/SIMD  2      3      4      5      6      8\n", "instruction");
   run<ADD>("v_add_u32", out, cyc, cus);
   run<XOR>("v_xor_b32", out, cyc, cus);
   run<MINU>("v_min_u32", out, cyc, cus);
