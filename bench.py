@@ -27,6 +27,7 @@ Rank 0 prints ONE JSON line (contract in the task statement).  Besides the contr
                     RGB-D (640x480, depth-projective path), KITTI at 1000 keypoints per image; a few steps each, with a parity check
   closed_loop       the stateful per-frame loop (matcher -> clipper -> finder / aligner + motion prior -> pose update -> merger) along
                     the KITTI-00 trajectory, checked frame by frame against the same loop on the CPU checker
+  from_images       pixels to poses on the device: extractor (both images) -> matcher -> finder + aligner on the reference's KITTI images, tiled
   latency_b1        ONE sequence, one frame at a time through the C++ plugin adapters (AoS clouds, gather timed) and through the bare
                     C-ABI with host pointers (PCIe, launches, synchronisation included), the CPU checker on the same frames beside it
   cpu_baseline      the single-threaded CPU restatement ("port") timed on a bounded sample of the same frames on this box's host
@@ -452,10 +453,69 @@ def kitti_real_frames(device_index, cfg, target):
     frames = []
     for a, b in ((0, 1), (1, 2), (2, 3), (3, 4), (5, 6)):
         prev, cur = per_pair[a], per_pair[b]
+        key, idx = ("city", b) if b < 5 else ("highway", b - 5)
         frames.append({"fr": {"uv_left": cur["uvl"], "desc_left": cur["dl"], "uv_right": cur["uvr"], "desc_right": cur["dr"]},
                        "mp": {"xyz": prev["xyz"].astype(np.float32), "desc": prev["desc"], "n_opt": np.zeros(len(prev["xyz"]), np.uint32)},
-                       "X0": np.eye(4, dtype=np.float32), "T": np.eye(4, dtype=np.float32)})
+                       "X0": np.eye(4, dtype=np.float32), "T": np.eye(4, dtype=np.float32),
+                       "images": (z[key + "_left"][idx], z[key + "_right"][idx])})
     return frames
+
+
+def from_images_leg(device_index, cfg, frames, poses, batch, target, steps=3):
+    """pixels -> poses on the device: FAST + binned selection + ORB of BOTH images of every stereo pair, epipolar matcher + triangulator,
+    projective finder + GN aligner, everything on device-resident buffers (the extractor writes the matcher's input arrays in place).
+    `frames` / `poses`: the five real KITTI frames of kitti_real_frames and what the CPU checker makes of their host-extracted features."""
+    import torch
+    from srrg2_proslam_amd import ops
+    stride = 2048
+    w = FrameWorkload(cfg, device_index, batch, stride, stride, 1024, len(frames), 0, frames=frames)
+    dev = w.dev
+    idx = torch.arange(batch, device=dev) % len(frames)
+    img_l = torch.from_numpy(np.stack([f["images"][0] for f in frames])).to(dev)[idx].contiguous()
+    img_r = torch.from_numpy(np.stack([f["images"][1] for f in frames])).to(dev)[idx].contiguous()
+    ep = ops.extractor_params(threshold=15, target=target, vertical=3, horizontal=3, selection_order=ops.SELECT_LIBSTDCXX)
+    st_l = torch.zeros((batch,), dtype=torch.int32, device=dev)
+    st_r = torch.zeros((batch,), dtype=torch.int32, device=dev)
+    sf = w.sframes
+    want_nl, want_nr = sf.n_left.clone(), sf.n_right.clone()  # counts of the host-extracted features (uploaded by the constructor)
+
+    def step(ev=None):
+        if ev:
+            ev[3].record()
+        ops.extract_features_batch(w.ctx, ep, img_l, sf.left_kp, sf.left_desc, sf.n_left, st_l)
+        ops.extract_features_batch(w.ctx, ep, img_r, sf.right_kp, sf.right_desc, sf.n_right, st_r)
+        w.step(ev)
+
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        w.ctx.use_torch_stream()
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        step(ev)
+        torch.cuda.synchronize()
+        snap = w.snapshot()
+        ok, _ = w.check(snap)
+    if int(st_l.min().item()) < 0 or int(st_r.min().item()) < 0:
+        raise SystemExit("extractor reported error %d" % min(int(st_l.min().item()), int(st_r.min().item())))
+    same_counts = bool(torch.equal(sf.n_left, want_nl)) and bool(torch.equal(sf.n_right, want_nr))
+    out = {"workload": "pixels to poses: %d stereo pairs (the reference's KITTI images, tiled) per step: FAST 15 + 3 x 3 binned selection (libstdc++ order) + ORB-256 of "
+                       "both images (target %d keypoints), epipolar matcher + triangulator, projective circle finder against the previous frame's points, "
+                       "stereo GN aligner; all on device buffers" % (batch, target),
+           "value": batch * steps / dt, "unit": "stereo frames/s", "images_per_second": 2 * batch * steps / dt, "ms_per_step": dt / steps * 1e3,
+           "frames_per_step": batch,
+           "ms_per_stage": {"extract (2 images per frame)": ev[3].elapsed_time(ev[0]), "stereo_match": ev[0].elapsed_time(ev[1]), "align": ev[1].elapsed_time(ev[2])},
+           "aligner_success_fraction": ok,
+           "parity": dict(w.parity(snap, poses), feature_counts_equal_host_extraction=same_counts)}
+    w.close()
+    del w, img_l, img_r
+    torch.cuda.empty_cache()
+    return out
 
 
 def kitti_real_leg(device_index, cfg, batch, target=2000, steps=3):
@@ -492,6 +552,10 @@ def kitti_real_leg(device_index, cfg, batch, target=2000, steps=3):
     w.close()
     del w
     torch.cuda.empty_cache()
+    try:
+        out["from_images"] = from_images_leg(device_index, cfg, frames, poses, min(batch, 2048), target)
+    except SystemExit as exc:
+        out["from_images"] = {"error": str(exc)}
     return out
 
 
@@ -833,6 +897,13 @@ def main():
         "roofline_search": roof_search,
         "roofline_gn": roof_gn,
         "roofline_matcher": roof_match,
+        # SURVEY 8(d) single-pass definition of a tracked frame (inputs read once, outputs written once, everything else on chip):
+        # 40 (N_L + N_R) + 29 M + 48 N_m + 64 + 12 N_c + 64 bytes, against the whole step's time
+        "roofline_whole_step": (lambda bytes_frame: {
+            "bound": "hbm", "achieved": B * world * bytes_frame / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
+            "frac": B * bytes_frame / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_frame": bytes_frame,
+            "note": "the step is bound by vector issue (GN, search) and by the serial 100-iteration chain, not by HBM: this is the figure SURVEY 8(d) "
+                    "prices the whole frame with"})(40.0 * (2 * N) + 29.0 * n_match + 48.0 * NM + 64 + 12.0 * n_corr + 64),
         "kernel_time_share": {"stereo_match5_kernel": ms_match / total_k, "align_kernel (search)": ms_search / total_k, "gn_kernel": ms_gn / total_k},
         "kernel_timing": "HIP events on the launch stream in a separate pass of %d steps after the timed loop (the timed loop carries no events)" % max(args.timing_steps, 1),
     }
@@ -886,6 +957,8 @@ def main():
                 others[name] = {"error": str(exc)}
         try:
             others["kitti_real"] = kitti_real_leg(local_rank, cfg, small)
+            if "from_images" in others["kitti_real"]:
+                out["from_images"] = others["kitti_real"].pop("from_images")
         except (SystemExit, OSError, KeyError) as exc:
             others["kitti_real"] = {"error": str(exc)}
         out["other_configs"] = others
