@@ -51,7 +51,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
             if "prs::" in r["Kernel_Name"]:
                 acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         summary[name] = {k: {c: {"launches": len(v), "mean": sum(v) / len(v)} for c, v in d.items()} for k, d in acc.items()}
-summary["frames_per_launch"] = int(os.environ.get("PRS_PROFILE_BATCH", "18432"))
+summary["frames_per_launch"] = int(os.environ.get("PRS_PROFILE_BATCH", "55296"))
 summary["keypoints_per_image"] = int(os.environ.get("PRS_PROFILE_KEYPOINTS", "2000"))
 json.dump(summary, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps(summary.get("per_launch_ms", {}), indent=1))
