@@ -950,7 +950,7 @@ def main():
 
     # ---- the other BASELINE configurations and the stateful loop, outside the headline timing (rank 0, single GPU) ----
     if rank == 0 and world == 1 and not args.no_other_configs:
-        small = min(B, 4608)
+        small = min(B, 6144)  # 24 frames per CU: whole resident sets of the GN kernel (8 frames per CU) and of the search kernel (3)
         others = {}
         for name, cname, kp, mv, mf, cidx in (("euroc", "euroc", 1000, 1000, 512, 2), ("tum", "tum", 1000, 1000, 1024, 3), ("kitti_n1000", "kitti", 1000, 1000, 512, 1)):
             try:

@@ -13,7 +13,7 @@ LEGS = {"euroc": ("euroc", 1000, 1000, 512, 2), "tum": ("tum", 1000, 1000, 1024,
 
 if __name__ == "__main__":
     name = sys.argv[1] if len(sys.argv) > 1 else "tum"
-    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 4608
+    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 6144
     if name == "kitti_real":
         print(json.dumps(bench.kitti_real_leg(0, configs.get("kitti"), batch)))
     else:
