@@ -133,7 +133,7 @@ class AlignResult(C.Structure):
 class Variant(C.Structure):
     """orc_variant: sweep switches for the BUILD-DEFINED arithmetic of rows a13 / a14 (tools/sweep_a13.py); all zero = shipped"""
     _fields_ = [("kernel_form", C.c_int32), ("idw_form", C.c_int32), ("damping_form", C.c_int32), ("v_row", C.c_int32),
-                ("chi_compare", C.c_int32), ("bounds_form", C.c_int32)]
+                ("chi_compare", C.c_int32), ("bounds_form", C.c_int32), ("accum_form", C.c_int32)]
 
 
 def build(force=False):

@@ -1232,6 +1232,16 @@ static inline void orc_sum128_fma3(orc_sum128* s, int index, float a0, float b0,
   *leaf       = fmaf(a2, b2, fmaf(a1, b1, fmaf(a0, b0, *leaf)));
 }
 
+/* leaf <- a*b + leaf and leaf <- a1*b1 + (a0*b0 + leaf) */
+static inline void orc_sum128_fma1(orc_sum128* s, int index, float a, float b) {
+  float* leaf = &s->leaf[index & (ORC_SUM_LEAVES - 1)];
+  *leaf       = fmaf(a, b, *leaf);
+}
+static inline void orc_sum128_fma2(orc_sum128* s, int index, float a0, float b0, float a1, float b1) {
+  float* leaf = &s->leaf[index & (ORC_SUM_LEAVES - 1)];
+  *leaf       = fmaf(a1, b1, fmaf(a0, b0, *leaf));
+}
+
 static float orc_sum128_result(const orc_sum128* s) {
   static const int level_mask[7] = {32, 16, 8, 7, 2, 1, 64};
   float v[ORC_SUM_LEAVES];
@@ -1278,6 +1288,43 @@ static void pose_to_camera(const orc_aligner_params* P, const float* X, float* A
     orc_se3_mul(Si, X, A);
   } else {
     memcpy(A, X, 16 * sizeof(float));
+  }
+}
+
+/* the device's test (csrc/align.hip pose_is_finite): the sum of the twelve entries, in this order, is finite */
+static int pose_is_finite12(const float* X) {
+  const float s = ((((X[0] + X[1]) + (X[2] + X[3])) + ((X[4] + X[5]) + (X[6] + X[7]))) + ((X[8] + X[9]) + (X[10] + X[11])));
+  return (s - s) == 0.0f;
+}
+
+/* camera frame -> tangent space of the estimate: H <- Rt^T H Rt, b <- Rt^T b with Rt = blockdiag(R, R), R the rotation of A.
+ * Row r = 3 * blk + i of the result: v = (column i of R)^T Y, out = v R for the two 3 x 3 blocks Y of block row blk; the rotated
+ * matrix is symmetric up to rounding: its LOWER triangle (row >= column) is the system and is mirrored into the upper one
+ * (BUILD-DEFINED; csrc/prs_se3.h rotate_normal_equations performs the same operations). */
+static void rotate_normal_equations(const float* A, float* H, float* b) {
+  float Hn[36], bn[6];
+  for (int r = 0; r < 6; ++r) {
+    const int blk = r >= 3 ? 1 : 0;
+    const int i   = r - 3 * blk;
+    const float Ri0 = A[i], Ri1 = A[4 + i], Ri2 = A[8 + i];
+    const float* Y = H + 18 * blk;
+    for (int cb = 0; cb < 2; ++cb) {
+      float v[3];
+      for (int c = 0; c < 3; ++c) {
+        v[c] = fmaf(Ri2, Y[12 + 3 * cb + c], fmaf(Ri1, Y[6 + 3 * cb + c], Ri0 * Y[3 * cb + c]));
+      }
+      for (int j = 0; j < 3; ++j) {
+        Hn[6 * r + 3 * cb + j] = fmaf(v[2], A[8 + j], fmaf(v[1], A[4 + j], v[0] * A[j]));
+      }
+    }
+    bn[r] = fmaf(Ri2, b[3 * blk + 2], fmaf(Ri1, b[3 * blk + 1], Ri0 * b[3 * blk]));
+  }
+  for (int r = 0; r < 6; ++r) {
+    for (int c = 0; c <= r; ++c) {
+      H[6 * r + c] = Hn[6 * r + c];
+      H[6 * c + r] = Hn[6 * r + c];
+    }
+    b[r] = bn[r];
   }
 }
 
@@ -1375,36 +1422,11 @@ void orc_linearize_ex(const orc_aligner_params* P,
 
     /* J = D * R * [ wt*I | -2 [p]x ]  (3x6), D = d(image point)/d(point in camera):
      *   row 0 (u):  (fx/z, 0, (cx - u)/z)     row 1 (v):  (0, fy/z, (cy - v)/z)
-     *   row 2:      stereo (uR): (fx/z, 0, (cx - uR)/z); depth: (0, 0, 1); mono: none.
-     * Evaluated as Q = D * R (three 3-vectors), then J_i = ( wt * Q_i | a x Q_i ) with a = 2 p
-     * (Q_i * (-2 [p]x) = a x Q_i).  BUILD-DEFINED operation order, one rounding per line. */
-    const float ax = 2.0f * px, ay = 2.0f * py, az = 2.0f * pz;
-    const float Rm[3][3] = {{R00, R01, R02}, {R10, R11, R12}, {R20, R21, R22}};
+     *   row 2:      stereo (uR): (fx/z, 0, (cx - uR)/z); depth: (0, 0, 1); mono: none. */
     const float alpha = fx * iz, gamma = fy * iz;
     const float beta0 = (cx - u_pred) * iz;
     const float beta1 = (cy - v_pred) * iz;
     const float beta2 = (cx - hrx * iz) * iz; /* stereo only */
-    float Q[3][3];
-    for (int c = 0; c < 3; ++c) {
-      Q[0][c] = fmaf(alpha, Rm[0][c], beta0 * Rm[2][c]);
-      Q[1][c] = fmaf(gamma, Rm[1][c], beta1 * Rm[2][c]);
-      if (dim == ORC_FACTOR_STEREO) {
-        Q[2][c] = fmaf(alpha, Rm[0][c], beta2 * Rm[2][c]);
-      } else if (dim == ORC_FACTOR_DEPTH) {
-        Q[2][c] = Rm[2][c];
-      } else {
-        Q[2][c] = 0.0f;
-      }
-    }
-    float J[3][6];
-    for (int i = 0; i < 3; ++i) {
-      J[i][0] = Q[i][0] * wt;
-      J[i][1] = Q[i][1] * wt;
-      J[i][2] = Q[i][2] * wt;
-      J[i][3] = fmaf(ay, Q[i][2], -(az * Q[i][1]));
-      J[i][4] = fmaf(az, Q[i][0], -(ax * Q[i][2]));
-      J[i][5] = fmaf(ax, Q[i][1], -(ay * Q[i][0]));
-    }
 
     /* Omega = diag(info) * scale(moving) (aligner_slice_processor_projective.cpp:46-56) */
     const float s = info_scale ? info_scale[m] : 1.0f;
@@ -1450,17 +1472,87 @@ void orc_linearize_ex(const orc_aligner_params* P,
     }
     orc_sum128_add(&sums[28], ic, chi);
 
-    /* H += J^T Omega J (upper), b += J^T Omega e: the three products of an entry are accumulated into the
-     * correspondence's leaf with fused multiply-adds (leaf <- j0*J0 + leaf, then j1*J1, then j2*J2) */
-    int t = 0;
-    for (int r = 0; r < 6; ++r) {
-      const float j0 = J[0][r] * o[0];
-      const float j1 = J[1][r] * o[1];
-      const float j2 = J[2][r] * o[2];
-      for (int c = r; c < 6; ++c) {
-        orc_sum128_fma3(&sums[t++], ic, j0, J[0][c], j1, J[1][c], j2, J[2][c]);
+    if (g_variant.accum_form == 1) {
+      /* the rounds 1-3 evaluation (kept for tests/test_oracle_aligner_ext.py: both forms are the same normal equations up to
+       * rounding): Q = D * R, J_i = ( wt * Q_i | a x Q_i ) with a = 2 p, every entry of J^T Omega J / J^T Omega e through three
+       * fused multiply-adds, sums in the tangent space of X directly */
+      const float ax = 2.0f * px, ay = 2.0f * py, az = 2.0f * pz;
+      const float Rm[3][3] = {{R00, R01, R02}, {R10, R11, R12}, {R20, R21, R22}};
+      float Q[3][3], J[3][6];
+      for (int c = 0; c < 3; ++c) {
+        Q[0][c] = fmaf(alpha, Rm[0][c], beta0 * Rm[2][c]);
+        Q[1][c] = fmaf(gamma, Rm[1][c], beta1 * Rm[2][c]);
+        Q[2][c] = dim == ORC_FACTOR_STEREO ? fmaf(alpha, Rm[0][c], beta2 * Rm[2][c]) : (dim == ORC_FACTOR_DEPTH ? Rm[2][c] : 0.0f);
       }
-      orc_sum128_fma3(&sums[21 + r], ic, j0, e[0], j1, e[1], j2, e[2]);
+      for (int i = 0; i < 3; ++i) {
+        J[i][0] = Q[i][0] * wt;
+        J[i][1] = Q[i][1] * wt;
+        J[i][2] = Q[i][2] * wt;
+        J[i][3] = fmaf(ay, Q[i][2], -(az * Q[i][1]));
+        J[i][4] = fmaf(az, Q[i][0], -(ax * Q[i][2]));
+        J[i][5] = fmaf(ax, Q[i][1], -(ay * Q[i][0]));
+      }
+      int t = 0;
+      for (int r = 0; r < 6; ++r) {
+        const float j0 = J[0][r] * o[0];
+        const float j1 = J[1][r] * o[1];
+        const float j2 = J[2][r] * o[2];
+        for (int c = r; c < 6; ++c) {
+          orc_sum128_fma3(&sums[t++], ic, j0, J[0][c], j1, J[1][c], j2, J[2][c]);
+        }
+        orc_sum128_fma3(&sums[21 + r], ic, j0, e[0], j1, e[1], j2, e[2]);
+      }
+      continue;
+    }
+
+    /* CAMERA-FRAME sums (BUILD-DEFINED operation order, one rounding per fmaf / product; the device performs the same,
+     * csrc/align.hip factor_accumulate).  R [a]x = [R a]x R, so J = D G_c Rt with G_c = [ wt I | -[y]x ], y = 2 R p and
+     * Rt = blockdiag(R, R), the same for every correspondence: summed are G_c^T K G_c (K = D^T Omega D, K01 = 0) and
+     * G_c^T D^T Omega e; Rt is applied once to the summed system below (rotate_normal_equations). */
+    {
+      const float d20 = dim == ORC_FACTOR_STEREO ? alpha : 0.0f;
+      const float d22 = dim == ORC_FACTOR_STEREO ? beta2 : (dim == ORC_FACTOR_DEPTH ? 1.0f : 0.0f);
+      const float yx = 2.0f * (pcx - t0), yy = 2.0f * (pcy - t1), yz = 2.0f * (pcz - t2);
+      const float p0 = o[0] * alpha, p2 = o[2] * d20, g1 = o[1] * gamma, q0 = o[0] * beta0, q1 = o[1] * beta1, q2 = o[2] * d22;
+      const float K00 = fmaf(p2, d20, p0 * alpha), K02 = fmaf(p2, d22, p0 * beta0), K11 = g1 * gamma, K12 = g1 * beta1;
+      const float K22 = fmaf(q2, d22, fmaf(q1, beta1, q0 * beta0));
+      const float w0 = o[0] * e[0], w1 = o[1] * e[1], w2 = o[2] * e[2];
+      const float r0 = fmaf(d20, w2, alpha * w0), r1 = gamma * w1, r2 = fmaf(d22, w2, fmaf(beta1, w1, beta0 * w0));
+      /* N = K [y]x */
+      const float N00 = -(K02 * yy), N01 = fmaf(K02, yx, -(K00 * yz)), N02 = K00 * yy;
+      const float N10 = fmaf(K11, yz, -(K12 * yy)), N11 = K12 * yx, N12 = -(K11 * yx);
+      const float N20 = fmaf(K12, yz, -(K22 * yy)), N21 = fmaf(K22, yx, -(K02 * yz)), N22 = fmaf(K02, yy, -(K12 * yx));
+      const float wt2 = wt * wt, nwt = -wt;
+      /* upper triangle, row-major: (0,0) 0, (0,1) 1 [receives nothing], (0,2) 2, (0,3..5) 3..5, (1,1) 6, (1,2) 7, (1,3..5) 8..10,
+       * (2,2) 11, (2,3..5) 12..14, (3,3) 15, (3,4) 16, (3,5) 17, (4,4) 18, (4,5) 19, (5,5) 20 */
+      orc_sum128_fma1(&sums[0], ic, wt2, K00);
+      orc_sum128_fma1(&sums[2], ic, wt2, K02);
+      orc_sum128_fma1(&sums[6], ic, wt2, K11);
+      orc_sum128_fma1(&sums[7], ic, wt2, K12);
+      orc_sum128_fma1(&sums[11], ic, wt2, K22);
+      orc_sum128_fma1(&sums[3], ic, nwt, N00);
+      orc_sum128_fma1(&sums[4], ic, nwt, N01);
+      orc_sum128_fma1(&sums[5], ic, nwt, N02);
+      orc_sum128_fma1(&sums[8], ic, nwt, N10);
+      orc_sum128_fma1(&sums[9], ic, nwt, N11);
+      orc_sum128_fma1(&sums[10], ic, nwt, N12);
+      orc_sum128_fma1(&sums[12], ic, nwt, N20);
+      orc_sum128_fma1(&sums[13], ic, nwt, N21);
+      orc_sum128_fma1(&sums[14], ic, nwt, N22);
+      /* H_rr = [y]x^T N */
+      orc_sum128_fma2(&sums[15], ic, -yy, N20, yz, N10);
+      orc_sum128_fma2(&sums[16], ic, -yy, N21, yz, N11);
+      orc_sum128_fma2(&sums[17], ic, -yy, N22, yz, N12);
+      orc_sum128_fma2(&sums[18], ic, -yz, N01, yx, N21);
+      orc_sum128_fma2(&sums[19], ic, -yz, N02, yx, N22);
+      orc_sum128_fma2(&sums[20], ic, -yx, N12, yy, N02);
+      /* b = G_c^T r */
+      orc_sum128_fma1(&sums[21], ic, wt, r0);
+      orc_sum128_fma1(&sums[22], ic, wt, r1);
+      orc_sum128_fma1(&sums[23], ic, wt, r2);
+      orc_sum128_fma2(&sums[24], ic, -yz, r1, yy, r2);
+      orc_sum128_fma2(&sums[25], ic, -yx, r2, yz, r0);
+      orc_sum128_fma2(&sums[26], ic, -yy, r0, yx, r1);
     }
   }
   int t = 0;
@@ -1474,6 +1566,9 @@ void orc_linearize_ex(const orc_aligner_params* P,
   }
   out->chi_inliers = orc_sum128_result(&sums[27]);
   out->chi_total   = orc_sum128_result(&sums[28]);
+  if (g_variant.accum_form != 1 && pose_is_finite12(X)) { /* (a pose that is not finite: every correspondence was invalid, the sums are zero) */
+    rotate_normal_equations(X, out->H, out->b);
+  }
 }
 
 /* IterationAlgorithmGN with damping + dense Cholesky (configurations/kitti.conf:20-22,310-315)

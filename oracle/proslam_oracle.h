@@ -243,6 +243,7 @@ typedef struct {
   int32_t v_row;        /* stereo row 1 measurement: 0 vL; 1 (vL + vR) / 2 */
   int32_t chi_compare;  /* 0 kernel active when chi > tau; 1 when chi >= tau */
   int32_t bounds_form;  /* 0 prediction must lie in [0, cols] x [0, rows]; 1 no image test; 2 [0, cols) x [0, rows) */
+  int32_t accum_form;   /* 0 camera-frame sums + one rotation of the summed system (shipped); 1 J^T Omega J entry by entry (rounds 1-3) */
 } orc_variant;
 void orc_set_variant(const orc_variant* v);
 

@@ -237,10 +237,9 @@ __device__ __forceinline__ float inverse_depth_weight(const float4 z, const floa
 }
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kPairs = 16;  // the 29 sums + 3 class counts of one linearisation travel as 16 float pairs (32 "slots")
-// slot (= 2 * pair + component) -> meaning.  The upper triangle of J^T Omega J is produced row by row as float pairs
-// (v_pk_fma_f32); where a row starts on the second element of a pair, the first element is the mirrored entry and is
-// not used.  The first of those three places carries the class counts into the reduction: #inliers + kClsOutUnit *
-// #kernelised as one float (an exact integer below 2^24, so its sum does not depend on the order).
+// slot (= 2 * pair + component) -> meaning: the upper triangle of the CAMERA-FRAME normal equations row by row (factor_accumulate),
+// rows starting on even slots; the three slots in between are free, the first of them carries the class counts into the reduction:
+// #inliers + kClsOutUnit * #kernelised as one float (an exact integer below 2^24, so its sum does not depend on the order).
 //    0..5   H00 H01 H02 H03 H04 H05      6  class counts  7..11  H11 H12 H13 H14 H15
 //   12..15  H22 H23 H24 H25             16  -            17..19  H33 H34 H35
 //   20..21  H44 H45                     22  -            23      H55
@@ -249,44 +248,44 @@ constexpr float kClsOutUnit = 2048.0f;  // > the largest number of correspondenc
 constexpr int kSlotCls = 6, kSlotUnusedA = 16, kSlotUnusedB = 22;
 
 // One correspondence of SE3{,Depth,RectifiedStereo}ProjectiveErrorFactor::errorAndJacobian + saturated robustifier,
-// ACCUMULATED into the 16 pairs above (the running sums of this lane's leaf of the fixed-shape sum): every entry of
-// J^T Omega J and J^T Omega e enters through three fused multiply-adds, acc <- j0 * J0 + acc, then j1 * J1, then j2 * J2.
+// ACCUMULATED into the 16 pairs above (the running sums of this lane's leaf of the fixed-shape sum).
 // cls: 0 inlier, 1 kernelised, 2 invalid (behind the camera / outside the image), 3 inactive.
-// J = D * R * [ wt I | -2 [p]x ] with D = d(image point) / d(point in camera) is evaluated as Q = D * R (three 3-vectors)
-// and J_i = ( wt Q_i | a x Q_i ), a = 2 p.
+// CAMERA-FRAME sums (round 4): with [R | t] the transform the point goes through and D = d(image point) / d(point in camera),
+//   J = D R [ wt I | -2 [p]x ] = D G_c Rt,   G_c = [ wt I | -[y]x ],  y = 2 R p,  Rt = blockdiag(R, R)      (R [a]x = [R a]x R)
+// so J^T Omega J = Rt^T (G_c^T K G_c) Rt with K = D^T Omega D and J^T Omega e = Rt^T G_c^T (D^T Omega e): what is summed over the
+// correspondences is the bracket (K has five distinct non-zero entries, no product with R), and Rt, the same for all of them, is
+// applied ONCE to the summed system (prs_se3.h, rotate_normal_equations).  ~85 instead of ~160 issue slots per correspondence.
+//   D rows: (alpha, 0, beta0), (0, gamma, beta1), (d20, 0, d22): stereo (alpha, beta2), depth (0, 1), mono (0, 0)
+//   K00 = o0 alpha^2 + o2 d20^2, K02 = o0 alpha beta0 + o2 d20 d22, K11 = o1 gamma^2, K12 = o1 gamma beta1, K22 = sum o_i d_i2^2, K01 = 0
+//   N = K [y]x;  H_tt += wt^2 K,  H_tr -= wt N,  H_rr += [y]x^T N,  b_t += wt r,  b_r += y x r,  r = D^T Omega e
+// Every entry enters its running sum through fused multiply-adds in the order written below (the CPU checker performs the same).
 template <int DIM = 0, bool PRE_WT = false>
 __device__ __forceinline__ void factor_accumulate(const prs_aligner_params& a, const PoseRegs& X, const float4 z, const float4 p_in,
                                                   const float mean_dsp, const bool active, f2* acc, float& code, int& cls, const bool inlier_only = false) {
   // Straight-line on purpose: with the terms live out of nested divergent branches the compiler re-materialises
   // all zeros at every nesting level.  A correspondence that is inactive (slot past the end) or invalid (behind the
-  // camera / outside the image) runs the same arithmetic on harmless stand-in values (point 0, image point 0,
-  // inverse depth 0) with zero information and zero error: every product is then +-0, and a fixed-shape sum that is
-  // normalised with + 0.0f at its root does not see the sign of a zero.  Valid correspondences execute exactly
-  // the operations of the sequential evaluation.
-  const float R00 = X.R00, R01 = X.R01, R02 = X.R02, t0 = X.t0;
-  const float R10 = X.R10, R11 = X.R11, R12 = X.R12, t1 = X.t1;
-  const float R20 = X.R20, R21 = X.R21, R22 = X.R22, t2 = X.t2;
+  // camera / outside the image) runs the same arithmetic on harmless stand-in values (inverse depth 0, y = 0,
+  // zero information): every product is then +-0, and a fixed-shape sum that is normalised with + 0.0f at its root does
+  // not see the sign of a zero.  Valid correspondences execute exactly the operations of the sequential evaluation.
   const float fx = a.fx, fy = a.fy, cx = a.cx, cy = a.cy;
   const int dim = DIM ? DIM : a.factor_type;
   // explicit fused multiply-adds (one rounding each): the factor arithmetic is defined this way on
   // both sides of the parity test
-  const float pcx = fmaf(R02, p_in.z, fmaf(R01, p_in.y, fmaf(R00, p_in.x, t0)));
-  const float pcy = fmaf(R12, p_in.z, fmaf(R11, p_in.y, fmaf(R10, p_in.x, t1)));
-  const float pcz = fmaf(R22, p_in.z, fmaf(R21, p_in.y, fmaf(R20, p_in.x, t2)));
+  const float pcx = fmaf(X.R02, p_in.z, fmaf(X.R01, p_in.y, fmaf(X.R00, p_in.x, X.t0)));
+  const float pcy = fmaf(X.R12, p_in.z, fmaf(X.R11, p_in.y, fmaf(X.R10, p_in.x, X.t1)));
+  const float pcz = fmaf(X.R22, p_in.z, fmaf(X.R21, p_in.y, fmaf(X.R20, p_in.x, X.t2)));
   const float hx_r = fmaf(fx, pcx, cx * pcz);
   const float hy_r = fmaf(fy, pcy, cy * pcz);
   const float iz_r = 1.0f / pcz;
   const float u_r = hx_r * iz_r, v_r = hy_r * iz_r;
   const bool valid = active && pcz > 0.0f && !(u_r < 0.0f || u_r > a.image_cols || v_r < 0.0f || v_r > a.image_rows);
-  // the stand-in of an invalid / inactive correspondence: inverse depth 0 and information 0.  With iz = 0 the predicted image
-  // point, D = d(image point) / d(point in camera) and hence Q and J are all zeros (hx_r, hy_r, the measurement and the weight are
-  // finite), so every product below is +-0 without further selects (round 4: a v_cndmask costs two issue slots on gfx950,
-  // profiles/r04/valu_issue_rates.txt; seven of them per correspondence went away).  The point itself is still replaced: a
-  // non-finite map point is "behind the camera" for the reference, and 0 * NaN would poison the sums.
-  const float px = valid ? p_in.x : 0.0f, py = valid ? p_in.y : 0.0f, pz = valid ? p_in.z : 0.0f;
+  // the stand-in of an invalid / inactive correspondence: inverse depth 0 (the predicted image point and D are then zeros: hx_r,
+  // hy_r, the measurement and the weight are finite), information 0 and y = 0 (a non-finite map point is "behind the camera"
+  // for the reference, and 0 * NaN would poison the sums)
   const float iz = valid ? iz_r : 0.0f;
   const float u_pred = hx_r * iz, v_pred = hy_r * iz;  // = u_r, v_r of a valid correspondence (same operations), 0 otherwise
-  float e0 = u_pred - z.x, e1 = v_pred - z.y, e2 = 0.0f;
+  const float e0 = u_pred - z.x, e1 = v_pred - z.y;
+  float e2 = 0.0f;
   float ur = 0.0f;  // predicted column in the right image
   if (dim == PRS_FACTOR_STEREO) {
     const float hrx = hx_r + a.baseline_left_in_right_px[0];
@@ -299,43 +298,13 @@ __device__ __forceinline__ void factor_accumulate(const prs_aligner_params& a, c
   if (dim == PRS_FACTOR_STEREO && a.enable_inverse_depth_weighting) {
     wt = PRE_WT ? z.w : inverse_depth_weight(z, mean_dsp);  // finite: min(.., 1) maps NaN and +inf to 1
   }
-  auto fma2 = [](f2 x, f2 y, f2 z2) -> f2 { return __builtin_elementwise_fma(x, y, z2); };
-  // Q = D * R, rows as (pair of columns 0 1, column 2)
   const float alpha = fx * iz, gamma = fy * iz;
   const float beta0 = (cx - u_pred) * iz;
   const float beta1 = (cy - v_pred) * iz;
   const float beta2 = (cx - ur) * iz;
-  const f2 R0p = {R00, R01}, R1p = {R10, R11}, R2p = {R20, R21};
-  f2 Qp[3];     // (Q_i0, Q_i1)
-  float Qz[3];  // Q_i2
-  Qp[0] = fma2(f2{alpha, alpha}, R0p, f2{beta0, beta0} * R2p);
-  Qz[0] = fmaf(alpha, R02, beta0 * R22);
-  Qp[1] = fma2(f2{gamma, gamma}, R1p, f2{beta1, beta1} * R2p);
-  Qz[1] = fmaf(gamma, R12, beta1 * R22);
-  if (dim == PRS_FACTOR_STEREO) {
-    Qp[2] = fma2(f2{alpha, alpha}, R0p, f2{beta2, beta2} * R2p);
-    Qz[2] = fmaf(alpha, R02, beta2 * R22);
-  } else if (dim == PRS_FACTOR_DEPTH) {
-    Qp[2] = R2p;
-    Qz[2] = R22;
-  } else {
-    Qp[2] = f2{0.0f, 0.0f};
-    Qz[2] = 0.0f;
-  }
-  // J_i = ( wt Q_i | a x Q_i ) as three pairs: (J_i0 J_i1) (J_i2 J_i3) (J_i4 J_i5).  The operand pairs are laid out so that
-  // no value has to sit in two register positions (a packed operation reads aligned register pairs; a scalar one any register):
-  //   (J_i2, J_i3) = (wt, ay) * Q_i2 - (0, az) * Q_i1        (wt * Q_i2 - 0 = wt * Q_i2 exactly)
-  //   (J_i4, J_i5) = (az, ax) * (Q_i0, Q_i1) - (ax * Q_i2, ay * Q_i0)
-  const f2 c_wt_ay = {wt, 2.0f * py};
-  const f2 c_0_az  = {0.0f, 2.0f * pz};
-  const f2 c_az_ax = {2.0f * pz, 2.0f * px};
-  f2 J[3][3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    J[i][0] = Qp[i] * f2{wt, wt};
-    J[i][1] = fma2(c_wt_ay, f2{Qz[i], Qz[i]}, -(c_0_az * f2{Qp[i].y, Qp[i].y}));
-    J[i][2] = fma2(c_az_ax, Qp[i], -f2{c_az_ax.y * Qz[i], c_wt_ay.y * Qp[i].x});
-  }
+  const float d20   = dim == PRS_FACTOR_STEREO ? alpha : 0.0f;
+  const float d22   = dim == PRS_FACTOR_STEREO ? beta2 : (dim == PRS_FACTOR_DEPTH ? (valid ? 1.0f : 0.0f) : 0.0f);
+  const float yx = valid ? 2.0f * (pcx - X.t0) : 0.0f, yy = valid ? 2.0f * (pcy - X.t1) : 0.0f, yz = valid ? 2.0f * (pcz - X.t2) : 0.0f;
   // Omega = diag(info) * scale(moving point) (aligner_slice_processor_projective.cpp:46-56)
   const float s = valid ? p_in.w : 0.0f;
   float o0 = a.diagonal_info[0] * s;
@@ -353,31 +322,46 @@ __device__ __forceinline__ void factor_accumulate(const prs_aligner_params& a, c
   chi = saturated ? a.chi_threshold : chi;
   cls = !active ? 3 : (!valid ? 2 : (saturated ? 1 : 0));
   acc[15] += f2{saturated ? 0.0f : chi, chi};
-  const f2 o02 = {o0, o0}, o12 = {o1, o1}, o22 = {o2, o2}, e02 = {e0, e0}, e12 = {e1, e1}, e22 = {e2, e2};
-  f2 j0[3], j1[3], j2[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    j0[k]       = J[0][k] * o02;
-    j1[k]       = J[1][k] * o12;
-    j2[k]       = J[2][k] * o22;
-    acc[12 + k] = fma2(j2[k], e22, fma2(j1[k], e12, fma2(j0[k], e02, acc[12 + k])));
-  }
   // class counts: one exact small-integer code per correspondence, 1 for an inlier, kClsOutUnit for a kernelised one
   code += valid ? (saturated ? kClsOutUnit : 1.0f) : 0.0f;
-  // the upper triangle of J^T Omega J row by row
-  int t = 0;
-#pragma unroll
-  for (int r = 0; r < 6; ++r) {
-    const float a0 = (r & 1) ? j0[r >> 1].y : j0[r >> 1].x;
-    const float a1 = (r & 1) ? j1[r >> 1].y : j1[r >> 1].x;
-    const float a2 = (r & 1) ? j2[r >> 1].y : j2[r >> 1].x;
-    const f2 r0 = {a0, a0}, r1 = {a1, a1}, r2 = {a2, a2};
-#pragma unroll
-    for (int k = r >> 1; k < 3; ++k) {
-      acc[t] = fma2(r2, J[2][k], fma2(r1, J[1][k], fma2(r0, J[0][k], acc[t])));  // (mirrored first elements: not used)
-      ++t;
-    }
-  }
+  // K = D^T Omega D, r = D^T Omega e
+  const float p0 = o0 * alpha, p2 = o2 * d20, g1 = o1 * gamma, q0 = o0 * beta0, q1 = o1 * beta1, q2 = o2 * d22;
+  const float K00 = fmaf(p2, d20, p0 * alpha), K02 = fmaf(p2, d22, p0 * beta0), K11 = g1 * gamma, K12 = g1 * beta1;
+  const float K22 = fmaf(q2, d22, fmaf(q1, beta1, q0 * beta0));
+  const float w0 = o0 * e0, w1 = o1 * e1, w2 = o2 * e2;
+  const float r0 = fmaf(d20, w2, alpha * w0), r1 = gamma * w1, r2 = fmaf(d22, w2, fmaf(beta1, w1, beta0 * w0));
+  // N = K [y]x (K01 = 0)
+  const float N00 = -(K02 * yy), N01 = fmaf(K02, yx, -(K00 * yz)), N02 = K00 * yy;
+  const float N10 = fmaf(K11, yz, -(K12 * yy)), N11 = K12 * yx, N12 = -(K11 * yx);
+  const float N20 = fmaf(K12, yz, -(K22 * yy)), N21 = fmaf(K22, yx, -(K02 * yz)), N22 = fmaf(K02, yy, -(K12 * yx));
+  const float wt2 = wt * wt, nwt = -wt;
+  // slot = 2 * pair + component; slot 1 (H01 of the camera-frame sums) receives nothing: K01 = 0
+  acc[0].x  = fmaf(wt2, K00, acc[0].x);                      //  0: (0,0)
+  acc[1].x  = fmaf(wt2, K02, acc[1].x);                      //  2: (0,2)
+  acc[3].y  = fmaf(wt2, K11, acc[3].y);                      //  7: (1,1)
+  acc[4].x  = fmaf(wt2, K12, acc[4].x);                      //  8: (1,2)
+  acc[6].x  = fmaf(wt2, K22, acc[6].x);                      // 12: (2,2)
+  acc[1].y  = fmaf(nwt, N00, acc[1].y);                      //  3: (0,3)
+  acc[2].x  = fmaf(nwt, N01, acc[2].x);                      //  4: (0,4)
+  acc[2].y  = fmaf(nwt, N02, acc[2].y);                      //  5: (0,5)
+  acc[4].y  = fmaf(nwt, N10, acc[4].y);                      //  9: (1,3)
+  acc[5].x  = fmaf(nwt, N11, acc[5].x);                      // 10: (1,4)
+  acc[5].y  = fmaf(nwt, N12, acc[5].y);                      // 11: (1,5)
+  acc[6].y  = fmaf(nwt, N20, acc[6].y);                      // 13: (2,3)
+  acc[7].x  = fmaf(nwt, N21, acc[7].x);                      // 14: (2,4)
+  acc[7].y  = fmaf(nwt, N22, acc[7].y);                      // 15: (2,5)
+  acc[8].y  = fmaf(yz, N10, fmaf(-yy, N20, acc[8].y));       // 17: (3,3)
+  acc[9].x  = fmaf(yz, N11, fmaf(-yy, N21, acc[9].x));       // 18: (3,4)
+  acc[9].y  = fmaf(yz, N12, fmaf(-yy, N22, acc[9].y));       // 19: (3,5)
+  acc[10].x = fmaf(yx, N21, fmaf(-yz, N01, acc[10].x));      // 20: (4,4)
+  acc[10].y = fmaf(yx, N22, fmaf(-yz, N02, acc[10].y));      // 21: (4,5)
+  acc[11].y = fmaf(yy, N02, fmaf(-yx, N12, acc[11].y));      // 23: (5,5)
+  acc[12].x = fmaf(wt, r0, acc[12].x);                       // 24..29: b
+  acc[12].y = fmaf(wt, r1, acc[12].y);
+  acc[13].x = fmaf(wt, r2, acc[13].x);
+  acc[13].y = fmaf(yy, r2, fmaf(-yz, r1, acc[13].y));
+  acc[14].x = fmaf(yz, r0, fmaf(-yx, r2, acc[14].x));
+  acc[14].y = fmaf(yx, r1, fmaf(-yy, r0, acc[14].y));
 }
 
 // ---- the fixed-shape sum of the normal equations (defined in include/proslam_hip.h, prs_align_result) --------------
@@ -1597,6 +1581,10 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
         }
       }
       __syncthreads();
+      if (tid == 0 && pose_ok) {
+        rotate_normal_equations(sh.A, sh.H, sh.b);  // camera frame -> tangent space of X (factor_accumulate)
+      }
+      __syncthreads();
       ALIGN_ACC(acc_sum);
     }
     if (g.mode == PRS_MODE_LINEARIZE) {
@@ -2004,6 +1992,45 @@ __global__ __launch_bounds__(128, 4) void gn_kernel(const AlignArgs g) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (sh.pose_ok) {  // (a pose that is not finite: all sums are zero and stay zero)
+          // camera frame -> tangent space of X: H <- Rt^T H Rt, b <- Rt^T b, Rt = blockdiag(R, R) (prs_se3.h, rotate_normal_equations:
+          // the same expressions); lane r < 6 owns row r, the lower triangle is the system and is mirrored
+          const int rrow = lane < 6 ? lane : 5;
+          const int blk  = rrow >= 3 ? 1 : 0;
+          const int ci   = rrow - 3 * blk;
+          const float* Yb = &sh.H[18 * blk];
+          const float Ri0 = sh.A[ci], Ri1 = sh.A[4 + ci], Ri2 = sh.A[8 + ci];
+          float o[6];
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            float v[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              v[c] = fmaf(Ri2, Yb[12 + 3 * cb + c], fmaf(Ri1, Yb[6 + 3 * cb + c], Ri0 * Yb[3 * cb + c]));
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              o[3 * cb + j] = fmaf(v[2], sh.A[8 + j], fmaf(v[1], sh.A[4 + j], v[0] * sh.A[j]));
+            }
+          }
+          const float bb = fmaf(Ri2, sh.b[3 * blk + 2], fmaf(Ri1, sh.b[3 * blk + 1], Ri0 * sh.b[3 * blk]));
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (lane < 6) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+              if (j <= rrow) {
+                sh.H[6 * rrow + j] = o[j];
+                sh.H[6 * j + rrow] = o[j];
+              }
+            }
+            sh.b[rrow] = bb;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         if (stid == 0) {
           const int cc = (int) sh.fcnt[0];  // #inliers + kClsOutUnit * #kernelised
           sh.n_inl     = cc & ((int) kClsOutUnit - 1);

@@ -143,6 +143,45 @@ __device__ __forceinline__ void tnq2t(const float* v6, float* T) {
   T[15] = 1.0f;
 }
 
+// The aligner sums its normal equations in the CAMERA frame (align.hip, factor_accumulate): with A = [R | t] the transform points
+// go through, J = D G_c Rt, G_c = [ wt I | -[y]x ], y = 2 R p, Rt = blockdiag(R, R), so J^T Omega J = Rt^T (G_c^T D^T Omega D G_c) Rt
+// and the rotation is the same for every correspondence: it is applied once, here, to the summed system.  Row r of the result
+// (r = 3 * blk + i): v = (column i of R)^T Y, out = v R for the two 3 x 3 blocks Y of block row blk of H; b likewise.  The rotated
+// matrix is symmetric up to rounding; its LOWER triangle (row >= column) is the system and is mirrored into the upper one.
+// In place; gn_kernel evaluates the same expressions with one lane per row.
+__device__ __forceinline__ void rotate_normal_equations(const float* A, float* H, float* b) {
+  float Hn[36], bn[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    const int blk = r >= 3 ? 1 : 0;
+    const int i   = r - 3 * blk;
+    const float Ri0 = A[i], Ri1 = A[4 + i], Ri2 = A[8 + i];
+    const float* Y = H + 18 * blk;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      float v[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        v[c] = fmaf(Ri2, Y[12 + 3 * cb + c], fmaf(Ri1, Y[6 + 3 * cb + c], Ri0 * Y[3 * cb + c]));
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        Hn[6 * r + 3 * cb + j] = fmaf(v[2], A[8 + j], fmaf(v[1], A[4 + j], v[0] * A[j]));
+      }
+    }
+    bn[r] = fmaf(Ri2, b[3 * blk + 2], fmaf(Ri1, b[3 * blk + 1], Ri0 * b[3 * blk]));
+  }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      H[6 * r + c] = Hn[6 * r + c];
+      H[6 * c + r] = Hn[6 * r + c];
+    }
+    b[r] = bn[r];
+  }
+}
+
 // (H + damping diag(H)) dx = -b by dense Cholesky (the damping form is a round-4 result of tools/sweep_a13.py); X <- X * exp(dx).  H: full 6x6 row-major (lower part
 // read), returns false (X untouched) when the system is not positive definite.
 __device__ __forceinline__ bool gn_step(const float* H, const float* b, float damping, float* X) {

@@ -267,3 +267,31 @@ def test_aligner_with_bruteforce_finder_on_the_reference_images(oracle):
         assert s.num_inliers >= al["min_num_inliers"]  # Status::Success
         err = rp.t2tnq(X.astype(np.float64) @ case["truth"])
         assert np.all(np.abs(err) < case["bound"]), (case["name"], err)
+
+
+@pytest.mark.parametrize("mode", [2, 3, 4])
+def test_camera_frame_sums_are_the_entry_by_entry_normal_equations(oracle, mode):
+    """The shipped accumulation sums G_c^T (D^T Omega D) G_c in the camera frame and rotates the summed system once
+    (oracle/proslam_oracle.c, csrc/align.hip factor_accumulate); rounds 1-3 summed J^T Omega J entry by entry in the tangent space of
+    X.  Same normal equations: the two agree to float rounding on every entry (and with the float64 evaluation, test above)."""
+    pts, desc, K, S, pose, fixed, idx, baseline_px = with_sensor_scene(mode, seed=5)
+    corr = np.zeros(len(idx), dtype=oracle.CORR_DTYPE)
+    corr["fixed_idx"], corr["moving_idx"] = np.arange(len(idx)), idx
+    cfg = _cfg_for(K, mode, baseline_px)
+    cfg["aligner"]["chi_threshold"] = 200.0
+    ap = aligner_params(oracle, cfg, mean_disparity=20.0, enable_inverse_depth_weighting=1 if mode == 4 else 0)
+    for k, (rot, trans) in enumerate(((0.05, 0.003), (0.3, 0.05), (0.0, 0.0))):
+        X = syn.perturb(np.random.default_rng(7 + k), np.linalg.inv(pose @ S), rot, trans)
+        new = oracle.linearize(ap, X, corr, fixed, pts, None)
+        oracle.set_variant(accum_form=1)
+        try:
+            old = oracle.linearize(ap, X, corr, fixed, pts, None)
+        finally:
+            oracle.set_variant()
+        Hn, Ho = np.array(new.H, np.float64).reshape(6, 6), np.array(old.H, np.float64).reshape(6, 6)
+        bn, bo = np.array(new.b, np.float64), np.array(old.b, np.float64)
+        assert new.num_inliers == old.num_inliers and new.num_outliers == old.num_outliers and new.num_inliers + new.num_outliers > 0
+        assert new.chi_total == old.chi_total and new.chi_inliers == old.chi_inliers  # chi does not depend on the form
+        assert np.abs(Hn - Ho).max() <= 2e-5 * np.abs(Ho).max()
+        assert np.abs(bn - bo).max() <= 2e-5 * max(np.abs(bo).max(), 1e-3 * np.abs(Ho).max())
+        assert np.array_equal(Hn, Hn.T)  # the lower triangle is the system, mirrored
