@@ -292,6 +292,12 @@ typedef struct {
  *   leaf l (0..127)  = ((+0 + t_l) + t_{l+128}) + t_{l+256} + ...   terms of the correspondences l, l + 128, ... in order
  *   seven levels      v[l] <- v[l] + v[l ^ m]  for m = 32, 16, 8, 7, 2, 1, 64 (a balanced binary tree over the 128 leaves)
  *   sum               = v[0] + 0.0f
+ * What is summed (round 4) are the CAMERA-FRAME normal equations: with [R | t] the transform a point goes through and
+ * D = d(image point) / d(point in camera), J = D R [ wt I | -2 [p]x ] = D G_c Rt with G_c = [ wt I | -[y]x ], y = 2 R p and
+ * Rt = blockdiag(R, R) -- the same for every correspondence --, so the terms are those of G_c^T (D^T Omega D) G_c and
+ * G_c^T D^T Omega e, and H = Rt^T (sum) Rt, b = Rt^T (sum) is evaluated ONCE per linearisation on the summed system (row by
+ * row; the lower triangle of the rotated matrix is the system and is mirrored).  Operation order: csrc/align.hip
+ * factor_accumulate, csrc/prs_se3.h rotate_normal_equations; restated in oracle/proslam_oracle.c.
  * Same inputs give the same bits on every launch, batch size and entry point (fused, split, prs_pcf_linearize). */
 typedef struct {
   float H[36];          /* last linearisation, row-major, without prior */
