@@ -1781,6 +1781,216 @@ __device__ __forceinline__ bool gn_advance(const prs_aligner_params& a, const in
   return it_align >= a.max_iterations + extra;
 }
 
+// The single-wave phase of a Gauss-Newton iteration once the 32 summed slots of the linearisation are in sh.H / b / chi / fcnt:
+// camera frame -> tangent space of X, class counts, (H + damping diag(H)) dx = -b, X <- X * exp(dx); `stid` = lane of the solving wave.
+__device__ __forceinline__ void gn_solve_wave(const AlignArgs& g, GnShared& sh, const int frame, const int nc, const int stid, const bool inlier_run) {
+  const int lane = stid;
+  if (sh.pose_ok) {  // (a pose that is not finite: all sums are zero and stay zero)
+    // camera frame -> tangent space of X: H <- Rt^T H Rt, b <- Rt^T b, Rt = blockdiag(R, R) (prs_se3.h, rotate_normal_equations:
+    // the same expressions); lane r < 6 owns row r, the lower triangle is the system and is mirrored
+    const int rrow = lane < 6 ? lane : 5;
+    const int blk  = rrow >= 3 ? 1 : 0;
+    const int ci   = rrow - 3 * blk;
+    const float* Yb = &sh.H[18 * blk];
+    const float Ri0 = sh.A[ci], Ri1 = sh.A[4 + ci], Ri2 = sh.A[8 + ci];
+    float o[6];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      float v[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        v[c] = fmaf(Ri2, Yb[12 + 3 * cb + c], fmaf(Ri1, Yb[6 + 3 * cb + c], Ri0 * Yb[3 * cb + c]));
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        o[3 * cb + j] = fmaf(v[2], sh.A[8 + j], fmaf(v[1], sh.A[4 + j], v[0] * sh.A[j]));
+      }
+    }
+    const float bb = fmaf(Ri2, sh.b[3 * blk + 2], fmaf(Ri1, sh.b[3 * blk + 1], Ri0 * sh.b[3 * blk]));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < 6) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        if (j <= rrow) {
+          sh.H[6 * rrow + j] = o[j];
+          sh.H[6 * j + rrow] = o[j];
+        }
+      }
+      sh.b[rrow] = bb;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  if (stid == 0) {
+    const int cc = (int) sh.fcnt[0];  // #inliers + kClsOutUnit * #kernelised
+    sh.n_inl     = cc & ((int) kClsOutUnit - 1);
+    sh.n_out     = cc / (int) kClsOutUnit;
+    sh.n_inv     = nc - sh.n_inl - sh.n_out;
+  }
+  // ---- (H + damping diag(H)) dx = -b, X <- X * exp(dx) by the lanes of this wave: lane i < 6 owns row i of the system and
+  // of the Cholesky factor, lane r < 3 row r of the pose; pivots, substitutions and the perturbation are uniform
+  // (every lane evaluates them from broadcast values).  Every element goes through exactly the operations of
+  // prs_se3.h's gn_step, in the same order, so the pose is bit-identical to the one-lane evaluation.
+  {
+    const int row     = lane < 6 ? lane : 5;  // lanes >= 6 shadow row 5 (results unused)
+    const int prow    = lane < 3 ? lane : 2;
+    const float2* hr2 = reinterpret_cast<const float2*>(&sh.H[6 * row]);
+    const float2 h01 = hr2[0], h23 = hr2[1], h45 = hr2[2];
+    float h[6] = {h01.x, h01.y, h23.x, h23.y, h45.x, h45.y};
+    float hb   = sh.b[row];
+    const float4 xr = *reinterpret_cast<const float4*>(&sh.X[4 * prow]);
+    if (g.b.prior) {
+      const float* pr = g.b.prior + (size_t) frame * 42;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        h[c] += pr[6 * row + c];
+      }
+      hb += pr[36 + row];
+    }
+    if (g.a.enable_motion_prior) {
+      // AlignerSliceMotionModel3D stand-in (add_motion_prior): e = t2tnq(Z^-1 X), H[i][i] += info[i], b[i] += info[i] * e[i]
+      float X[16], e[6];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        X[i] = sh.X[i];
+      }
+      if (g.prior_mean) {
+        const float* Z = g.prior_mean + (size_t) frame * 16;
+        float z[16], Zi[16], D[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          z[i] = Z[i];
+        }
+        se3_inverse(z, Zi);
+        se3_mul(Zi, X, D);
+        t2tnq(D, e);
+      } else {
+        t2tnq(X, e);
+      }
+      float er = e[0], ir = g.a.motion_prior_info[0];
+#pragma unroll
+      for (int k = 1; k < 6; ++k) {
+        er = row == k ? e[k] : er;
+        ir = row == k ? g.a.motion_prior_info[k] : ir;
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        h[c] = row == c ? h[c] + ir : h[c];
+      }
+      hb += ir * er;
+    }
+    auto bcast = [](const float v, const int l) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+    float Lr[6], inv[6];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float v = row == j ? fmaf(g.a.damping, h[j], h[j]) : h[j];  // H + damping diag(H)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        if (k < j) {
+          v = fmaf(-Lr[k], bcast(Lr[k], j), v);
+        }
+      }
+      const float piv = bcast(v, j);
+      ok              = ok && piv > 0.0f;  // (no early exit: a failed pivot only poisons values that are dropped below)
+      inv[j]          = 1.0f / sqrtf(piv);
+      Lr[j]           = v * inv[j];
+    }
+    float y[6], dx[6];
+    float vy = -hb;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      y[k] = bcast(vy, k) * inv[k];
+      vy   = fmaf(-Lr[k], y[k], vy);
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+      float v = y[i];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        if (k > i) {
+          v = fmaf(-bcast(Lr[i], k), dx[k], v);
+        }
+      }
+      dx[i] = v * inv[i];
+    }
+    float D[16];
+    tnq2t(dx, D);
+    float4 xn;
+    xn.x = (xr.x * D[0] + xr.y * D[4]) + xr.z * D[8];
+    xn.y = (xr.x * D[1] + xr.y * D[5]) + xr.z * D[9];
+    xn.z = (xr.x * D[2] + xr.y * D[6]) + xr.z * D[10];
+    xn.w = ((xr.x * D[3] + xr.y * D[7]) + xr.z * D[11]) + xr.w;
+    xn.x = ok ? xn.x : xr.x;  // (component by component: a select between the two structs goes through scratch)
+    xn.y = ok ? xn.y : xr.y;
+    xn.z = ok ? xn.z : xr.z;
+    xn.w = ok ? xn.w : xr.w;
+    const uint32_t changed = (__float_as_uint(xn.x) ^ __float_as_uint(xr.x)) | (__float_as_uint(xn.y) ^ __float_as_uint(xr.y)) |
+                             (__float_as_uint(xn.z) ^ __float_as_uint(xr.z)) | (__float_as_uint(xn.w) ^ __float_as_uint(xr.w));
+    const bool any_changed = (__ballot(changed != 0u) & 7ull) != 0ull;
+    // points -> camera: X, or sensor_in_robot^-1 * X
+    float4 an = xn;
+    if (g.a.with_sensor) {
+      const float4 sr = *reinterpret_cast<const float4*>(&sh.Sinv[4 * prow]);
+      const float4 x0 = {bcast(xn.x, 0), bcast(xn.y, 0), bcast(xn.z, 0), bcast(xn.w, 0)};
+      const float4 x1 = {bcast(xn.x, 1), bcast(xn.y, 1), bcast(xn.z, 1), bcast(xn.w, 1)};
+      const float4 x2 = {bcast(xn.x, 2), bcast(xn.y, 2), bcast(xn.z, 2), bcast(xn.w, 2)};
+      an.x = (sr.x * x0.x + sr.y * x1.x) + sr.z * x2.x;
+      an.y = (sr.x * x0.y + sr.y * x1.y) + sr.z * x2.y;
+      an.z = (sr.x * x0.z + sr.y * x1.z) + sr.z * x2.z;
+      an.w = ((sr.x * x0.w + sr.y * x1.w) + sr.z * x2.w) + sr.w;
+    }
+    const float rs = (an.x + an.y) + (an.z + an.w);
+    const float fs = (bcast(rs, 0) + bcast(rs, 1)) + bcast(rs, 2);  // pose_is_finite's sum
+    if (lane < 3) {
+      *reinterpret_cast<float4*>(&sh.X[4 * lane]) = xn;
+      *reinterpret_cast<float4*>(&sh.A[4 * lane]) = an;
+    }
+    if (stid == 0) {
+      sh.stop    = (g.a.stop_at_fixed_point && !any_changed && (sh.converged || inlier_run)) ? 1 : 0;
+      sh.pose_ok = (fs - fs) == 0.0f ? 1 : 0;
+    }
+  }
+}
+
+// What the solving wave does once an iteration's pose is final (uniform control flow inside the wave): decide whether the
+// loop goes on and, if the next iteration belongs to the first phase, perform its finder.setLocalMapInSensor(X);
+// finder.compute() as long as that needs no projective search (CF/correspondence_finder_projective_base_impl.cpp:138-178)
+__device__ __forceinline__ void gn_finder_bookkeeping(const AlignArgs& g, GnShared& sh, const int stid, const int nc, const int it_align, const int extra,
+                                                      const bool fixed_point) {
+    int next        = it_align;
+    const bool over = gn_advance(g.a, extra, next, fixed_point, sh.n_inl);
+    if (!over && next < g.a.max_iterations) {
+      if (stid < 16) {
+        sh.T[stid] = sh.A[stid];
+      }
+      if (!sh.converged) {
+        const unsigned long long k  = g.f.number_of_solver_iterations_per_projection;
+        const unsigned long long it = sh.it;
+        if (k == 0 || it % k == 0 || it == 1) {
+          if (stid == 0) {
+            sh.need_search = 1;
+          }
+        } else {
+          if (stid < 16) {
+            sh.Tprev[stid] = sh.A[stid];
+          }
+          if (stid == 0) {
+            sh.it = it + 1;
+            if (nc == 0) {
+              sh.flags |= PRS_WARN_NO_MATCHES;  // _postCompute (bruteforce_impl.cpp:237-242)
+            }
+          }
+        }
+      } else if (stid == 0 && nc == 0) {
+        sh.flags |= PRS_WARN_NO_MATCHES;
+      }
+    }
+}
+
 // SLOTS = correspondences per thread the instantiation can hold (ceil(max_fixed / 128)).  The operand rows of the first
 // kGnLdsSlots * 128 correspondences (measurement + inverse-depth weight, moving point + information scale: 32 B each) are
 // parked in LDS for the whole launch (16 KB per frame; registers are needed for the 32 running sums), later ones (rare: more
@@ -1879,39 +2089,6 @@ __global__ __launch_bounds__(128, 4) void gn_kernel(const AlignArgs g) {
   uint32_t cls_bits = 0;                     // factor classes of this thread's correspondences in the last linearisation (2 bits each)
   bool have_cls     = false;                 // (block-uniform) the last executed iteration linearised
 
-  // What the solving wave does once an iteration's pose is final (uniform control flow inside the wave): decide whether the
-  // loop goes on and, if the next iteration belongs to the first phase, perform its finder.setLocalMapInSensor(X);
-  // finder.compute() as long as that needs no projective search (CF/correspondence_finder_projective_base_impl.cpp:138-178)
-  auto finder_bookkeeping = [&](const bool fixed_point) {
-    int next        = it_align;
-    const bool over = gn_advance(g.a, extra, next, fixed_point, sh.n_inl);
-    if (!over && next < g.a.max_iterations) {
-      if (stid < 16) {
-        sh.T[stid] = sh.A[stid];
-      }
-      if (!sh.converged) {
-        const unsigned long long k  = g.f.number_of_solver_iterations_per_projection;
-        const unsigned long long it = sh.it;
-        if (k == 0 || it % k == 0 || it == 1) {
-          if (stid == 0) {
-            sh.need_search = 1;
-          }
-        } else {
-          if (stid < 16) {
-            sh.Tprev[stid] = sh.A[stid];
-          }
-          if (stid == 0) {
-            sh.it = it + 1;
-            if (nc == 0) {
-              sh.flags |= PRS_WARN_NO_MATCHES;  // _postCompute (bruteforce_impl.cpp:237-242)
-            }
-          }
-        }
-      } else if (stid == 0 && nc == 0) {
-        sh.flags |= PRS_WARN_NO_MATCHES;
-      }
-    }
-  };
 
   while (true) {
     ++executed;
@@ -1931,7 +2108,7 @@ __global__ __launch_bounds__(128, 4) void gn_kernel(const AlignArgs g) {
       have_cls = false;
       __syncthreads();
       if (wave == solver) {
-        finder_bookkeeping(sh.stop != 0);
+        gn_finder_bookkeeping(g, sh, stid, nc, it_align, extra, sh.stop != 0);
       }
       __syncthreads();
     } else {
@@ -1992,179 +2169,11 @@ __global__ __launch_bounds__(128, 4) void gn_kernel(const AlignArgs g) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (sh.pose_ok) {  // (a pose that is not finite: all sums are zero and stay zero)
-          // camera frame -> tangent space of X: H <- Rt^T H Rt, b <- Rt^T b, Rt = blockdiag(R, R) (prs_se3.h, rotate_normal_equations:
-          // the same expressions); lane r < 6 owns row r, the lower triangle is the system and is mirrored
-          const int rrow = lane < 6 ? lane : 5;
-          const int blk  = rrow >= 3 ? 1 : 0;
-          const int ci   = rrow - 3 * blk;
-          const float* Yb = &sh.H[18 * blk];
-          const float Ri0 = sh.A[ci], Ri1 = sh.A[4 + ci], Ri2 = sh.A[8 + ci];
-          float o[6];
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
-            float v[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              v[c] = fmaf(Ri2, Yb[12 + 3 * cb + c], fmaf(Ri1, Yb[6 + 3 * cb + c], Ri0 * Yb[3 * cb + c]));
-            }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-              o[3 * cb + j] = fmaf(v[2], sh.A[8 + j], fmaf(v[1], sh.A[4 + j], v[0] * sh.A[j]));
-            }
-          }
-          const float bb = fmaf(Ri2, sh.b[3 * blk + 2], fmaf(Ri1, sh.b[3 * blk + 1], Ri0 * sh.b[3 * blk]));
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          if (lane < 6) {
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-              if (j <= rrow) {
-                sh.H[6 * rrow + j] = o[j];
-                sh.H[6 * j + rrow] = o[j];
-              }
-            }
-            sh.b[rrow] = bb;
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        if (stid == 0) {
-          const int cc = (int) sh.fcnt[0];  // #inliers + kClsOutUnit * #kernelised
-          sh.n_inl     = cc & ((int) kClsOutUnit - 1);
-          sh.n_out     = cc / (int) kClsOutUnit;
-          sh.n_inv     = nc - sh.n_inl - sh.n_out;
-        }
-        // ---- (H + damping diag(H)) dx = -b, X <- X * exp(dx) by the lanes of this wave: lane i < 6 owns row i of the system and
-        // of the Cholesky factor, lane r < 3 row r of the pose; pivots, substitutions and the perturbation are uniform
-        // (every lane evaluates them from broadcast values).  Every element goes through exactly the operations of
-        // prs_se3.h's gn_step, in the same order, so the pose is bit-identical to the one-lane evaluation.
-        {
-          const int row     = lane < 6 ? lane : 5;  // lanes >= 6 shadow row 5 (results unused)
-          const int prow    = lane < 3 ? lane : 2;
-          const float2* hr2 = reinterpret_cast<const float2*>(&sh.H[6 * row]);
-          const float2 h01 = hr2[0], h23 = hr2[1], h45 = hr2[2];
-          float h[6] = {h01.x, h01.y, h23.x, h23.y, h45.x, h45.y};
-          float hb   = sh.b[row];
-          const float4 xr = *reinterpret_cast<const float4*>(&sh.X[4 * prow]);
-          if (g.b.prior) {
-            const float* pr = g.b.prior + (size_t) frame * 42;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-              h[c] += pr[6 * row + c];
-            }
-            hb += pr[36 + row];
-          }
-          if (g.a.enable_motion_prior) {
-            // AlignerSliceMotionModel3D stand-in (add_motion_prior): e = t2tnq(Z^-1 X), H[i][i] += info[i], b[i] += info[i] * e[i]
-            float X[16], e[6];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              X[i] = sh.X[i];
-            }
-            if (g.prior_mean) {
-              const float* Z = g.prior_mean + (size_t) frame * 16;
-              float z[16], Zi[16], D[16];
-#pragma unroll
-              for (int i = 0; i < 16; ++i) {
-                z[i] = Z[i];
-              }
-              se3_inverse(z, Zi);
-              se3_mul(Zi, X, D);
-              t2tnq(D, e);
-            } else {
-              t2tnq(X, e);
-            }
-            float er = e[0], ir = g.a.motion_prior_info[0];
-#pragma unroll
-            for (int k = 1; k < 6; ++k) {
-              er = row == k ? e[k] : er;
-              ir = row == k ? g.a.motion_prior_info[k] : ir;
-            }
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-              h[c] = row == c ? h[c] + ir : h[c];
-            }
-            hb += ir * er;
-          }
-          auto bcast = [](const float v, const int l) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
-          float Lr[6], inv[6];
-          bool ok = true;
-#pragma unroll
-          for (int j = 0; j < 6; ++j) {
-            float v = row == j ? fmaf(g.a.damping, h[j], h[j]) : h[j];  // H + damping diag(H)
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-              if (k < j) {
-                v = fmaf(-Lr[k], bcast(Lr[k], j), v);
-              }
-            }
-            const float piv = bcast(v, j);
-            ok              = ok && piv > 0.0f;  // (no early exit: a failed pivot only poisons values that are dropped below)
-            inv[j]          = 1.0f / sqrtf(piv);
-            Lr[j]           = v * inv[j];
-          }
-          float y[6], dx[6];
-          float vy = -hb;
-#pragma unroll
-          for (int k = 0; k < 6; ++k) {
-            y[k] = bcast(vy, k) * inv[k];
-            vy   = fmaf(-Lr[k], y[k], vy);
-          }
-#pragma unroll
-          for (int i = 5; i >= 0; --i) {
-            float v = y[i];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-              if (k > i) {
-                v = fmaf(-bcast(Lr[i], k), dx[k], v);
-              }
-            }
-            dx[i] = v * inv[i];
-          }
-          float D[16];
-          tnq2t(dx, D);
-          float4 xn;
-          xn.x = (xr.x * D[0] + xr.y * D[4]) + xr.z * D[8];
-          xn.y = (xr.x * D[1] + xr.y * D[5]) + xr.z * D[9];
-          xn.z = (xr.x * D[2] + xr.y * D[6]) + xr.z * D[10];
-          xn.w = ((xr.x * D[3] + xr.y * D[7]) + xr.z * D[11]) + xr.w;
-          xn.x = ok ? xn.x : xr.x;  // (component by component: a select between the two structs goes through scratch)
-          xn.y = ok ? xn.y : xr.y;
-          xn.z = ok ? xn.z : xr.z;
-          xn.w = ok ? xn.w : xr.w;
-          const uint32_t changed = (__float_as_uint(xn.x) ^ __float_as_uint(xr.x)) | (__float_as_uint(xn.y) ^ __float_as_uint(xr.y)) |
-                                   (__float_as_uint(xn.z) ^ __float_as_uint(xr.z)) | (__float_as_uint(xn.w) ^ __float_as_uint(xr.w));
-          const bool any_changed = (__ballot(changed != 0u) & 7ull) != 0ull;
-          // points -> camera: X, or sensor_in_robot^-1 * X
-          float4 an = xn;
-          if (g.a.with_sensor) {
-            const float4 sr = *reinterpret_cast<const float4*>(&sh.Sinv[4 * prow]);
-            const float4 x0 = {bcast(xn.x, 0), bcast(xn.y, 0), bcast(xn.z, 0), bcast(xn.w, 0)};
-            const float4 x1 = {bcast(xn.x, 1), bcast(xn.y, 1), bcast(xn.z, 1), bcast(xn.w, 1)};
-            const float4 x2 = {bcast(xn.x, 2), bcast(xn.y, 2), bcast(xn.z, 2), bcast(xn.w, 2)};
-            an.x = (sr.x * x0.x + sr.y * x1.x) + sr.z * x2.x;
-            an.y = (sr.x * x0.y + sr.y * x1.y) + sr.z * x2.y;
-            an.z = (sr.x * x0.z + sr.y * x1.z) + sr.z * x2.z;
-            an.w = ((sr.x * x0.w + sr.y * x1.w) + sr.z * x2.w) + sr.w;
-          }
-          const float rs = (an.x + an.y) + (an.z + an.w);
-          const float fs = (bcast(rs, 0) + bcast(rs, 1)) + bcast(rs, 2);  // pose_is_finite's sum
-          if (lane < 3) {
-            *reinterpret_cast<float4*>(&sh.X[4 * lane]) = xn;
-            *reinterpret_cast<float4*>(&sh.A[4 * lane]) = an;
-          }
-          if (stid == 0) {
-            sh.stop    = (g.a.stop_at_fixed_point && !any_changed && (sh.converged || inlier_run)) ? 1 : 0;
-            sh.pose_ok = (fs - fs) == 0.0f ? 1 : 0;
-          }
-        }
+        gn_solve_wave(g, sh, frame, nc, stid, inlier_run);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        finder_bookkeeping(sh.stop != 0);
+        gn_finder_bookkeeping(g, sh, stid, nc, it_align, extra, sh.stop != 0);
       }
       __syncthreads();
     }
@@ -2526,7 +2535,6 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
                                                                      : align_kernel<kSearchThreads, true, PRS_SEARCH_KDTREE>));
   // two waves per frame (eight frames resident per CU: the kernel is bound by its single-wave phases and by
   // instruction issue, more independent frames fill the idle slots)
-  const size_t lds_gn  = ((sizeof(GnShared) + 15) / 16) * 16 + (size_t) kGnLdsRows * 2 * sizeof(float4);  // shared state + parked operand rows
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(skernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_search);
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_align_batch_run attribute");
@@ -2537,6 +2545,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   const bool fast = aligner->factor_type == PRS_FACTOR_STEREO && !aligner->keep_only_inlier_correspondences;
   auto gnk        = max_fixed <= 4 * 128 ? (fast ? gn_kernel<4, PRS_FACTOR_STEREO, false> : gn_kernel<4, 0, true>)
                                          : (fast ? gn_kernel<8, PRS_FACTOR_STEREO, false> : gn_kernel<8, 0, true>);
+  const size_t lds_gn = ((sizeof(GnShared) + 15) / 16) * 16 + (size_t) kGnLdsRows * 2 * sizeof(float4);  // shared state + parked operand rows
   // The job lives in the context until align_batch_finish: the rounds are plain launches on the context's stream (no host
   // synchronisation here, the sequence can be captured in a HIP graph once the scratch buffers exist).
   job->active      = true;

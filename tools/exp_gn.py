@@ -4,7 +4,7 @@ import torch, bench
 from srrg2_proslam_amd import configs, synthetic as syn
 cfg = configs.get("kitti")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 18432
-w = bench.FrameWorkload(cfg, 0, B, 2000, 2000, 896, 251, syn.seed_for(1,0), True)
+w = bench.FrameWorkload(cfg, 0, B, 2000, 2000, 896, 251, syn.seed_for(1,0))
 for _ in range(2): w.step()
 torch.cuda.synchronize()
 kt = w.kernel_times(3)
