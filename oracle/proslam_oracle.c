@@ -1571,28 +1571,32 @@ void orc_linearize_ex(const orc_aligner_params* P,
   }
 }
 
-/* IterationAlgorithmGN with damping + dense Cholesky (configurations/kitti.conf:20-22,310-315)
+/* IterationAlgorithmGN with damping + dense solve (configurations/kitti.conf:20-22,310-315; the solver is external)
  * and VariableSE3QuaternionRight::applyPerturbation: X <- X * exp(dx) */
 int orc_gn_step(const orc_linear_system* sys, float damping, float* X) {
-  /* dense Cholesky with fused multiply-subtracts and one reciprocal per pivot (BUILD-DEFINED) */
-  float L[6][6], inv[6];
+  /* (H + damping diag(H)) dx = -b by LDL^T with fused multiply-subtracts and one reciprocal per pivot (BUILD-DEFINED; the device
+   * performs the same operations, csrc/prs_se3.h ldlt_solve6).  L unit lower triangular, U[i][j] = L[i][j] * d_j the entry before
+   * its division; the LOWER triangle of H is read.  Rounds 1-3 used the Cholesky factor (six sqrt + six divisions): same system,
+   * same damping, different rounding. */
+  float L[6][6], U[6][6], inv[6];
   memset(L, 0, sizeof(L));
+  memset(U, 0, sizeof(U));
   for (int j = 0; j < 6; ++j) {
     /* damping: H_jj <- H_jj + damping * H_jj (round-4 result of tools/sweep_a13.py; form 1 = H_jj + damping) */
-    float s = g_variant.damping_form == 1 ? sys->H[6 * j + j] + damping : fmaf(damping, sys->H[6 * j + j], sys->H[6 * j + j]);
+    float d = g_variant.damping_form == 1 ? sys->H[6 * j + j] + damping : fmaf(damping, sys->H[6 * j + j], sys->H[6 * j + j]);
     for (int k = 0; k < j; ++k) {
-      s = fmaf(-L[j][k], L[j][k], s);
+      d = fmaf(-L[j][k], U[j][k], d);
     }
-    if (!(s > 0.0f)) {
+    if (!(d > 0.0f)) {
       return 1;
     }
-    L[j][j] = sqrtf(s);
-    inv[j]  = 1.0f / L[j][j];
+    inv[j] = 1.0f / d;
     for (int i = j + 1; i < 6; ++i) {
       float v = sys->H[6 * i + j];
       for (int k = 0; k < j; ++k) {
-        v = fmaf(-L[i][k], L[j][k], v);
+        v = fmaf(-L[i][k], U[j][k], v);
       }
+      U[i][j] = v;
       L[i][j] = v * inv[j];
     }
   }
@@ -1602,14 +1606,14 @@ int orc_gn_step(const orc_linear_system* sys, float damping, float* X) {
     for (int k = 0; k < i; ++k) {
       v = fmaf(-L[i][k], y[k], v);
     }
-    y[i] = v * inv[i];
+    y[i] = v;
   }
   for (int i = 5; i >= 0; --i) {
-    float v = y[i];
+    float v = y[i] * inv[i];
     for (int k = i + 1; k < 6; ++k) {
       v = fmaf(-L[k][i], dx[k], v);
     }
-    dx[i] = v * inv[i];
+    dx[i] = v;
   }
   float D[16], Xn[16];
   orc_tnq2t(dx, D);

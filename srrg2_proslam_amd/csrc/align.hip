@@ -1590,7 +1590,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
     if (g.mode == PRS_MODE_LINEARIZE) {
       break;
     }
-    // ---- damped GN step on one lane (IterationAlgorithmGN + dense Cholesky + X <- X * exp(dx)) ---
+    // ---- damped GN step on one lane (IterationAlgorithmGN + dense LDL^T + X <- X * exp(dx)) ---
     ALIGN_MARK();
     if (tid == 0) {
       float H[36], b[6], X[16];
@@ -1830,93 +1830,42 @@ __device__ __forceinline__ void gn_solve_wave(const AlignArgs& g, GnShared& sh, 
     sh.n_out     = cc / (int) kClsOutUnit;
     sh.n_inv     = nc - sh.n_inl - sh.n_out;
   }
-  // ---- (H + damping diag(H)) dx = -b, X <- X * exp(dx) by the lanes of this wave: lane i < 6 owns row i of the system and
-  // of the Cholesky factor, lane r < 3 row r of the pose; pivots, substitutions and the perturbation are uniform
-  // (every lane evaluates them from broadcast values).  Every element goes through exactly the operations of
-  // prs_se3.h's gn_step, in the same order, so the pose is bit-identical to the one-lane evaluation.
+  // ---- (H + damping diag(H)) dx = -b, X <- X * exp(dx): every lane evaluates the (uniform) 6 x 6 solve of prs_se3.h, lane r < 3
+  // then owns row r of the pose.  Same operations as gn_step on one lane, so the pose is bit-identical to that evaluation.
   {
-    const int row     = lane < 6 ? lane : 5;  // lanes >= 6 shadow row 5 (results unused)
-    const int prow    = lane < 3 ? lane : 2;
-    const float2* hr2 = reinterpret_cast<const float2*>(&sh.H[6 * row]);
-    const float2 h01 = hr2[0], h23 = hr2[1], h45 = hr2[2];
-    float h[6] = {h01.x, h01.y, h23.x, h23.y, h45.x, h45.y};
-    float hb   = sh.b[row];
+    const int prow  = lane < 3 ? lane : 2;
     const float4 xr = *reinterpret_cast<const float4*>(&sh.X[4 * prow]);
+    float H[36], b[6];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) {
+      H[i] = sh.H[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      b[i] = sh.b[i];
+    }
     if (g.b.prior) {
       const float* pr = g.b.prior + (size_t) frame * 42;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        h[c] += pr[6 * row + c];
+      for (int i = 0; i < 36; ++i) {
+        H[i] += pr[i];
       }
-      hb += pr[36 + row];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        b[i] += pr[36 + i];
+      }
     }
     if (g.a.enable_motion_prior) {
-      // AlignerSliceMotionModel3D stand-in (add_motion_prior): e = t2tnq(Z^-1 X), H[i][i] += info[i], b[i] += info[i] * e[i]
-      float X[16], e[6];
+      float X[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         X[i] = sh.X[i];
       }
-      if (g.prior_mean) {
-        const float* Z = g.prior_mean + (size_t) frame * 16;
-        float z[16], Zi[16], D[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          z[i] = Z[i];
-        }
-        se3_inverse(z, Zi);
-        se3_mul(Zi, X, D);
-        t2tnq(D, e);
-      } else {
-        t2tnq(X, e);
-      }
-      float er = e[0], ir = g.a.motion_prior_info[0];
-#pragma unroll
-      for (int k = 1; k < 6; ++k) {
-        er = row == k ? e[k] : er;
-        ir = row == k ? g.a.motion_prior_info[k] : ir;
-      }
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        h[c] = row == c ? h[c] + ir : h[c];
-      }
-      hb += ir * er;
+      add_motion_prior(g.a, g.prior_mean ? g.prior_mean + (size_t) frame * 16 : nullptr, X, H, b);
     }
     auto bcast = [](const float v, const int l) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
-    float Lr[6], inv[6];
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      float v = row == j ? fmaf(g.a.damping, h[j], h[j]) : h[j];  // H + damping diag(H)
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        if (k < j) {
-          v = fmaf(-Lr[k], bcast(Lr[k], j), v);
-        }
-      }
-      const float piv = bcast(v, j);
-      ok              = ok && piv > 0.0f;  // (no early exit: a failed pivot only poisons values that are dropped below)
-      inv[j]          = 1.0f / sqrtf(piv);
-      Lr[j]           = v * inv[j];
-    }
-    float y[6], dx[6];
-    float vy = -hb;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      y[k] = bcast(vy, k) * inv[k];
-      vy   = fmaf(-Lr[k], y[k], vy);
-    }
-#pragma unroll
-    for (int i = 5; i >= 0; --i) {
-      float v = y[i];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        if (k > i) {
-          v = fmaf(-bcast(Lr[i], k), dx[k], v);
-        }
-      }
-      dx[i] = v * inv[i];
-    }
+    float dx[6];
+    const bool ok = ldlt_solve6(H, b, g.a.damping, dx);
     float D[16];
     tnq2t(dx, D);
     float4 xn;

@@ -182,24 +182,28 @@ __device__ __forceinline__ void rotate_normal_equations(const float* A, float* H
   }
 }
 
-// (H + damping diag(H)) dx = -b by dense Cholesky (the damping form is a round-4 result of tools/sweep_a13.py); X <- X * exp(dx).  H: full 6x6 row-major (lower part
-// read), returns false (X untouched) when the system is not positive definite.
-__device__ __forceinline__ bool gn_step(const float* H, const float* b, float damping, float* X) {
-  // dense Cholesky with fused multiply-subtracts and one reciprocal per pivot
-  float L[6][6], inv[6];
+// (H + damping diag(H)) dx = -b by LDL^T (L unit lower triangular, D diagonal; the damping form is a round-4 result of
+// tools/sweep_a13.py).  H: full 6x6 row-major, the LOWER triangle is read.  U[i][j] = L[i][j] * D[j] is the entry before its division:
+//   d_j = (1 + damping) H_jj - sum_k<j L_jk U_jk;   U_ij = H_ij - sum_k<j L_ik U_jk,  L_ij = U_ij / d_j   (one reciprocal per pivot)
+//   y = L^-1 (-b);   dx = L^-T (y / d)
+// Fused multiply-subtracts in the order written; returns false when a pivot is not positive (dx is then garbage, to be dropped).
+// No square roots: round 4 replaced the Cholesky factorisation (six correctly rounded sqrt + six divisions were a third of the
+// instructions of the solve).  gn_kernel evaluates this function on every lane of the solving wave (uniform), the CPU checker
+// restates it (orc_gn_step).
+__device__ __forceinline__ bool ldlt_solve6(const float* H, const float* b, const float damping, float* dx) {
+  float L[6][6], U[6][6], inv[6];
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    float s = fmaf(damping, H[6 * j + j], H[6 * j + j]);
+    float d = fmaf(damping, H[6 * j + j], H[6 * j + j]);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       if (k < j) {
-        s = fmaf(-L[j][k], L[j][k], s);
+        d = fmaf(-L[j][k], U[j][k], d);
       }
     }
-    ok      = ok && s > 0.0f;  // (no early exit: a failed pivot only poisons values that are dropped below)
-    L[j][j] = sqrtf(s);
-    inv[j]  = 1.0f / L[j][j];
+    ok     = ok && d > 0.0f;  // (no early exit: a failed pivot only poisons values that are dropped)
+    inv[j] = 1.0f / d;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       if (i > j) {
@@ -207,14 +211,15 @@ __device__ __forceinline__ bool gn_step(const float* H, const float* b, float da
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
           if (k < j) {
-            v = fmaf(-L[i][k], L[j][k], v);
+            v = fmaf(-L[i][k], U[j][k], v);
           }
         }
+        U[i][j] = v;
         L[i][j] = v * inv[j];
       }
     }
   }
-  float y[6], dx[6];
+  float y[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     float v = -b[i];
@@ -224,19 +229,26 @@ __device__ __forceinline__ bool gn_step(const float* H, const float* b, float da
         v = fmaf(-L[i][k], y[k], v);
       }
     }
-    y[i] = v * inv[i];
+    y[i] = v;
   }
 #pragma unroll
   for (int i = 5; i >= 0; --i) {
-    float v = y[i];
+    float v = y[i] * inv[i];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       if (k > i) {
         v = fmaf(-L[k][i], dx[k], v);
       }
     }
-    dx[i] = v * inv[i];
+    dx[i] = v;
   }
+  return ok;
+}
+
+// one damped Gauss-Newton step: X <- X * exp(dx); returns false (X untouched) when the system is not positive definite
+__device__ __forceinline__ bool gn_step(const float* H, const float* b, float damping, float* X) {
+  float dx[6];
+  const bool ok = ldlt_solve6(H, b, damping, dx);
   float D[16], Xn[16];
   tnq2t(dx, D);
   se3_mul(X, D, Xn);
