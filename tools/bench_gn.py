@@ -1,3 +1,5 @@
+"""Per-kernel times of the headline step alone (matcher, search and Gauss-Newton launches by round), a few seconds on the GPU box.
+    python tools/bench_gn.py [batch]"""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch, bench
