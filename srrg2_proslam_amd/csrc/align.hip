@@ -1811,13 +1811,11 @@ __device__ __forceinline__ void gn_solve_wave(const AlignArgs& g, GnShared& sh, 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (lane < 6) {
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        if (j <= rrow) {
-          sh.H[6 * rrow + j] = o[j];
-          sh.H[6 * j + rrow] = o[j];
-        }
-      }
+      // (the whole row: the solve reads the lower triangle only; the upper one is mirrored when the kernel stores H)
+      float2* hw = reinterpret_cast<float2*>(&sh.H[6 * rrow]);
+      hw[0]      = make_float2(o[0], o[1]);
+      hw[1]      = make_float2(o[2], o[3]);
+      hw[2]      = make_float2(o[4], o[5]);
       sh.b[rrow] = bb;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2178,7 +2176,8 @@ __global__ __launch_bounds__(128, 4) void gn_kernel(const AlignArgs g) {
     gstate->local_map_in_sensor_previous[tid] = sh.Tprev[tid];
   }
   for (int i = tid; i < 36; i += THREADS) {
-    gres->H[i] = sh.H[i];
+    const int r = i / 6, c = i - 6 * r;
+    gres->H[i]  = sh.H[r >= c ? i : 6 * c + r];  // the lower triangle is the system (gn_solve_wave)
   }
   if (tid < 6) {
     gres->b[tid] = sh.b[tid];
