@@ -1276,12 +1276,26 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                     return dcol > col - width && dcol < col + width;
                   }
                 };
-                // the lattice scan: two entries per trip (the entry behind the last one of a segment is read but not used)
+                // the lattice scan: two entries per trip (the entry behind the last one of a segment is read but not used).  ONE loop over
+                // the entries of all cell rows of the query: a lane that has finished a cell row's segment moves on to the next row
+                // while its neighbours are still inside theirs, so a wave makes max over lanes of (sum over rows) trips instead of
+                // sum over rows of (max over lanes) -- the segments hold 3 +- 2 entries, which nearly halves the trips
                 auto scan = [&](auto accepts, auto visit) {
-                  for (int cy = r0 >> g.cell_sy; cy <= (r1 >> g.cell_sy); ++cy) {
-                    const int seg0 = cellstart[cy * g.cell_ncx + cx0];
-                    const int seg1 = cellstart[cy * g.cell_ncx + cx1 + 1];
-                    for (int pos = seg0; pos < seg1; pos += 2) {
+                  const uint16_t* cs = cellstart + (r0 >> g.cell_sy) * g.cell_ncx + cx0;  // bounds of the next cell row's segment
+                  const int width    = cx1 + 1 - cx0;
+                  int rows_left      = (r1 >> g.cell_sy) - (r0 >> g.cell_sy) + 1;
+                  int pos = 0, seg1 = 0;
+                  for (;;) {
+                    if (pos >= seg1) {
+                      if (rows_left <= 0) {
+                        break;
+                      }
+                      pos  = cs[0];
+                      seg1 = cs[width];
+                      cs += g.cell_ncx;
+                      --rows_left;
+                    }
+                    if (pos < seg1) {
                       // (whole entries at once: the fixed index of an accepted entry must not be a second, dependent LDS read)
                       const unsigned long long wa = reinterpret_cast<const unsigned long long*>(db)[pos];
                       const unsigned long long wb = reinterpret_cast<const unsigned long long*>(db)[pos + 1];
@@ -1294,6 +1308,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                       if (in_b) {
                         visit(eb.y);
                       }
+                      pos += 2;
                     }
                   }
                 };
