@@ -519,7 +519,8 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
   uint16_t* cellstart = reinterpret_cast<uint16_t*>(smem + g.off_cellstart);
   float4* cfix        = reinterpret_cast<float4*>(smem + g.off_cfix);      // per-correspondence fixed measurement
   float4* cmov        = reinterpret_cast<float4*>(smem + g.off_cmov);      // per-correspondence moving point + information scale
-  au32x4* fdesc       = reinterpret_cast<au32x4*>(smem + g.off_fdesc);    // fixed descriptor rows (search phase only)
+  au32x4* fdesc       = reinterpret_cast<au32x4*>(smem + g.off_fdesc);    // fixed descriptor rows (search phase only): first halves of all rows, then second halves
+  au32x4* fdesc_hi    = fdesc + g.max_fixed;                               // (16-byte stride: a gather of first halves spreads over all 32 LDS banks; 32-byte rows hit 16)
   float2* fuv         = reinterpret_cast<float2*>(smem + g.off_fuv);      // fixed (u,v) in index order (KD-tree variant)
   uint32_t* bestkey   = reinterpret_cast<uint32_t*>(smem + g.off_best);
   uint32_t* second    = reinterpret_cast<uint32_t*>(smem + g.off_second);
@@ -1128,7 +1129,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
             second[i]  = kNoneU32;
           }
           for (int i = tid; i < 2 * nF; i += T) {
-            fdesc[i] = gfd[i];  // coalesced 16 B/lane; the rows are re-read ~10x per query from LDS
+            (i & 1 ? fdesc_hi : fdesc)[i >> 1] = gfd[i];  // coalesced 16 B/lane; the rows are re-read ~10x per query from LDS
           }
           if (!lattice) {
             for (int i = tid; i < nF; i += T) {
@@ -1230,7 +1231,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                   const float2 c = fuv[fi];
                   const float du = c.x - u, dv = c.y - v;
                   if (du * du + dv * dv < r2f) {
-                    const uint32_t d   = (uint32_t) hamming_regs(fdesc[2 * fi], fdesc[2 * fi + 1], q0, q1);
+                    const uint32_t d   = (uint32_t) hamming_regs(fdesc[fi], fdesc_hi[fi], q0, q1);
                     const uint32_t key = (float) d < max_dd ? ((d << 16) | (uint32_t) fi) : kNoneU32;
                     bestk              = key < bestk ? key : bestk;
                   }
@@ -1315,7 +1316,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                 const bool lean_circle = stype == PRS_SEARCH_CIRCLE && circle_exact;
                 auto score = [&](const uint32_t ey) {  // ey: fixed index | canonical lattice position << 16
                   const int fi     = (int) (ey & 0xffffu);
-                  const uint32_t d = (uint32_t) hamming_regs(fdesc[2 * fi], fdesc[2 * fi + 1], q0, q1);
+                  const uint32_t d = (uint32_t) hamming_regs(fdesc[fi], fdesc_hi[fi], q0, q1);
                   // best / second best (circle_impl.cpp:64-72) as min / second-min of unique keys
                   const uint32_t key = (d << 16) | (ey >> 16);
                   const uint32_t hi  = key > bestk ? key : bestk;
@@ -1327,7 +1328,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                   // irrelevance bound (irrelevant_distance) are remembered and scored in full after the scan
                   uint32_t kept = 0xffffffffu;  // canonical lattice positions of up to two such candidates (0xffff: none)
                   auto prescore = [&](const uint32_t ey) {
-                    if (hamming_half(fdesc[2 * (int) (ey & 0xffffu)], q0) < prune_at) {
+                    if (hamming_half(fdesc[(int) (ey & 0xffffu)], q0) < prune_at) {
                       const uint32_t evicted = kept >> 16;
                       if (evicted != 0xffffu) {
                         score((uint32_t) inv[evicted] | (evicted << 16));
