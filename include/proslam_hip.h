@@ -415,7 +415,8 @@ PRS_API int prs_pcf_linearize(prs_pcf* h,
                               int32_t n_corr,
                               prs_align_result* result);
 
-/* (H + damping diag(H)) dx = -b, X <- X * exp(dx) on the device (same arithmetic as the fused loop) */
+/* (H + damping diag(H)) dx = -b, X <- X * exp(dx) on the device (same arithmetic as the aligner loops: LDL^T without square roots,
+ * csrc/prs_se3.h ldlt_solve6; H row-major, its LOWER triangle is read; a pivot that is not positive leaves X untouched) */
 PRS_API int prs_gn_step(prs_context* ctx, const float* H36, const float* b6, float damping, float* X16);
 
 /* host helper: information scale column from landmark ages
