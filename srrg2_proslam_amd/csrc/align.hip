@@ -1963,10 +1963,17 @@ constexpr int kGnLdsSlots = 4;
 // ... plus the rows of ONE more wave (64 correspondences, 2 KB): a frame with a few correspondences more than 512 (the TUM-shaped
 // workload: 524) otherwise waits for a global-memory round trip in every one of its 200 iterations (round 4: 9.0 -> 4.6 ms per
 // 4608 frames).  8 frames x (16 + 2 + 0.7) KB = 150 KB of the CU's 160 KB.
-constexpr int kGnLdsRows = kGnLdsSlots * 128 + 64;
-template <int SLOTS, int DIM, bool KEEP_CLS>
-__global__ __launch_bounds__(128, 4) void gn_kernel(const AlignArgs g) {
+// LDS_SLOTS / WAVES: the instantiation of the headline configuration (stereo factor, up to 1024 fixed points) parks 448 rows and is
+// built for five waves per SIMD (96 VGPRs, ten frames per CU: 15 KB each): -3.5 % on the headline, -5 % on real KITTI frames; the
+// generic ones lose with it (spills, streamed rows) and keep four waves per SIMD and 576 parked rows
+constexpr size_t gn_lds_bytes(const int lds_slots) {
+  return ((sizeof(GnShared) + 15) / 16) * 16 + (size_t) (lds_slots * 128 + 64) * 2 * sizeof(float4);  // shared state + parked operand rows
+}
+template <int SLOTS, int DIM, bool KEEP_CLS, int LDS_SLOTS = kGnLdsSlots, int WAVES = 4>
+__global__ __launch_bounds__(128, WAVES) void gn_kernel(const AlignArgs g) {
   constexpr int THREADS = 128;
+  constexpr int kGnLdsSlots = LDS_SLOTS;  // (shadow the defaults)
+  constexpr int kGnLdsRows  = LDS_SLOTS * 128 + 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid   = threadIdx.x;
   const int lane  = tid & 63;
@@ -2507,9 +2514,10 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   // (the rectified-stereo factor, the one kitti.conf / euroc.conf use, has its own instantiation: the factor type as a
   // compile-time constant removes ~10 selects per linearised correspondence; so does not remembering the factor classes)
   const bool fast = aligner->factor_type == PRS_FACTOR_STEREO && !aligner->keep_only_inlier_correspondences;
+  const bool five = fast && max_fixed > 4 * 128;  // (gn_kernel: LDS_SLOTS / WAVES)
   auto gnk        = max_fixed <= 4 * 128 ? (fast ? gn_kernel<4, PRS_FACTOR_STEREO, false> : gn_kernel<4, 0, true>)
-                                         : (fast ? gn_kernel<8, PRS_FACTOR_STEREO, false> : gn_kernel<8, 0, true>);
-  const size_t lds_gn = ((sizeof(GnShared) + 15) / 16) * 16 + (size_t) kGnLdsRows * 2 * sizeof(float4);  // shared state + parked operand rows
+                                         : (fast ? gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5> : gn_kernel<8, 0, true>);
+  const size_t lds_gn = gn_lds_bytes(five ? 3 : kGnLdsSlots);
   // The job lives in the context until align_batch_finish: the rounds are plain launches on the context's stream (no host
   // synchronisation here, the sequence can be captured in a HIP graph once the scratch buffers exist).
   job->active      = true;
