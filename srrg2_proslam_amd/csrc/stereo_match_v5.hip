@@ -588,22 +588,19 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
             // more than four in-window candidates, scored into the pool: best / second best from the cursor on
             const uint32_t poff = w.x & 0xffffu;
             const int hi        = lo + (int) (w.x >> 16);
-            uint32_t best = kNone, second = kNone, best_q = 0, best_keep = 0;
+            // best / second best (epipolar_impl.cpp:158-164: the first of equal distances wins, the second best counts multiplicity) as
+            // the smallest and second smallest of the unique keys (distance, position, keep bit): no branch in the loop -- the 64 rows
+            // of a wave are at different places of theirs, a divergent branch costs every lane both sides
+            uint32_t bestk = 0xffffffffu, seck = 0xffffffffu;
             for (int q = c > lo ? c : lo; q < hi; ++q) {
-              const uint32_t e = pool[poff + (uint32_t) (q - lo)];
-              if (e & kPoolPruned) {
-                continue;
-              }
-              const uint32_t d = e & 0x1ffu;
-              if (d < best) {  // epipolar_impl.cpp:158-164
-                second    = best;
-                best      = d;
-                best_q    = (uint32_t) q;
-                best_keep = (e >> 12) & 1u;
-              } else if (d < second) {
-                second = d;
-              }
+              const uint32_t e   = pool[poff + (uint32_t) (q - lo)];
+              const uint32_t key = (e & kPoolPruned) ? 0xffffffffu : (((e & 0x1ffu) << 17) | ((uint32_t) q << 1) | ((e >> 12) & 1u));
+              const uint32_t hk  = key > bestk ? key : bestk;
+              seck               = hk < seck ? hk : seck;
+              bestk              = key < bestk ? key : bestk;
             }
+            const uint32_t best = bestk == 0xffffffffu ? kNone : bestk >> 17, second = seck == 0xffffffffu ? kNone : seck >> 17;
+            const uint32_t best_q = (bestk >> 1) & 0xffffu, best_keep = bestk & 1u;
             if (best != kNone && (int) best < best_lim && (int) best <= (int) tab[second == kNone ? 257u : second]) {
               dist4[p] = (sortedR[best_q] & 0xffffu) | (best << 16);  // (res[p] keeps the pool reference: the row may be replayed)
               outv[p]  = ((8u | best_keep) << 28) | kOutRescored | (kept << 12) | cnt;
