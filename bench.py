@@ -564,6 +564,32 @@ def kitti_real_leg(device_index, cfg, batch, target=2000, steps=3):
 # ---------------------------------------------------------------------------------------------------------------------
 # latency of the drop-in path: one sequence, one frame at a time, host pointers (tools/latency_b1.cpp)
 # ---------------------------------------------------------------------------------------------------------------------
+def write_latency_frames(path, par, seq):
+    """the frames file tools/latency_b1.cpp reads: header, parameter block, then per frame the flat arrays"""
+    import struct
+    N, NM = seq[0]["fr"]["uv_left"].shape[0], seq[0]["mp"]["xyz"].shape[0]
+    with open(path, "wb") as fh:
+        fh.write(struct.pack("<4i", len(seq), N, NM, len(par)))
+        fh.write(np.asarray(par, np.float32).tobytes())
+        for d in seq:
+            fr, mp = d["fr"], d["mp"]
+            for a, dt in ((fr["uv_left"], np.float32), (fr["desc_left"], np.uint8), (fr["uv_right"], np.float32), (fr["desc_right"], np.uint8),
+                          (mp["xyz"], np.float32), (mp["desc"], np.uint8), (mp["n_opt"], np.uint32), (d["X0"], np.float32)):
+                fh.write(np.ascontiguousarray(a, dt).tobytes())
+
+
+def latency_params(cfg):
+    cam, m, tri, f, al = cfg["camera"], cfg["stereo_matcher"], cfg["triangulator"], cfg["projective_finder"], cfg["aligner"]
+    return [cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["cols"], cam["rows"], cam["baseline_m"], cfg["projector"]["range_min"], cfg["projector"]["range_max"],
+            m["maximum_descriptor_distance"], m["maximum_distance_ratio_to_second_best"], m["minimum_matching_ratio"], m["maximum_disparity_pixels"],
+            m["epipolar_line_thickness_pixels"], tri["minimum_disparity_pixels"], tri["infinity_depth_meters"],
+            f["maximum_descriptor_distance"], f["maximum_distance_ratio_to_second_best"], f["minimum_matching_ratio"], f["minimum_descriptor_distance"],
+            f["descriptor_distance_step_size_pixels"], f["maximum_search_radius_pixels"], f["minimum_search_radius_pixels"], f["search_radius_step_size_pixels"],
+            f["minimum_number_of_iterations"], f["maximum_estimate_change_norm_for_convergence"], f["number_of_solver_iterations_per_projection"],
+            al["diagonal_info"][0], al["diagonal_info"][1], al["diagonal_info"][2], al["chi_threshold"], al["enable_inverse_depth_weighting"], al["damping"],
+            al["max_iterations"], al["min_num_inliers"], al["min_num_correspondences"], -cam["fx"] * cam["baseline_m"]]
+
+
 def latency_b1(cfg, frames, n_frames=64):
     """one frame at a time through the C++ adapters of plugin/ (AoS clouds, gather included) and through the bare C-ABI (flat arrays),
     PCIe and launch latency included; the CPU checker on the same frames beside it, poses compared"""
@@ -574,28 +600,12 @@ def latency_b1(cfg, frames, n_frames=64):
     exe = os.path.join(ROOT, "tools", "bin", "latency_b1")
     if not os.path.exists(exe):
         return {"error": "tools/bin/latency_b1 is not built (__graft_entry__.build())"}
-    cam, m, tri, f, al = cfg["camera"], cfg["stereo_matcher"], cfg["triangulator"], cfg["projective_finder"], cfg["aligner"]
-    par = [cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["cols"], cam["rows"], cam["baseline_m"], cfg["projector"]["range_min"], cfg["projector"]["range_max"],
-           m["maximum_descriptor_distance"], m["maximum_distance_ratio_to_second_best"], m["minimum_matching_ratio"], m["maximum_disparity_pixels"],
-           m["epipolar_line_thickness_pixels"], tri["minimum_disparity_pixels"], tri["infinity_depth_meters"],
-           f["maximum_descriptor_distance"], f["maximum_distance_ratio_to_second_best"], f["minimum_matching_ratio"], f["minimum_descriptor_distance"],
-           f["descriptor_distance_step_size_pixels"], f["maximum_search_radius_pixels"], f["minimum_search_radius_pixels"], f["search_radius_step_size_pixels"],
-           f["minimum_number_of_iterations"], f["maximum_estimate_change_norm_for_convergence"], f["number_of_solver_iterations_per_projection"],
-           al["diagonal_info"][0], al["diagonal_info"][1], al["diagonal_info"][2], al["chi_threshold"], al["enable_inverse_depth_weighting"], al["damping"],
-           al["max_iterations"], al["min_num_inliers"], al["min_num_correspondences"], -cam["fx"] * cam["baseline_m"]]
+    par = latency_params(cfg)
     seq = [frames[k % len(frames)] for k in range(n_frames)]
-    N, NM = seq[0]["fr"]["uv_left"].shape[0], seq[0]["mp"]["xyz"].shape[0]
     warm = 4
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "frames.bin")
-        with open(path, "wb") as fh:
-            fh.write(struct.pack("<4i", n_frames, N, NM, len(par)))
-            fh.write(np.asarray(par, np.float32).tobytes())
-            for d in seq:
-                fr, mp = d["fr"], d["mp"]
-                for a, dt in ((fr["uv_left"], np.float32), (fr["desc_left"], np.uint8), (fr["uv_right"], np.float32), (fr["desc_right"], np.uint8),
-                              (mp["xyz"], np.float32), (mp["desc"], np.uint8), (mp["n_opt"], np.uint32), (d["X0"], np.float32)):
-                    fh.write(np.ascontiguousarray(a, dt).tobytes())
+        write_latency_frames(path, par, seq)
         run = subprocess.run([exe, path, str(warm)], capture_output=True, text=True, timeout=600)
         if run.returncode != 0:
             return {"error": "latency_b1 exit %d: %s" % (run.returncode, run.stderr[-400:])}

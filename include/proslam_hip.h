@@ -283,7 +283,23 @@ typedef struct {
    * Z = prs_align_batch.prior_mean (NULL = identity: the local map was clipped at the motion-model prediction). */
   int32_t enable_motion_prior;
   float motion_prior_info[6];
+  /* Readings of the un-vendored srrg2_solver arithmetic, selectable per call.  0 everywhere
+   * (what memset gives) = the shipped family, the one under which all 17 pose bounds of the reference's gtests hold
+   * (DESIGN.md section 2).  The other values are the readings a maintainer with the real srrg2_solver sources may need instead
+   * ("Which upstream lines decide the a13 forms"); the CPU checker switches the same forms (orc_set_variant). */
+  int32_t kernel_weight_form;      /* RobustifierSaturated, chi > chi_threshold: PRS_KERNEL_WEIGHT_INV_CHI Omega / chi (shipped);
+                                      PRS_KERNEL_WEIGHT_TAU_OVER_CHI Omega * chi_threshold / chi (the form of the in-repo smoother,
+                                      mapping/landmarks/landmark_estimator_pose_based_smoother_impl.cpp:81-84) */
+  int32_t damping_form;            /* IterationAlgorithmGN: PRS_DAMPING_DIAG (H + damping diag(H)) dx = -b (shipped);
+                                      PRS_DAMPING_IDENTITY (H + damping I) dx = -b */
+  int32_t translation_weight_form; /* aligner_slice_processor_projective.cpp:107-112, dn = d / mean disparity:
+                                      PRS_TRANSLATION_WEIGHT_OFFSET min(0.01 + dn, 1) (shipped, the literal "(0.01+d,1)*I");
+                                      PRS_TRANSLATION_WEIGHT_CLAMP clamp(dn, 0.01, 1).  Non-finite results count as 1 (0.01 for a NaN
+                                      under CLAMP). */
 } prs_aligner_params;
+enum { PRS_KERNEL_WEIGHT_INV_CHI = 0, PRS_KERNEL_WEIGHT_TAU_OVER_CHI = 1 };
+enum { PRS_DAMPING_DIAG = 0, PRS_DAMPING_IDENTITY = 1 };
+enum { PRS_TRANSLATION_WEIGHT_OFFSET = 0, PRS_TRANSLATION_WEIGHT_CLAMP = 1 };
 
 /* The normal equations of one linearisation.  Every one of the 29 sums (21 entries of the upper triangle of H, 6 of b,
  * the two chi) is a FIXED-SHAPE float reduction over the correspondence vector (BUILD-DEFINED: the upstream factor loop
@@ -375,6 +391,11 @@ PRS_API int prs_align_batch_enqueue(prs_context* ctx,
                                     int32_t rounds);
 PRS_API int prs_align_batch_finish(prs_context* ctx);
 PRS_API int prs_align_batch_rearm(prs_context* ctx);
+/* rearm for a graph that is replayed on ANOTHER stream than the one the batch was enqueued / captured on: finish then synchronises
+ * `hip_stream` (a hipStream_t) and enqueues its extra rounds there.  prs_align_batch_rearm assumes the capture stream; replaying
+ * elsewhere without telling the library would let finish read the completion word before the replay has run.  Either way the
+ * number of rounds the graph holds is the `rounds` the captured enqueue was called with (remembered by the context). */
+PRS_API int prs_align_batch_rearm_on(prs_context* ctx, void* hip_stream);
 
 /* ---- host, one frame: stateful finder handle mirroring the reference object -------------------
  * setFixed / setMoving / setLocalMapInSensor / compute (tests/test_correspondence_finders.cpp:314,
@@ -418,6 +439,8 @@ PRS_API int prs_pcf_linearize(prs_pcf* h,
 /* (H + damping diag(H)) dx = -b, X <- X * exp(dx) on the device (same arithmetic as the aligner loops: LDL^T without square roots,
  * csrc/prs_se3.h ldlt_solve6; H row-major, its LOWER triangle is read; a pivot that is not positive leaves X untouched) */
 PRS_API int prs_gn_step(prs_context* ctx, const float* H36, const float* b6, float damping, float* X16);
+/* the same with the damping form chosen (prs_aligner_params.damping_form: PRS_DAMPING_DIAG or PRS_DAMPING_IDENTITY) */
+PRS_API int prs_gn_step_ex(prs_context* ctx, const float* H36, const float* b6, float damping, int32_t damping_form, float* X16);
 
 /* host helper: information scale column from landmark ages
  * (aligner_slice_processor_projective.cpp:46-52: n > 2 ? 1 + log(n) : 1) */

@@ -139,6 +139,9 @@ class AlignerParams(C.Structure):
         ("sensor_in_robot", C.c_float * 16),
         ("enable_motion_prior", C.c_int32),
         ("motion_prior_info", C.c_float * 6),
+        ("kernel_weight_form", C.c_int32),       # 0 Omega / chi (shipped), 1 Omega * tau / chi
+        ("damping_form", C.c_int32),             # 0 H + lambda diag(H) (shipped), 1 H + lambda I
+        ("translation_weight_form", C.c_int32),  # 0 min(0.01 + dn, 1) (shipped), 1 clamp(dn, 0.01, 1)
     ]
 
 
@@ -281,6 +284,7 @@ SYMBOLS = {
     "prs_align_batch_enqueue": (C.c_int, [_vp, C.POINTER(PcfParams), C.POINTER(AlignerParams), C.POINTER(AlignBatch), C.c_int32]),
     "prs_align_batch_finish": (C.c_int, [_vp]),
     "prs_align_batch_rearm": (C.c_int, [_vp]),
+    "prs_align_batch_rearm_on": (C.c_int, [_vp, _vp]),
     "prs_pcf_create": (C.c_int, [_vp, C.POINTER(PcfParams), C.POINTER(_vp)]),
     "prs_pcf_destroy": (C.c_int, [_vp]),
     "prs_pcf_set_params": (C.c_int, [_vp, C.POINTER(PcfParams)]),
@@ -295,6 +299,7 @@ SYMBOLS = {
     "prs_pcf_align": (C.c_int, [_vp, C.POINTER(AlignerParams), _vp, _vp, _vp, _vp, C.c_int32, _i32p, C.POINTER(AlignResult)]),
     "prs_pcf_linearize": (C.c_int, [_vp, C.POINTER(AlignerParams), _vp, _vp, C.c_int32, C.POINTER(AlignResult)]),
     "prs_gn_step": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp]),
+    "prs_gn_step_ex": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_int32, _vp]),
     "prs_info_scale_from_nopt": (None, [_vp, C.c_int32, _vp]),
     "prs_triangulate": (C.c_int, [_vp, C.POINTER(TriangulatorParams), _vp, C.c_int32, _vp, _vp]),
     "prs_triangulate_dev": (C.c_int, [_vp, C.POINTER(TriangulatorParams), _vp, C.c_int64, _vp]),

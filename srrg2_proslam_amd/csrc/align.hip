@@ -230,10 +230,17 @@ __device__ __forceinline__ bool pose_is_finite(const PoseRegs& X) {
 // DIM: the factor type as a compile-time constant (0 = read it from the parameters)
 // inverse-depth weight of a stereo measurement (aligner_slice_processor_projective.cpp:107-112): a function of the measurement and
 // the frame's mean disparity only, so callers that iterate over fixed correspondences evaluate it once (PRE_WT: z.w carries it)
-// "(0.01 + d, 1) * I": wt = min(0.01 + d / mean disparity, 1); NaN (0 / 0) -> 1 (round 4: tools/sweep_a13.py)
-__device__ __forceinline__ float inverse_depth_weight(const float4 z, const float mean_dsp) {
-  const float wt = 0.01f + (z.x - z.z) / mean_dsp;
-  return wt < 1.0f ? wt : 1.0f;
+// "(0.01 + d, 1) * I": wt = min(0.01 + d / mean disparity, 1); NaN (0 / 0) and +-inf -> 1 (round 4: tools/sweep_a13.py).
+// The result is always finite (a weight of -inf -- a negative disparity over a zero mean -- times the zero K of an invalid
+// correspondence would be a NaN in the sums of the whole frame).  clamp_form: prs_aligner_params.translation_weight_form,
+// clamp(d / mean disparity, 0.01, 1), NaN -> 0.01.
+__device__ __forceinline__ float inverse_depth_weight(const float4 z, const float mean_dsp, const int clamp_form) {
+  const float dn = (z.x - z.z) / mean_dsp;
+  if (clamp_form) {
+    return !(dn >= 0.01f) ? 0.01f : (dn > 1.0f ? 1.0f : dn);
+  }
+  const float wt = 0.01f + dn;
+  return wt < 1.0f ? (wt >= -kFltMax ? wt : 1.0f) : 1.0f;
 }
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kPairs = 16;  // the 29 sums + 3 class counts of one linearisation travel as 16 float pairs (32 "slots")
@@ -296,7 +303,7 @@ __device__ __forceinline__ void factor_accumulate(const prs_aligner_params& a, c
   }
   float wt = 1.0f;
   if (dim == PRS_FACTOR_STEREO && a.enable_inverse_depth_weighting) {
-    wt = PRE_WT ? z.w : inverse_depth_weight(z, mean_dsp);  // finite: min(.., 1) maps NaN and +inf to 1
+    wt = PRE_WT ? z.w : inverse_depth_weight(z, mean_dsp, a.translation_weight_form);  // always finite
   }
   const float alpha = fx * iz, gamma = fy * iz;
   const float beta0 = (cx - u_pred) * iz;
@@ -314,7 +321,8 @@ __device__ __forceinline__ void factor_accumulate(const prs_aligner_params& a, c
   // saturated kernel: a kernelised factor is weighted 1 / chi (round 4: tools/sweep_a13.py; a factor of exactly 1 leaves the
   // unsaturated weights untouched)
   const bool saturated = valid && chi > a.chi_threshold;
-  const float ratio    = inlier_only ? 0.0f : 1.0f / chi;  // inlier-only run: kernelised factors are suppressed
+  // (prs_aligner_params.kernel_weight_form: tau / chi instead; the division has the same cost with either numerator)
+  const float ratio    = inlier_only ? 0.0f : (a.kernel_weight_form == PRS_KERNEL_WEIGHT_TAU_OVER_CHI ? a.chi_threshold : 1.0f) / chi;  // inlier-only run: kernelised factors are suppressed
   const float scale    = saturated ? ratio : 1.0f;
   o0 *= scale;
   o1 *= scale;
@@ -1636,7 +1644,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
       if (g.a.enable_motion_prior) {
         add_motion_prior(g.a, g.prior_mean ? g.prior_mean + (size_t) frame * 16 : nullptr, X, H, b);
       }
-      gn_step(H, b, g.a.damping, X);
+      gn_step(H, b, g.a.damping, X, g.a.damping_form == PRS_DAMPING_IDENTITY);
       uint32_t changed_bits = 0;  // (bitwise, no short-circuit: sixteen compares would be sixteen branches)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -1879,7 +1887,7 @@ __device__ __forceinline__ void gn_solve_wave(const AlignArgs& g, GnShared& sh, 
     }
     auto bcast = [](const float v, const int l) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
     float dx[6];
-    const bool ok = ldlt_solve6(H, b, g.a.damping, dx);
+    const bool ok = ldlt_solve6(H, b, g.a.damping, dx, g.a.damping_form == PRS_DAMPING_IDENTITY);
     float D[16];
     tnq2t(dx, D);
     float4 xn;
@@ -2042,7 +2050,7 @@ __global__ __launch_bounds__(128, WAVES) void gn_kernel(const AlignArgs g) {
     const int c = k * THREADS + tid;
     if (k * THREADS < nc && c < LROWS) {
       float4 z = c < nc ? gops[2 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
-      z.w      = inverse_depth_weight(z, mean_dsp);  // (the factors read x, y, z of the measurement only)
+      z.w      = inverse_depth_weight(z, mean_dsp, g.a.translation_weight_form);  // (the factors read x, y, z of the measurement only)
       lz[c]    = z;
       lp[c]    = c < nc ? gops[2 * c + 1] : make_float4(0.f, 0.f, 1.f, 1.f);
     }
@@ -2108,7 +2116,7 @@ __global__ __launch_bounds__(128, WAVES) void gn_kernel(const AlignArgs g) {
             } else {
               z   = c < nc ? gops[2 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
               p   = c < nc ? gops[2 * c + 1] : make_float4(0.f, 0.f, 1.f, 1.f);
-              z.w = inverse_depth_weight(z, mean_dsp);
+              z.w = inverse_depth_weight(z, mean_dsp, g.a.translation_weight_form);
             }
             int cls;
             factor_accumulate<DIM, true>(g.a, pose, z, p, mean_dsp, c < nc, acc, code, cls, inlier_run);
@@ -2263,7 +2271,7 @@ __global__ void split_init_kernel(FrameCtl* ctl, prs_align_result* res, int* pen
   }
 }
 
-__global__ void gn_step_kernel(const float* H, const float* b, float damping, float* X, int* ok) {
+__global__ void gn_step_kernel(const float* H, const float* b, float damping, int identity_damping, float* X, int* ok) {
   float h[36], bb[6], x[16];
   for (int i = 0; i < 36; ++i) {
     h[i] = H[i];
@@ -2274,7 +2282,7 @@ __global__ void gn_step_kernel(const float* H, const float* b, float damping, fl
   for (int i = 0; i < 16; ++i) {
     x[i] = X[i];
   }
-  const bool r = gn_step(h, bb, damping, x);
+  const bool r = gn_step(h, bb, damping, x, identity_damping != 0);
   for (int i = 0; i < 16; ++i) {
     X[i] = x[i];
   }
@@ -2324,6 +2332,7 @@ struct SplitJob {
   void (*gn)(AlignArgs)     = nullptr;
   size_t lds_search = 0, lds_gn = 0;
   int total = 0, limit = 0;  // rounds launched so far / upper bound
+  int enqueued = 0;          // rounds align_batch_launch enqueued (what a captured graph replays)
   int ev_used = 0;
   int rounds_timed = 0;
   bool stamps = false;
@@ -2357,6 +2366,11 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   }
   if (aligner->factor_type != PRS_FACTOR_MONO && aligner->factor_type != PRS_FACTOR_DEPTH && aligner->factor_type != PRS_FACTOR_STEREO) {
     return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_run: factor_type must be 2, 3 or 4");
+  }
+  if ((aligner->kernel_weight_form != PRS_KERNEL_WEIGHT_INV_CHI && aligner->kernel_weight_form != PRS_KERNEL_WEIGHT_TAU_OVER_CHI) ||
+      (aligner->damping_form != PRS_DAMPING_DIAG && aligner->damping_form != PRS_DAMPING_IDENTITY) ||
+      (aligner->translation_weight_form != PRS_TRANSLATION_WEIGHT_OFFSET && aligner->translation_weight_form != PRS_TRANSLATION_WEIGHT_CLAMP)) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_run: unknown kernel_weight_form / damping_form / translation_weight_form");
   }
   AlignArgs g;
   g.f          = *finder;
@@ -2533,7 +2547,8 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   job->ev_used     = 0;
   job->rounds_timed = 0;
   job->stamps      = stamps_split;
-  return split_rounds(ctx, job, rounds > 0 ? rounds : 5);
+  job->enqueued    = rounds > 0 ? rounds : 5;
+  return split_rounds(ctx, job, job->enqueued);
 }
 
 // `rounds` x (search launch, Gauss-Newton launch) over the frames that are still pending; every launch skips the others
@@ -2624,8 +2639,10 @@ int align_batch_finish(prs_context* ctx) {
 }
 
 // a HIP graph captured around align_batch_launch replays the rounds without passing through the host code: re-arm the job so
-// that align_batch_finish checks completion (and adds rounds) for the replayed batch too
-int align_batch_rearm(prs_context* ctx) {
+// that align_batch_finish checks completion (and adds rounds) for the replayed batch too.  `replay_stream`: the stream the graph
+// was launched on (NULL = the stream the batch was enqueued / captured on); finish synchronises THAT stream and enqueues its extra
+// rounds there, so a replay on another stream is not raced.
+int align_batch_rearm(prs_context* ctx, hipStream_t replay_stream) {
   SplitJob* job = static_cast<SplitJob*>(ctx->align_job);
   if (!job || !job->gn) {
     return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_rearm: no batch has been enqueued on this context");
@@ -2633,8 +2650,11 @@ int align_batch_rearm(prs_context* ctx) {
   if (job->active) {
     return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_rearm: the previous batch has not been finished");
   }
+  if (replay_stream) {
+    job->stream = replay_stream;
+  }
   job->active       = true;
-  job->total        = 5;
+  job->total        = job->enqueued;  // the rounds the captured enqueue holds
   job->ev_used      = 0;
   job->rounds_timed = 0;
   return PRS_OK;
@@ -2645,8 +2665,8 @@ bool align_job_active(const prs_context* ctx) {
   return job && job->active;
 }
 
-int gn_step_launch(prs_context* ctx, const float* dH, const float* db, float damping, float* dX, int* dok) {
-  hipLaunchKernelGGL(gn_step_kernel, dim3(1), dim3(1), 0, ctx_stream(ctx), dH, db, damping, dX, dok);
+int gn_step_launch(prs_context* ctx, const float* dH, const float* db, float damping, int damping_form, float* dX, int* dok) {
+  hipLaunchKernelGGL(gn_step_kernel, dim3(1), dim3(1), 0, ctx_stream(ctx), dH, db, damping, damping_form == PRS_DAMPING_IDENTITY ? 1 : 0, dX, dok);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_gn_step launch");

@@ -439,7 +439,14 @@ int prs_align_batch_rearm(prs_context* ctx) {
   if (!ctx) {
     return PRS_ERR_NULL;
   }
-  return align_batch_rearm(ctx);
+  return align_batch_rearm(ctx, nullptr);
+}
+
+int prs_align_batch_rearm_on(prs_context* ctx, void* hip_stream) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  return align_batch_rearm(ctx, static_cast<hipStream_t>(hip_stream));
 }
 
 int prs_triangulate_dev(prs_context* ctx, const prs_triangulator_params* params, const float* d_uvuv, int64_t n, float* d_xyz4) {

@@ -413,8 +413,15 @@ int prs_pcf_linearize(prs_pcf* h, const prs_aligner_params* aligner, const float
 }
 
 int prs_gn_step(prs_context* ctx, const float* H36, const float* b6, float damping, float* X16) {
+  return prs_gn_step_ex(ctx, H36, b6, damping, PRS_DAMPING_DIAG, X16);
+}
+
+int prs_gn_step_ex(prs_context* ctx, const float* H36, const float* b6, float damping, int32_t damping_form, float* X16) {
   if (!ctx || !H36 || !b6 || !X16) {
     return PRS_ERR_NULL;
+  }
+  if (damping_form != PRS_DAMPING_DIAG && damping_form != PRS_DAMPING_IDENTITY) {
+    return prs::ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_gn_step_ex: unknown damping form");
   }
   (void) hipSetDevice(ctx->device);
   float* d = static_cast<float*>(prs::ctx_device_scratch_slot(ctx, 2, 512));
@@ -432,7 +439,7 @@ int prs_gn_step(prs_context* ctx, const float* H36, const float* b6, float dampi
   if (e != hipSuccess) {
     return prs::ctx_fail_hip(ctx, e, "prs_gn_step upload");
   }
-  const int rc = prs::gn_step_launch(ctx, d, d + 36, damping, d + 48, reinterpret_cast<int*>(d + 64));
+  const int rc = prs::gn_step_launch(ctx, d, d + 36, damping, damping_form, d + 48, reinterpret_cast<int*>(d + 64));
   if (rc != PRS_OK) {
     return rc;
   }

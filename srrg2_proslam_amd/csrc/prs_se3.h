@@ -183,19 +183,19 @@ __device__ __forceinline__ void rotate_normal_equations(const float* A, float* H
 }
 
 // (H + damping diag(H)) dx = -b by LDL^T (L unit lower triangular, D diagonal; the damping form is a round-4 result of
-// tools/sweep_a13.py).  H: full 6x6 row-major, the LOWER triangle is read.  U[i][j] = L[i][j] * D[j] is the entry before its division:
+// tools/sweep_a13.py; identity_damping selects (H + damping I) dx = -b, prs_aligner_params.damping_form).  H: full 6x6 row-major, the LOWER triangle is read.  U[i][j] = L[i][j] * D[j] is the entry before its division:
 //   d_j = (1 + damping) H_jj - sum_k<j L_jk U_jk;   U_ij = H_ij - sum_k<j L_ik U_jk,  L_ij = U_ij / d_j   (one reciprocal per pivot)
 //   y = L^-1 (-b);   dx = L^-T (y / d)
 // Fused multiply-subtracts in the order written; returns false when a pivot is not positive (dx is then garbage, to be dropped).
 // No square roots: round 4 replaced the Cholesky factorisation (six correctly rounded sqrt + six divisions were a third of the
 // instructions of the solve).  gn_kernel evaluates this function on every lane of the solving wave (uniform), the CPU checker
 // restates it (orc_gn_step).
-__device__ __forceinline__ bool ldlt_solve6(const float* H, const float* b, const float damping, float* dx) {
+__device__ __forceinline__ bool ldlt_solve6(const float* H, const float* b, const float damping, float* dx, const bool identity_damping = false) {
   float L[6][6], U[6][6], inv[6];
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    float d = fmaf(damping, H[6 * j + j], H[6 * j + j]);
+    float d = identity_damping ? H[6 * j + j] + damping : fmaf(damping, H[6 * j + j], H[6 * j + j]);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       if (k < j) {
@@ -246,9 +246,9 @@ __device__ __forceinline__ bool ldlt_solve6(const float* H, const float* b, cons
 }
 
 // one damped Gauss-Newton step: X <- X * exp(dx); returns false (X untouched) when the system is not positive definite
-__device__ __forceinline__ bool gn_step(const float* H, const float* b, float damping, float* X) {
+__device__ __forceinline__ bool gn_step(const float* H, const float* b, float damping, float* X, const bool identity_damping = false) {
   float dx[6];
-  const bool ok = ldlt_solve6(H, b, damping, dx);
+  const bool ok = ldlt_solve6(H, b, damping, dx, identity_damping);
   float D[16], Xn[16];
   tnq2t(dx, D);
   se3_mul(X, D, Xn);

@@ -248,6 +248,10 @@ def aligner_params(cfg, mean_disparity=-1.0, stop_at_fixed_point=1, **overrides)
     p.enable_inlier_only_runs = int(al.get("enable_inlier_only_runs", 0))
     p.keep_only_inlier_correspondences = int(al.get("keep_only_inlier_correspondences", 0))
     p.inlier_only_iterations = int(al.get("inlier_only_iterations", 0))
+    # readings of the external srrg2_solver arithmetic (0 = shipped; include/proslam_hip.h)
+    p.kernel_weight_form = int(al.get("kernel_weight_form", 0))
+    p.damping_form = int(al.get("damping_form", 0))
+    p.translation_weight_form = int(al.get("translation_weight_form", 0))
     if al.get("sensor_in_robot") is not None:
         set_sensor_in_robot(p, al["sensor_in_robot"])
     if al.get("motion_prior_info") is not None:
@@ -278,10 +282,10 @@ def info_scale_from_nopt(n_opt):
     return out[: len(n_opt)].copy()
 
 
-def gn_step(ctx, H, b, damping, X):
+def gn_step(ctx, H, b, damping, X, damping_form=0):
     H, b = _np(H, np.float32, (36,)), _np(b, np.float32, (6,))
     X = _np(X, np.float32, (16,)).copy()
-    rc = _lib.load().prs_gn_step(ctx._h, _p(H), _p(b), float(damping), _p(X))
+    rc = _lib.load().prs_gn_step_ex(ctx._h, _p(H), _p(b), float(damping), int(damping_form), _p(X))
     _check(ctx, rc, "prs_gn_step")
     return X.reshape(4, 4), rc
 
@@ -504,11 +508,16 @@ def align_batch_finish(ctx):
     """prs_align_batch_finish: wait for the enqueued batch, run more rounds for frames that are still pending"""
     rc = _lib.load().prs_align_batch_finish(ctx._h)
     _check(ctx, rc, "prs_align_batch_finish")
+    return rc
 
 
-def align_batch_rearm(ctx):
-    """prs_align_batch_rearm: after replaying a HIP graph captured around align_batch_enqueue, so that finish checks the replay"""
-    rc = _lib.load().prs_align_batch_rearm(ctx._h)
+def align_batch_rearm(ctx, replay_stream=None):
+    """prs_align_batch_rearm{,_on}: after replaying a HIP graph captured around align_batch_enqueue, so that finish checks the replay
+    (replay_stream: the hipStream_t handle the graph was launched on when that is not the capture stream)"""
+    if replay_stream is None:
+        rc = _lib.load().prs_align_batch_rearm(ctx._h)
+    else:
+        rc = _lib.load().prs_align_batch_rearm_on(ctx._h, C.c_void_p(int(replay_stream)))
     _check(ctx, rc, "prs_align_batch_rearm")
     return rc
 
