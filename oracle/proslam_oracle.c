@@ -1408,7 +1408,7 @@ void orc_linearize_ex(const orc_aligner_params* P,
       switch (g_variant.idw_form) {
         case 0: /* shipped */
           wt = 0.01f + dn;
-          wt = wt < 1.0f ? (wt >= -FLT_MAX ? wt : 1.0f) : 1.0f; /* NaN (0 / 0), +inf and -inf -> 1: the weight is always finite */
+          wt = wt < 1.0f ? (wt >= -1.0e19f ? wt : 1.0f) : 1.0f; /* NaN (0 / 0), +-inf, or a square that is not finite -> 1: wt and wt^2 are always finite */
           break;
         case 1: wt = !(dn >= 0.01f) ? 0.01f : (dn > 1.0f ? 1.0f : dn); break; /* (NaN -> 0.01) */
         case 2: wt = sqrtf(dn < 0.01f ? 0.01f : (dn > 1.0f ? 1.0f : dn)); break;

@@ -230,17 +230,18 @@ __device__ __forceinline__ bool pose_is_finite(const PoseRegs& X) {
 // DIM: the factor type as a compile-time constant (0 = read it from the parameters)
 // inverse-depth weight of a stereo measurement (aligner_slice_processor_projective.cpp:107-112): a function of the measurement and
 // the frame's mean disparity only, so callers that iterate over fixed correspondences evaluate it once (PRE_WT: z.w carries it)
-// "(0.01 + d, 1) * I": wt = min(0.01 + d / mean disparity, 1); NaN (0 / 0) and +-inf -> 1 (round 4: tools/sweep_a13.py).
-// The result is always finite (a weight of -inf -- a negative disparity over a zero mean -- times the zero K of an invalid
-// correspondence would be a NaN in the sums of the whole frame).  clamp_form: prs_aligner_params.translation_weight_form,
-// clamp(d / mean disparity, 0.01, 1), NaN -> 0.01.
+// "(0.01 + d, 1) * I": wt = min(0.01 + d / mean disparity, 1) (round 4: tools/sweep_a13.py); a weight that is
+// NaN (0 / 0), +-inf or so negative that its square is not finite (a negative disparity over a zero / denormal mean) counts as 1:
+// wt and wt^2 are always finite, so the zero K of an invalid correspondence cannot turn them into a NaN in the sums of the whole
+// frame.  clamp_form: prs_aligner_params.translation_weight_form, clamp(d / mean disparity, 0.01, 1), NaN -> 0.01.
+constexpr float kWeightFloor = -1.0e19f;  // (-1e19)^2 = 1e38 < FLT_MAX
 __device__ __forceinline__ float inverse_depth_weight(const float4 z, const float mean_dsp, const int clamp_form) {
   const float dn = (z.x - z.z) / mean_dsp;
   if (clamp_form) {
     return !(dn >= 0.01f) ? 0.01f : (dn > 1.0f ? 1.0f : dn);
   }
   const float wt = 0.01f + dn;
-  return wt < 1.0f ? (wt >= -kFltMax ? wt : 1.0f) : 1.0f;
+  return wt < 1.0f ? (wt >= kWeightFloor ? wt : 1.0f) : 1.0f;
 }
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kPairs = 16;  // the 29 sums + 3 class counts of one linearisation travel as 16 float pairs (32 "slots")
