@@ -5,67 +5,42 @@
 #include <math.h>
 #include <string.h>
 
-#include <vector>
-
 #include "prs_host.h"
 
+// The handle keeps ONE block of device memory and a pinned host mirror with the same layout:
+//   [ correspondences (cap_f x 12 B) | small: state, X, n_corr, result | header: counts, changed, prior, prior mean |
+//     fixed: float4[cap_f], rows[cap_f] | moving: float4[cap_m], rows[cap_m] ]
+// setFixed / setMoving pack straight into the mirror (no allocation, no copy command); a call uploads the dirty span of the
+// mirror with ONE asynchronous copy from pinned memory, launches, and downloads [correspondences | small] with ONE copy.
 struct prs_pcf {
   prs_context* ctx = nullptr;
   prs_pcf_params params;
-  prs_pcf_state state;  // host mirror of the device-resident state
-  bool state_dirty   = true;
+  prs_pcf_state state;  // host copy of the device-resident state
   bool fixed_set     = false;
   bool moving_set    = false;
   bool inputs_changed = false;
+  bool fixed_dirty = false, moving_dirty = false;  // packed into the mirror since the last upload
   int n_fixed = 0, n_moving = 0, fixed_dim = 2;
   int cap_f = 0, cap_m = 0;
-  float* d_fixed     = nullptr;
-  uint8_t* d_fdesc   = nullptr;
-  float* d_moving    = nullptr;
-  uint8_t* d_mdesc   = nullptr;
-  prs_corr* d_corr   = nullptr;
-  unsigned char* d_small = nullptr;  // counts, state, X, result, changed, prior
+  unsigned char* d_block = nullptr;
+  unsigned char* h_block = nullptr;  // pinned
+  size_t block_bytes = 0;
+  size_t off_small = 0, off_head = 0, off_fixed = 0, off_fdesc = 0, off_moving = 0, off_mdesc = 0;
   float local_map_in_sensor[16];
-  std::vector<prs_corr> corr;  // the persisting correspondence vector (host mirror)
-  int n_corr = 0;
+  int n_corr = 0;  // size of the persisting correspondence vector (its host copy: the front of h_block)
   bool has_prior_mean = false;  // mean of the motion prior (prs_pcf_set_motion_prior_mean)
   float prior_mean[16];
 };
 
 namespace {
 
-struct SmallLayout {
-  int32_t* n_fixed;
-  int32_t* n_moving;
-  int32_t* n_corr;
-  uint8_t* changed;
-  prs_pcf_state* state;
-  float* X;
-  prs_align_result* result;
-  float* prior;
-  float* prior_mean;
-  float* H;
-  float* b;
-  int* ok;
-};
+// the small in / out words (offsets from off_small) and the input-only header (offsets from off_head)
+constexpr size_t kSmState = 0, kSmX = 192, kSmNcorr = 256, kSmResult = 320, kSmallBytes = 640;
+constexpr size_t kHdNfixed = 0, kHdNmoving = 4, kHdChanged = 8, kHdPrior = 64, kHdPriorMean = 256, kHeadBytes = 384;
+static_assert(sizeof(prs_pcf_state) <= kSmX - kSmState && sizeof(prs_align_result) <= kSmallBytes - kSmResult, "small block layout");
 
-constexpr size_t kSmallBytes = 4096;
-
-SmallLayout small_layout(unsigned char* d) {
-  SmallLayout s;
-  s.n_fixed  = reinterpret_cast<int32_t*>(d + 0);
-  s.n_moving = reinterpret_cast<int32_t*>(d + 4);
-  s.n_corr   = reinterpret_cast<int32_t*>(d + 8);
-  s.changed  = reinterpret_cast<uint8_t*>(d + 12);
-  s.state    = reinterpret_cast<prs_pcf_state*>(d + 64);
-  s.X        = reinterpret_cast<float*>(d + 512);
-  s.result   = reinterpret_cast<prs_align_result*>(d + 1024);
-  s.prior    = reinterpret_cast<float*>(d + 2048);
-  s.prior_mean = reinterpret_cast<float*>(d + 2304);
-  s.H        = reinterpret_cast<float*>(d + 2560);
-  s.b        = reinterpret_cast<float*>(d + 2816);
-  s.ok       = reinterpret_cast<int*>(d + 2880);
-  return s;
+size_t align256(size_t v) {
+  return (v + 255) / 256 * 256;
 }
 
 int fail(prs_pcf* h, int status, const char* what) {
@@ -80,37 +55,54 @@ int fail(prs_pcf* h, int status, const char* what) {
     }                                                          \
   } while (0)
 
+prs_corr* host_corr(prs_pcf* h) {
+  return reinterpret_cast<prs_corr*>(h->h_block);
+}
+
+// (re)allocates the block for nf fixed and nm moving points; the mirror's contents survive
 int ensure_capacity(prs_pcf* h, int nf, int nm) {
-  if (!h->d_small) {
-    PCF_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_small), kSmallBytes));
-    PCF_TRY(hipMemset(h->d_small, 0, kSmallBytes));
+  if (h->d_block && nf <= h->cap_f && nm <= h->cap_m) {
+    return PRS_OK;
   }
-  if (nf > h->cap_f || !h->d_fixed) {
-    const int cap = nf + nf / 4 + 16;
-    if (h->d_fixed) {
-      (void) hipFree(h->d_fixed);
-      (void) hipFree(h->d_fdesc);
-      (void) hipFree(h->d_corr);
-    }
-    PCF_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_fixed), sizeof(float) * 4 * (size_t) cap));
-    PCF_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_fdesc), (size_t) PRS_DESC_BYTES * (size_t) cap));
-    PCF_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_corr), sizeof(prs_corr) * (size_t) cap));
-    h->cap_f = cap;
+  const int cap_f = nf > h->cap_f || !h->d_block ? nf + nf / 4 + 16 : h->cap_f;
+  const int cap_m = nm > h->cap_m || !h->d_block ? nm + nm / 4 + 16 : h->cap_m;
+  prs_pcf n        = *h;
+  n.cap_f          = cap_f;
+  n.cap_m          = cap_m;
+  n.off_small      = align256(sizeof(prs_corr) * (size_t) cap_f);
+  n.off_head       = n.off_small + kSmallBytes;
+  n.off_fixed      = align256(n.off_head + kHeadBytes);
+  n.off_fdesc      = n.off_fixed + sizeof(float) * 4 * (size_t) cap_f;
+  n.off_moving     = align256(n.off_fdesc + (size_t) PRS_DESC_BYTES * (size_t) cap_f);
+  n.off_mdesc      = n.off_moving + sizeof(float) * 4 * (size_t) cap_m;
+  n.block_bytes    = align256(n.off_mdesc + (size_t) PRS_DESC_BYTES * (size_t) cap_m);
+  n.d_block        = nullptr;
+  n.h_block        = nullptr;
+  (void) hipStreamSynchronize(h->ctx->stream);
+  PCF_TRY(hipMalloc(reinterpret_cast<void**>(&n.d_block), n.block_bytes));
+  if (hipHostMalloc(reinterpret_cast<void**>(&n.h_block), n.block_bytes, hipHostMallocDefault) != hipSuccess) {
+    (void) hipFree(n.d_block);
+    return fail(h, PRS_ERR_HIP, "prs_pcf: pinned staging allocation failed");
   }
-  if (nm > h->cap_m || !h->d_moving) {
-    const int cap = nm + nm / 4 + 16;
-    if (h->d_moving) {
-      (void) hipFree(h->d_moving);
-      (void) hipFree(h->d_mdesc);
-    }
-    PCF_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_moving), sizeof(float) * 4 * (size_t) cap));
-    PCF_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_mdesc), (size_t) PRS_DESC_BYTES * (size_t) cap));
-    h->cap_m = cap;
+  memset(n.h_block, 0, n.block_bytes);
+  if (h->h_block) {
+    memcpy(n.h_block, h->h_block, sizeof(prs_corr) * (size_t) h->n_corr);
+    memcpy(n.h_block + n.off_fixed, h->h_block + h->off_fixed, sizeof(float) * 4 * (size_t) h->n_fixed);
+    memcpy(n.h_block + n.off_fdesc, h->h_block + h->off_fdesc, (size_t) PRS_DESC_BYTES * (size_t) h->n_fixed);
+    memcpy(n.h_block + n.off_moving, h->h_block + h->off_moving, sizeof(float) * 4 * (size_t) h->n_moving);
+    memcpy(n.h_block + n.off_mdesc, h->h_block + h->off_mdesc, (size_t) PRS_DESC_BYTES * (size_t) h->n_moving);
+    (void) hipHostFree(h->h_block);
+    (void) hipFree(h->d_block);
   }
+  n.fixed_dirty  = h->fixed_set;
+  n.moving_dirty = h->moving_set;
+  *h             = n;
+  // everything the device block holds is stale: upload the whole mirror (incl. the persisting correspondence vector) next time
+  PCF_TRY(hipMemcpyAsync(h->d_block, h->h_block, h->off_small, hipMemcpyHostToDevice, h->ctx->stream));
   return PRS_OK;
 }
 
-// one launch of the batch-1 kernel in `mode`; uploads dirty state, downloads state/result/correspondences
+// one call of the batch-1 pipeline in `mode`: ONE upload of the dirty span of the mirror, the launches, ONE download
 int run(prs_pcf* h, const prs_aligner_params* aligner, int mode, const float* X_in, const float* prior42,
         float* X_out, prs_align_result* result_out) {
   // _preCompute (CF/..bruteforce_impl.cpp:203-216): unset buffers are hard errors
@@ -118,20 +110,31 @@ int run(prs_pcf* h, const prs_aligner_params* aligner, int mode, const float* X_
     return fail(h, PRS_ERR_NULL, "prs_pcf: fixed or moving not set");
   }
   (void) hipSetDevice(h->ctx->device);
-  hipStream_t s  = h->ctx->stream;
-  SmallLayout sl = small_layout(h->d_small);
-  int32_t counts[3] = {h->n_fixed, h->n_moving, h->n_corr};
-  PCF_TRY(hipMemcpyAsync(sl.n_fixed, counts, sizeof(counts), hipMemcpyHostToDevice, s));
-  const uint8_t changed = h->inputs_changed ? 1 : 0;
-  PCF_TRY(hipMemcpyAsync(sl.changed, &changed, 1, hipMemcpyHostToDevice, s));
-  if (h->state_dirty) {
-    PCF_TRY(hipMemcpyAsync(sl.state, &h->state, sizeof(prs_pcf_state), hipMemcpyHostToDevice, s));
-    h->state_dirty = false;
-  }
-  PCF_TRY(hipMemcpyAsync(sl.X, X_in, sizeof(float) * 16, hipMemcpyHostToDevice, s));
+  hipStream_t s     = h->ctx->stream;
+  unsigned char* hb = h->h_block;
+  unsigned char* db = h->d_block;
+  // ---- header + small words into the mirror
+  memcpy(hb + h->off_small + kSmState, &h->state, sizeof(prs_pcf_state));
+  memcpy(hb + h->off_small + kSmX, X_in, sizeof(float) * 16);
+  memcpy(hb + h->off_small + kSmNcorr, &h->n_corr, sizeof(int32_t));
+  int32_t counts[2] = {h->n_fixed, h->n_moving};
+  memcpy(hb + h->off_head + kHdNfixed, counts, sizeof(counts));
+  hb[h->off_head + kHdChanged] = h->inputs_changed ? 1 : 0;
   if (prior42) {
-    PCF_TRY(hipMemcpyAsync(sl.prior, prior42, sizeof(float) * 42, hipMemcpyHostToDevice, s));
+    memcpy(hb + h->off_head + kHdPrior, prior42, sizeof(float) * 42);
   }
+  if (h->has_prior_mean) {
+    memcpy(hb + h->off_head + kHdPriorMean, h->prior_mean, sizeof(float) * 16);
+  }
+  size_t hi = h->off_head + kHeadBytes;
+  if (h->fixed_dirty) {
+    hi = h->off_fdesc + (size_t) PRS_DESC_BYTES * (size_t) h->n_fixed;
+  }
+  if (h->moving_dirty) {
+    hi = h->off_mdesc + (size_t) PRS_DESC_BYTES * (size_t) h->n_moving;  // (a clean fixed region in between is uploaded again: same bytes)
+  }
+  PCF_TRY(hipMemcpyAsync(db + h->off_small, hb + h->off_small, hi - h->off_small, hipMemcpyHostToDevice, s));
+  h->fixed_dirty = h->moving_dirty = false;
   prs_aligner_params ap;
   if (aligner) {
     ap = *aligner;
@@ -144,23 +147,20 @@ int run(prs_pcf* h, const prs_aligner_params* aligner, int mode, const float* X_
   b.batch          = 1;
   b.fixed_stride   = h->cap_f > 0 ? h->cap_f : 1;
   b.moving_stride  = h->cap_m > 0 ? h->cap_m : 1;
-  b.fixed          = h->d_fixed;
-  b.fixed_desc     = h->d_fdesc;
-  b.n_fixed        = sl.n_fixed;
-  b.moving         = h->d_moving;
-  b.moving_desc    = h->d_mdesc;
-  b.n_moving       = sl.n_moving;
-  b.inputs_changed = sl.changed;
-  b.state          = sl.state;
-  b.X              = sl.X;
-  b.corr           = h->d_corr;
-  b.n_corr         = sl.n_corr;
-  b.result         = sl.result;
-  b.prior          = prior42 ? sl.prior : nullptr;
-  if (h->has_prior_mean) {
-    PCF_TRY(hipMemcpyAsync(sl.prior_mean, h->prior_mean, sizeof(float) * 16, hipMemcpyHostToDevice, s));
-    b.prior_mean = sl.prior_mean;
-  }
+  b.fixed          = reinterpret_cast<const float*>(db + h->off_fixed);
+  b.fixed_desc     = db + h->off_fdesc;
+  b.n_fixed        = reinterpret_cast<const int32_t*>(db + h->off_head + kHdNfixed);
+  b.moving         = reinterpret_cast<const float*>(db + h->off_moving);
+  b.moving_desc    = db + h->off_mdesc;
+  b.n_moving       = reinterpret_cast<const int32_t*>(db + h->off_head + kHdNmoving);
+  b.inputs_changed = db + h->off_head + kHdChanged;
+  b.state          = reinterpret_cast<prs_pcf_state*>(db + h->off_small + kSmState);
+  b.X              = reinterpret_cast<float*>(db + h->off_small + kSmX);
+  b.corr           = reinterpret_cast<prs_corr*>(db);
+  b.n_corr         = reinterpret_cast<int32_t*>(db + h->off_small + kSmNcorr);
+  b.result         = reinterpret_cast<prs_align_result*>(db + h->off_small + kSmResult);
+  b.prior          = prior42 ? reinterpret_cast<const float*>(db + h->off_head + kHdPrior) : nullptr;
+  b.prior_mean     = h->has_prior_mean ? reinterpret_cast<const float*>(db + h->off_head + kHdPriorMean) : nullptr;
   int rc           = prs::align_batch_launch(h->ctx, &h->params, &ap, &b, mode, 0);
   if (rc == PRS_OK) {
     rc = prs::align_batch_finish(h->ctx);
@@ -168,30 +168,25 @@ int run(prs_pcf* h, const prs_aligner_params* aligner, int mode, const float* X_
   if (rc != PRS_OK) {
     return rc;
   }
-  prs_align_result res;
-  float X[16];
-  int32_t n_corr = 0;
-  PCF_TRY(hipMemcpyAsync(&res, sl.result, sizeof(res), hipMemcpyDeviceToHost, s));
-  PCF_TRY(hipMemcpyAsync(&h->state, sl.state, sizeof(prs_pcf_state), hipMemcpyDeviceToHost, s));
-  PCF_TRY(hipMemcpyAsync(X, sl.X, sizeof(X), hipMemcpyDeviceToHost, s));
-  PCF_TRY(hipMemcpyAsync(&n_corr, sl.n_corr, sizeof(n_corr), hipMemcpyDeviceToHost, s));
+  // ---- ONE download: [correspondences | state, X, n_corr, result]; a linearisation leaves the correspondences alone
+  const size_t lo = mode == PRS_MODE_LINEARIZE ? h->off_small : 0;
+  PCF_TRY(hipMemcpyAsync(hb + lo, db + lo, h->off_small + kSmallBytes - lo, hipMemcpyDeviceToHost, s));
   PCF_TRY(hipStreamSynchronize(s));
+  prs_align_result res;
+  int32_t n_corr = 0;
+  memcpy(&res, hb + h->off_small + kSmResult, sizeof(res));
+  memcpy(&h->state, hb + h->off_small + kSmState, sizeof(prs_pcf_state));
+  memcpy(&n_corr, hb + h->off_small + kSmNcorr, sizeof(n_corr));
   if (res.warnings < 0) {
     return fail(h, res.warnings, "prs_pcf: fixed coordinates outside the projector canvas / int16 lattice, or bad correspondence index");
   }
   if (mode != PRS_MODE_LINEARIZE) {
-    h->n_corr = n_corr;
-    if ((int) h->corr.size() < h->cap_f) {
-      h->corr.resize((size_t) h->cap_f);
-    }
-    if (n_corr > 0) {
-      PCF_TRY(hipMemcpy(h->corr.data(), h->d_corr, sizeof(prs_corr) * (size_t) n_corr, hipMemcpyDeviceToHost));
-    }
+    h->n_corr         = n_corr;
     h->inputs_changed = false;
     memcpy(h->local_map_in_sensor, h->state.local_map_in_sensor, sizeof(float) * 16);
   }
   if (X_out) {
-    memcpy(X_out, X, sizeof(X));
+    memcpy(X_out, hb + h->off_small + kSmX, sizeof(float) * 16);
   }
   if (result_out) {
     *result_out = res;
@@ -228,11 +223,11 @@ int prs_pcf_destroy(prs_pcf* h) {
   }
   (void) hipSetDevice(h->ctx->device);
   (void) hipStreamSynchronize(h->ctx->stream);
-  void* bufs[] = {h->d_fixed, h->d_fdesc, h->d_moving, h->d_mdesc, h->d_corr, h->d_small};
-  for (void* p : bufs) {
-    if (p) {
-      (void) hipFree(p);
-    }
+  if (h->d_block) {
+    (void) hipFree(h->d_block);
+  }
+  if (h->h_block) {
+    (void) hipHostFree(h->h_block);
   }
   delete h;
   return PRS_OK;
@@ -244,7 +239,6 @@ int prs_pcf_set_params(prs_pcf* h, const prs_pcf_params* params) {
   }
   h->params               = *params;
   h->state.config_changed = 1;  // PARAM(.., &_config_changed), CF/..projective_base.h:30-44
-  h->state_dirty          = true;
   return PRS_OK;
 }
 
@@ -257,16 +251,16 @@ int prs_pcf_set_fixed(prs_pcf* h, const float* coords, int32_t fixed_dim, const 
   if (rc != PRS_OK) {
     return rc;
   }
-  if (n > 0) {
-    std::vector<float> packed((size_t) n * 4, 0.0f);
-    for (int i = 0; i < n; ++i) {
-      for (int d = 0; d < fixed_dim; ++d) {
-        packed[(size_t) i * 4 + d] = coords[(size_t) i * fixed_dim + d];
-      }
+  float* packed = reinterpret_cast<float*>(h->h_block + h->off_fixed);
+  for (int i = 0; i < n; ++i) {
+    for (int d = 0; d < 4; ++d) {
+      packed[(size_t) i * 4 + d] = d < fixed_dim ? coords[(size_t) i * fixed_dim + d] : 0.0f;
     }
-    PCF_TRY(hipMemcpy(h->d_fixed, packed.data(), sizeof(float) * 4 * (size_t) n, hipMemcpyHostToDevice));
-    PCF_TRY(hipMemcpy(h->d_fdesc, desc, (size_t) PRS_DESC_BYTES * (size_t) n, hipMemcpyHostToDevice));
   }
+  if (n > 0) {
+    memcpy(h->h_block + h->off_fdesc, desc, (size_t) PRS_DESC_BYTES * (size_t) n);
+  }
+  h->fixed_dirty    = true;
   h->n_fixed        = n;
   h->fixed_dim      = fixed_dim;
   h->fixed_set      = true;
@@ -284,17 +278,17 @@ int prs_pcf_set_moving(prs_pcf* h, const float* xyz, const float* info_scale, co
   if (rc != PRS_OK) {
     return rc;
   }
-  if (n > 0) {
-    std::vector<float> packed((size_t) n * 4);
-    for (int i = 0; i < n; ++i) {
-      packed[(size_t) i * 4 + 0] = xyz[(size_t) i * 3 + 0];
-      packed[(size_t) i * 4 + 1] = xyz[(size_t) i * 3 + 1];
-      packed[(size_t) i * 4 + 2] = xyz[(size_t) i * 3 + 2];
-      packed[(size_t) i * 4 + 3] = info_scale ? info_scale[i] : 1.0f;
-    }
-    PCF_TRY(hipMemcpy(h->d_moving, packed.data(), sizeof(float) * 4 * (size_t) n, hipMemcpyHostToDevice));
-    PCF_TRY(hipMemcpy(h->d_mdesc, desc, (size_t) PRS_DESC_BYTES * (size_t) n, hipMemcpyHostToDevice));
+  float* packed = reinterpret_cast<float*>(h->h_block + h->off_moving);
+  for (int i = 0; i < n; ++i) {
+    packed[(size_t) i * 4 + 0] = xyz[(size_t) i * 3 + 0];
+    packed[(size_t) i * 4 + 1] = xyz[(size_t) i * 3 + 1];
+    packed[(size_t) i * 4 + 2] = xyz[(size_t) i * 3 + 2];
+    packed[(size_t) i * 4 + 3] = info_scale ? info_scale[i] : 1.0f;
   }
+  if (n > 0) {
+    memcpy(h->h_block + h->off_mdesc, desc, (size_t) PRS_DESC_BYTES * (size_t) n);
+  }
+  h->moving_dirty   = true;
   h->n_moving       = n;
   h->moving_set     = true;
   h->inputs_changed = true;
@@ -315,7 +309,6 @@ int prs_pcf_set_search_radius(prs_pcf* h, uint64_t radius_pixels) {
   }
   h->state.search_radius_pixels = radius_pixels;  // CF/..projective_base.h:82-85
   h->state.config_changed       = 0;
-  h->state_dirty                = true;
   return PRS_OK;
 }
 
@@ -325,7 +318,6 @@ int prs_pcf_set_descriptor_distance(prs_pcf* h, float distance) {
   }
   h->state.descriptor_distance = distance;  // CF/..projective_base.h:94-97
   h->state.config_changed      = 0;
-  h->state_dirty               = true;
   return PRS_OK;
 }
 
@@ -361,7 +353,7 @@ int prs_pcf_compute(prs_pcf* h, prs_corr* out, int32_t capacity, int32_t* n_out)
     return fail(h, PRS_ERR_CAPACITY, "prs_pcf_compute: capacity < number of correspondences");
   }
   if (h->n_corr > 0) {
-    memcpy(out, h->corr.data(), sizeof(prs_corr) * (size_t) h->n_corr);
+    memcpy(out, host_corr(h), sizeof(prs_corr) * (size_t) h->n_corr);
   }
   *n_out = h->n_corr;
   return rc;
@@ -380,7 +372,7 @@ int prs_pcf_align(prs_pcf* h, const prs_aligner_params* aligner, const float* X_
     return fail(h, PRS_ERR_CAPACITY, "prs_pcf_align: capacity < number of correspondences");
   }
   if (h->n_corr > 0) {
-    memcpy(corr_out, h->corr.data(), sizeof(prs_corr) * (size_t) h->n_corr);
+    memcpy(corr_out, host_corr(h), sizeof(prs_corr) * (size_t) h->n_corr);
   }
   *n_corr_out = h->n_corr;
   return rc;
@@ -398,16 +390,17 @@ int prs_pcf_linearize(prs_pcf* h, const prs_aligner_params* aligner, const float
     return fail(h, PRS_ERR_CAPACITY, "prs_pcf_linearize: more correspondences than fixed points");
   }
   (void) hipSetDevice(h->ctx->device);
+  // the caller's correspondences take the place of the finder's own vector on the device for this launch only (the host copy of
+  // that vector stays in the mirror and is put back afterwards)
   const int saved = h->n_corr;
   if (n_corr > 0) {
-    PCF_TRY(hipMemcpy(h->d_corr, corr, sizeof(prs_corr) * (size_t) n_corr, hipMemcpyHostToDevice));
+    PCF_TRY(hipMemcpyAsync(h->d_block, corr, sizeof(prs_corr) * (size_t) n_corr, hipMemcpyHostToDevice, h->ctx->stream));
   }
   h->n_corr    = n_corr;
   const int rc = run(h, aligner, PRS_MODE_LINEARIZE, X16, nullptr, nullptr, result);
-  // restore the finder's own vector on the device
-  h->n_corr = saved;
+  h->n_corr    = saved;
   if (saved > 0) {
-    PCF_TRY(hipMemcpy(h->d_corr, h->corr.data(), sizeof(prs_corr) * (size_t) saved, hipMemcpyHostToDevice));
+    PCF_TRY(hipMemcpyAsync(h->d_block, host_corr(h), sizeof(prs_corr) * (size_t) saved, hipMemcpyHostToDevice, h->ctx->stream));
   }
   return rc;
 }
