@@ -120,7 +120,7 @@ unsigned long long* ctx_stamps(prs_context* ctx, size_t bytes) {
   return ctx->d_stamps;
 }
 
-void ctx_report_stamps(prs_context* ctx, int blocks, int n_stamps, const char* legend) {
+void ctx_report_stamps(prs_context* ctx, int blocks, int n_stamps, const char* legend, bool raw) {
   (void) hipStreamSynchronize(ctx->stream);
   std::vector<unsigned long long> h((size_t) blocks * 16);
   (void) hipMemcpy(h.data(), ctx->d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -129,7 +129,7 @@ void ctx_report_stamps(prs_context* ctx, int blocks, int n_stamps, const char* l
   for (int i = 1; i < n_stamps; ++i) {
     double acc = 0;
     for (int b = 0; b < blocks; ++b) {
-      acc += (double) (h[(size_t) b * 16 + i] - h[(size_t) b * 16 + i - 1]);
+      acc += raw ? (double) h[(size_t) b * 16 + i] : (double) (h[(size_t) b * 16 + i] - h[(size_t) b * 16 + i - 1]);
     }
     fprintf(stderr, " %.0f", acc / blocks);
     total += acc / blocks;
@@ -415,8 +415,16 @@ int prs_align_batch_run(prs_context* ctx, const prs_pcf_params* finder, const pr
     return PRS_ERR_NULL;
   }
   (void) hipSetDevice(ctx->device);
-  const int rc = align_batch_launch(ctx, finder, aligner, batch, mode, 0);
-  return rc != PRS_OK ? rc : align_batch_finish(ctx);
+  int rc = align_batch_launch(ctx, finder, aligner, batch, mode, 0);
+  if (rc != PRS_OK) {
+    return rc;
+  }
+  if (align_job_active(ctx)) {
+    return align_batch_finish(ctx);
+  }
+  // (the one-launch paths -- finder / linearise modes, the fused kernel -- have nothing enqueued to finish)
+  const hipError_t e = hipStreamSynchronize(ctx->stream);
+  return e == hipSuccess ? PRS_OK : ctx_fail_hip(ctx, e, "prs_align_batch_run");
 }
 
 int prs_align_batch_enqueue(prs_context* ctx, const prs_pcf_params* finder, const prs_aligner_params* aligner, const prs_align_batch* batch, int32_t rounds) {
@@ -424,7 +432,8 @@ int prs_align_batch_enqueue(prs_context* ctx, const prs_pcf_params* finder, cons
     return PRS_ERR_NULL;
   }
   (void) hipSetDevice(ctx->device);
-  return align_batch_launch(ctx, finder, aligner, batch, PRS_MODE_ALIGN, rounds);
+  // (an explicit round count: the split pipeline, which is what a caller that enqueues -- and may capture -- asked for)
+  return align_batch_launch(ctx, finder, aligner, batch, PRS_MODE_ALIGN, rounds > 0 ? rounds : 5);
 }
 
 int prs_align_batch_finish(prs_context* ctx) {
