@@ -2529,9 +2529,15 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   // (the rectified-stereo factor, the one kitti.conf / euroc.conf use, has its own instantiation: the factor type as a
   // compile-time constant removes ~10 selects per linearised correspondence; so does not remembering the factor classes)
   const bool fast = aligner->factor_type == PRS_FACTOR_STEREO && !aligner->keep_only_inlier_correspondences;
-  const bool five = fast && max_fixed > 4 * 128;  // (gn_kernel: LDS_SLOTS / WAVES)
-  auto gnk        = max_fixed <= 4 * 128 ? (fast ? gn_kernel<4, PRS_FACTOR_STEREO, false> : gn_kernel<4, 0, true>)
-                                         : (fast ? gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5> : gn_kernel<8, 0, true>);
+  // a batch that cannot fill the chip (fewer frames than two per CU) is bound by the serial chain of each frame, not by occupancy:
+  // its instantiation may use the whole register file (WAVES = 1: no spills in the solve, the compiler schedules for latency)
+  int n_cu = 0;
+  (void) hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+  const bool lone = fast && batch->batch <= 2 * (n_cu > 0 ? n_cu : 256) && !ctx->no_lone_gn;
+  const bool five = fast && !lone && max_fixed > 4 * 128;  // (gn_kernel: LDS_SLOTS / WAVES)
+  auto gnk        = lone ? (max_fixed <= 4 * 128 ? gn_kernel<4, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1> : gn_kernel<8, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1>)
+                         : (max_fixed <= 4 * 128 ? (fast ? gn_kernel<4, PRS_FACTOR_STEREO, false> : gn_kernel<4, 0, true>)
+                                                 : (fast ? gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5> : gn_kernel<8, 0, true>));
   const size_t lds_gn = gn_lds_bytes(five ? 3 : kGnLdsSlots);
   // The job lives in the context until align_batch_finish: the rounds are plain launches on the context's stream (no host
   // synchronisation here, the sequence can be captured in a HIP graph once the scratch buffers exist).

@@ -201,6 +201,8 @@ int prs_context_create(int device_id, prs_context** out) {
   ctx->stamps_split    = ssplit && ssplit[0] == '1';
   const char* nopre    = getenv("PRS_NO_PREFILTER");
   ctx->no_prefilter    = nopre && nopre[0] == '1';
+  const char* nolone   = getenv("PRS_NO_LONE_GN");
+  ctx->no_lone_gn      = nolone && nolone[0] == '1';
   const char* mfused   = getenv("PRS_MERGE_FUSED");
   ctx->merge_fused     = mfused && mfused[0] == '1';
   *out                 = ctx;
@@ -346,24 +348,31 @@ int prs_stereo_match(prs_context* ctx,
   (void) hipSetDevice(ctx->device);
   *n_out           = 0;
   const int stride = n_left > n_right ? (n_left > 0 ? n_left : 1) : (n_right > 0 ? n_right : 1);
-  // device scratch layout
+  // one block on the device and a pinned mirror with the same layout: [ matches | meta | left kp | right kp | left rows | right rows ];
+  // ONE upload of [meta .. right rows] from pinned memory, the launch, ONE download of [matches | meta]
   const size_t sz_kp   = align256(sizeof(prs_kp2) * (size_t) stride);
   const size_t sz_desc = align256((size_t) PRS_DESC_BYTES * (size_t) stride);
   const size_t sz_corr = align256(sizeof(prs_corr) * (size_t) stride);
-  const size_t total   = 2 * sz_kp + 2 * sz_desc + sz_corr + 256;
-  unsigned char* d     = static_cast<unsigned char*>(ctx_device_scratch(ctx, total));
-  if (!d) {
-    return ctx_fail(ctx, PRS_ERR_HIP, "prs_stereo_match: device scratch allocation failed");
+  const size_t off_meta = sz_corr, off_kpl = off_meta + 256, off_kpr = off_kpl + sz_kp, off_dl = off_kpr + sz_kp, off_dr = off_dl + sz_desc;
+  const size_t total    = off_dr + sz_desc;
+  unsigned char* d      = static_cast<unsigned char*>(ctx_device_scratch(ctx, total));
+  unsigned char* h      = static_cast<unsigned char*>(ctx_pinned_scratch(ctx, total));
+  if (!d || !h) {
+    return ctx_fail(ctx, PRS_ERR_HIP, "prs_stereo_match: scratch allocation failed");
   }
-  prs_kp2* d_kpl  = reinterpret_cast<prs_kp2*>(d);
-  prs_kp2* d_kpr  = reinterpret_cast<prs_kp2*>(d + sz_kp);
-  uint8_t* d_dl   = d + 2 * sz_kp;
-  uint8_t* d_dr   = d + 2 * sz_kp + sz_desc;
-  prs_corr* d_out = reinterpret_cast<prs_corr*>(d + 2 * sz_kp + 2 * sz_desc);
-  int32_t* d_meta = reinterpret_cast<int32_t*>(d + 2 * sz_kp + 2 * sz_desc + sz_corr);  // n_left, n_right, n_matches, status
+  int32_t* d_meta = reinterpret_cast<int32_t*>(d + off_meta);  // n_left, n_right, n_matches, status
+  int32_t* h_meta = reinterpret_cast<int32_t*>(h + off_meta);
   hipStream_t s   = ctx->stream;
   hipError_t e    = hipSuccess;
-  int32_t meta[4] = {n_left, n_right, 0, 0};
+  h_meta[0] = n_left, h_meta[1] = n_right, h_meta[2] = 0, h_meta[3] = 0;
+  if (n_left > 0) {
+    memcpy(h + off_kpl, left, sizeof(prs_kp2) * (size_t) n_left);
+    memcpy(h + off_dl, desc_left, (size_t) PRS_DESC_BYTES * (size_t) n_left);
+  }
+  if (n_right > 0) {
+    memcpy(h + off_kpr, right, sizeof(prs_kp2) * (size_t) n_right);
+    memcpy(h + off_dr, desc_right, (size_t) PRS_DESC_BYTES * (size_t) n_right);
+  }
 #define PRS_TRY(x)                                  \
   do {                                              \
     e = (x);                                        \
@@ -371,43 +380,37 @@ int prs_stereo_match(prs_context* ctx,
       return ctx_fail_hip(ctx, e, "prs_stereo_match"); \
     }                                               \
   } while (0)
-  if (n_left > 0) {
-    PRS_TRY(hipMemcpyAsync(d_kpl, left, sizeof(prs_kp2) * (size_t) n_left, hipMemcpyHostToDevice, s));
-    PRS_TRY(hipMemcpyAsync(d_dl, desc_left, (size_t) PRS_DESC_BYTES * (size_t) n_left, hipMemcpyHostToDevice, s));
-  }
-  if (n_right > 0) {
-    PRS_TRY(hipMemcpyAsync(d_kpr, right, sizeof(prs_kp2) * (size_t) n_right, hipMemcpyHostToDevice, s));
-    PRS_TRY(hipMemcpyAsync(d_dr, desc_right, (size_t) PRS_DESC_BYTES * (size_t) n_right, hipMemcpyHostToDevice, s));
-  }
-  PRS_TRY(hipMemcpyAsync(d_meta, meta, sizeof(meta), hipMemcpyHostToDevice, s));
+  PRS_TRY(hipMemcpyAsync(d + off_meta, h + off_meta, off_dr + (size_t) PRS_DESC_BYTES * (size_t) (n_right > 0 ? n_right : 0) - off_meta, hipMemcpyHostToDevice, s));
   prs_stereo_batch b;
   memset(&b, 0, sizeof(b));
   b.batch      = 1;
   b.stride     = stride;
-  b.left_kp    = d_kpl;
-  b.left_desc  = d_dl;
+  b.left_kp    = reinterpret_cast<prs_kp2*>(d + off_kpl);
+  b.left_desc  = d + off_dl;
   b.n_left     = d_meta + 0;
-  b.right_kp   = d_kpr;
-  b.right_desc = d_dr;
+  b.right_kp   = reinterpret_cast<prs_kp2*>(d + off_kpr);
+  b.right_desc = d + off_dr;
   b.n_right    = d_meta + 1;
-  b.matches    = d_out;
+  b.matches    = reinterpret_cast<prs_corr*>(d);
   b.n_matches  = d_meta + 2;
   b.status     = d_meta + 3;
   const int rc = stereo_match_batch_launch(ctx, params, &b);
   if (rc != PRS_OK) {
     return rc;
   }
-  PRS_TRY(hipMemcpyAsync(meta, d_meta, sizeof(meta), hipMemcpyDeviceToHost, s));
+  // (a frame has at most n_left matches: the copy covers them and the meta words behind the match array)
+  const size_t lo = 0;
+  PRS_TRY(hipMemcpyAsync(h + lo, d + lo, off_meta + 16 - lo, hipMemcpyDeviceToHost, s));
   PRS_TRY(hipStreamSynchronize(s));
-  if (meta[3] < 0) {
-    return ctx_fail(ctx, meta[3], "prs_stereo_match: keypoint outside the supported domain (0<=u<32768, 0<=v<image_rows)");
-  }
-  if (meta[2] > 0) {
-    PRS_TRY(hipMemcpy(out, d_out, sizeof(prs_corr) * (size_t) meta[2], hipMemcpyDeviceToHost));
-  }
 #undef PRS_TRY
-  *n_out = meta[2];
-  return meta[3];
+  if (h_meta[3] < 0) {
+    return ctx_fail(ctx, h_meta[3], "prs_stereo_match: keypoint outside the supported domain (0<=u<32768, 0<=v<image_rows)");
+  }
+  if (h_meta[2] > 0) {
+    memcpy(out, h, sizeof(prs_corr) * (size_t) h_meta[2]);
+  }
+  *n_out = h_meta[2];
+  return h_meta[3];
 }
 
 int prs_align_batch_run(prs_context* ctx, const prs_pcf_params* finder, const prs_aligner_params* aligner, const prs_align_batch* batch, int32_t mode) {
@@ -480,14 +483,16 @@ int prs_triangulate(prs_context* ctx, const prs_triangulator_params* params, con
   (void) hipSetDevice(ctx->device);
   const size_t bytes = sizeof(float) * 4 * (size_t) n;
   unsigned char* d   = static_cast<unsigned char*>(ctx_device_scratch(ctx, 2 * align256(bytes)));
-  float* h           = static_cast<float*>(ctx_pinned_scratch(ctx, bytes));
-  if (!d || !h) {
+  float* h_in        = static_cast<float*>(ctx_pinned_scratch(ctx, 2 * align256(bytes)));  // [measurements | points]: pinned both ways
+  if (!d || !h_in) {
     return ctx_fail(ctx, PRS_ERR_HIP, "prs_triangulate: scratch allocation failed");
   }
+  float* h      = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(h_in) + align256(bytes));
   float* d_in   = reinterpret_cast<float*>(d);
   float* d_out  = reinterpret_cast<float*>(d + align256(bytes));
   hipStream_t s = ctx->stream;
-  hipError_t e  = hipMemcpyAsync(d_in, uvuv, bytes, hipMemcpyHostToDevice, s);
+  memcpy(h_in, uvuv, bytes);
+  hipError_t e  = hipMemcpyAsync(d_in, h_in, bytes, hipMemcpyHostToDevice, s);
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_triangulate upload");
   }

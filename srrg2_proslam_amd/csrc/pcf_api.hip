@@ -64,8 +64,9 @@ int ensure_capacity(prs_pcf* h, int nf, int nm) {
   if (h->d_block && nf <= h->cap_f && nm <= h->cap_m) {
     return PRS_OK;
   }
-  const int cap_f = nf > h->cap_f || !h->d_block ? nf + nf / 4 + 16 : h->cap_f;
-  const int cap_m = nm > h->cap_m || !h->d_block ? nm + nm / 4 + 16 : h->cap_m;
+  // (generous headroom: a reallocation costs milliseconds, and the counts of a sequence wander by tens of per cent)
+  const int cap_f = nf > h->cap_f || !h->d_block ? (nf + nf / 2 + 255) / 256 * 256 : h->cap_f;
+  const int cap_m = nm > h->cap_m || !h->d_block ? (nm + nm / 2 + 255) / 256 * 256 : h->cap_m;
   prs_pcf n        = *h;
   n.cap_f          = cap_f;
   n.cap_m          = cap_m;
@@ -161,6 +162,10 @@ int run(prs_pcf* h, const prs_aligner_params* aligner, int mode, const float* X_
   b.result         = reinterpret_cast<prs_align_result*>(db + h->off_small + kSmResult);
   b.prior          = prior42 ? reinterpret_cast<const float*>(db + h->off_head + kHdPrior) : nullptr;
   b.prior_mean     = h->has_prior_mean ? reinterpret_cast<const float*>(db + h->off_head + kHdPriorMean) : nullptr;
+  b.max_fixed      = (h->n_fixed + 63) / 64 * 64 > 0 ? (h->n_fixed + 63) / 64 * 64 : 64;  // the kernels' LDS is sized for this frame, not for the block's capacity
+  if (b.max_fixed > b.fixed_stride) {
+    b.max_fixed = b.fixed_stride;
+  }
   int rc           = prs::align_batch_launch(h->ctx, &h->params, &ap, &b, mode, 0);
   if (rc == PRS_OK) {
     rc = prs::align_batch_finish(h->ctx);
