@@ -427,6 +427,120 @@ def small_config_leg(name, cfg, keypoints, moving, max_fixed, batch, device_inde
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# small batches: what a caller with few sequences gets from the device-resident batch API (between latency_b1 and the headline)
+# ---------------------------------------------------------------------------------------------------------------------
+def small_batch_curve(cfg, frames, keypoints, moving, max_fixed, device_index, batches=(1, 2, 4, 8, 16, 64, 256, 2048), steps=8):
+    """frames per second and ms per step of the headline step (matcher + epilogue, search / GN rounds) at B = 1 .. 2048 frames per
+    step, inputs resident in HBM, device pointers (prs_stereo_match_batch + prs_align_batch_run), fresh finders every step"""
+    import torch
+    curve = []
+    for b in batches:
+        w = FrameWorkload(cfg, device_index, b, keypoints, moving, max_fixed, len(frames), 0, frames=frames)
+        stream = torch.cuda.Stream(device=w.dev)
+        with torch.cuda.stream(stream):
+            w.ctx.use_torch_stream()
+            w.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                w.step()
+                torch.cuda.synchronize()  # a caller with one frame per sequence needs the pose before the next frame
+            dt = (time.perf_counter() - t0) / steps
+            ok, _ = w.check(w.snapshot())
+        curve.append({"frames_per_step": b, "ms_per_step": dt * 1e3, "frames_per_s": b / dt, "aligner_success_fraction": ok})
+        w.close()
+        del w
+        torch.cuda.empty_cache()
+    return {"curve": curve,
+            "note": "device-resident batch API, one synchronisation per step; up to two frames per CU the Gauss-Newton rounds run the instantiation "
+                    "that owns the whole register file (align.hip, `lone`); the serial chain of a frame (100 damped iterations) sets ms_per_step "
+                    "until the batch fills the chip"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# host-fed sequences: keypoints + descriptors of every frame arrive from pinned host memory (SURVEY 8e: "host memory bandwidth /
+# PCIe for input upload" is what the ranks of a node share)
+# ---------------------------------------------------------------------------------------------------------------------
+def streamed_leg(cfg, frames, keypoints, moving, max_fixed, batch, device_index, steps=6):
+    """B frames per step whose stereo inputs (2 x 8 B keypoints + 2 x 32 B descriptor rows per keypoint = 160 kB per frame at 2000
+    keypoints) are copied from pinned host memory on a copy stream into one of two device slots while the previous step computes
+    on the other; the local map stays resident (it is the tracker's own output).  -> streamed rate, the resident rate of the same
+    batch, the copy-only rate and how much of the shorter of the two the overlap hides"""
+    import torch
+    w = FrameWorkload(cfg, device_index, batch, keypoints, moving, max_fixed, len(frames), 0, frames=frames)
+    sf = w.sframes
+    names = ("left_kp", "right_kp", "left_desc", "right_desc")
+    slots = [[getattr(sf, n) for n in names], [torch.empty_like(getattr(sf, n)) for n in names]]
+    host = [getattr(sf, n).cpu().pin_memory() for n in names]  # ONE pinned image of the batch's inputs (both slots are fed from it)
+    bytes_step = float(sum(t.numel() * t.element_size() for t in host))
+    compute = torch.cuda.Stream(device=w.dev)
+    copier = torch.cuda.Stream(device=w.dev)
+    copied = [torch.cuda.Event() for _ in range(2)]
+    consumed = [torch.cuda.Event() for _ in range(2)]
+
+    def enqueue_copy(k):
+        with torch.cuda.stream(copier):
+            if k >= 2:
+                copier.wait_event(consumed[k % 2])  # the step that read this slot has finished with it
+            for dst, src in zip(slots[k % 2], host):
+                dst.copy_(src, non_blocking=True)
+            copied[k % 2].record(copier)
+
+    def use_slot(k):
+        for n, t in zip(names, slots[k % 2]):
+            setattr(sf, n, t)
+
+    with torch.cuda.stream(compute):
+        w.ctx.use_torch_stream()
+        # resident: the same batch with its inputs already in HBM
+        w.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            w.step()
+        torch.cuda.synchronize()
+        t_resident = (time.perf_counter() - t0) / steps
+        # copy only
+        enqueue_copy(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            enqueue_copy(k % 2)
+        torch.cuda.synchronize()
+        t_copy = (time.perf_counter() - t0) / steps
+        # streamed: the copy of step k + 1 runs under the compute of step k
+        copied = [torch.cuda.Event() for _ in range(2)]
+        consumed = [torch.cuda.Event() for _ in range(2)]
+        enqueue_copy(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            enqueue_copy(k + 1)
+            compute.wait_event(copied[k % 2])
+            use_slot(k)
+            w.step()
+            consumed[k % 2].record(compute)
+        torch.cuda.synchronize()
+        t_streamed = (time.perf_counter() - t0) / steps
+        snap = w.snapshot()
+        ok, _ = w.check(snap)
+    hidden = (t_copy + t_resident - t_streamed) / min(t_copy, t_resident)
+    out = {"workload": "the headline frames, %d per step, stereo inputs (%.0f kB per frame) streamed from pinned host memory into two device slots; "
+                       "local map resident" % (batch, bytes_step / batch / 1e3),
+           "value": batch / t_streamed, "unit": "frames/s", "ms_per_step": t_streamed * 1e3, "frames_per_step": batch, "steps": steps,
+           "resident_frames_per_s": batch / t_resident, "ms_per_step_resident": t_resident * 1e3,
+           "h2d_gbps_streamed": bytes_step / t_streamed / 1e9, "h2d_gbps_copy_only": bytes_step / t_copy / 1e9, "ms_per_step_copy_only": t_copy * 1e3,
+           "overlap_fraction": max(0.0, min(1.0, hidden)), "bound": "h2d" if t_copy > t_resident else "compute",
+           "aligner_success_fraction": ok,
+           "note": "PCIe-inclusive rate of a host-fed set of sequences on ONE GPU; at N > 1 the ranks share the host's memory and PCIe root "
+                   "complexes (SURVEY 8e): compare value x N with the N-GPU line.  `value` of the headline keeps inputs resident in HBM."}
+    w.close()
+    del w
+    torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # real descriptors: the reference's own KITTI stereo pairs (tests/golden/ref_kitti.npz), extracted on the device
 # ---------------------------------------------------------------------------------------------------------------------
 def kitti_real_frames(device_index, cfg, target):
@@ -695,17 +809,43 @@ def closed_loop(args):
     sharding.shutdown()
 
 
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT a HIP call (the parent of the ranks must not initialise the runtime): the KFD topology
+    (one node per agent, `simd_count` > 0 = a GPU), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES"""
+    import glob
+    n = 0
+    for props in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            fields = dict(line.split()[:2] for line in open(props) if len(line.split()) >= 2)
+            n += int(fields.get("simd_count", "0")) > 0
+        except OSError:
+            continue
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            listed = len([x for x in v.split(",") if x.strip() != ""])
+            n = min(n, listed) if n else listed
+    if n == 0:  # no readable topology (some containers): ask a CHILD process, so that still no GPU call happens in this one
+        import subprocess
+        try:
+            n = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True,
+                                   timeout=300).stdout.strip().splitlines()[-1])
+        except (ValueError, IndexError, OSError, subprocess.SubprocessError):
+            n = 0
+    return n
+
+
 def spawn_ranks(args):
-    """`python bench.py --gpus N` without a launcher: this process (which makes no GPU call: device_count() does not initialise the
-    runtime) starts N fresh children of itself, one per device, with the environment torch.distributed.run would give them, waits,
-    and exits with the worst child's code.  Rank 0 prints the line.  Fewer visible devices than N is an error, never a 1-GPU run."""
+    """`python bench.py --gpus N` without a launcher: this process (which makes NO GPU call: the devices are counted from the KFD
+    topology in sysfs, visible_gpu_count) starts N fresh children of itself, one per device, with the environment
+    torch.distributed.run would give them, waits, and exits with the worst child's code.  Rank 0 prints the line.  Fewer visible
+    devices than N is an error, never a 1-GPU run."""
     import socket
     import subprocess
     n = args.gpus
     shared = os.environ.get("PRS_BENCH_SHARE_GPU", "0") == "1"
     if not (shared or args.dry_run):
-        import torch
-        have = torch.cuda.device_count()
+        have = visible_gpu_count()
         if have < n:
             raise SystemExit("bench.py --gpus %d: only %d device(s) visible (PRS_BENCH_SHARE_GPU=1 puts all ranks on device 0)" % (n, have))
     sock = socket.socket()
@@ -967,6 +1107,16 @@ def main():
                 others[name] = small_config_leg(name, configs.get(cname), kp, mv, mf, small, local_rank, syn.seed_for(cidx, 0) + 31)
             except SystemExit as exc:  # a loud per-frame error of a side leg must not take the headline line with it
                 others[name] = {"error": str(exc)}
+        try:
+            out["small_batch"] = small_batch_curve(cfg, uniq_frames if uniq_frames is not None else make_unique_frames(cfg, 13, N, NM, syn.seed_for(1, 0)),
+                                                   N, NM, args.max_fixed, local_rank)
+        except (SystemExit, RuntimeError) as exc:
+            out["small_batch"] = {"error": str(exc)}
+        try:
+            out["streamed"] = streamed_leg(cfg, uniq_frames if uniq_frames is not None else make_unique_frames(cfg, 13, N, NM, syn.seed_for(1, 0)),
+                                           N, NM, args.max_fixed, small, local_rank)
+        except (SystemExit, RuntimeError) as exc:
+            out["streamed"] = {"error": str(exc)}
         try:
             others["kitti_real"] = kitti_real_leg(local_rank, cfg, small)
             if "from_images" in others["kitti_real"]:

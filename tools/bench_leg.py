@@ -1,5 +1,5 @@
 """One side configuration of bench.py (EuRoC / TUM / KITTI-1000 shaped) alone, with its per-round kernel times.
-    python tools/bench_leg.py tum|euroc|kitti_n1000|kitti_real [batch]"""
+    python tools/bench_leg.py tum|euroc|kitti_n1000|kitti_real|streamed|small_batch [batch]"""
 import json
 import os
 import sys
@@ -16,6 +16,13 @@ if __name__ == "__main__":
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 6144
     if name == "kitti_real":
         print(json.dumps(bench.kitti_real_leg(0, configs.get("kitti"), batch)))
+    elif name in ("streamed", "small_batch"):
+        cfg = configs.get("kitti")
+        frames = bench.make_unique_frames(cfg, 13, 2000, 2000, syn.seed_for(1, 0))
+        if name == "streamed":
+            print(json.dumps(bench.streamed_leg(cfg, frames, 2000, 2000, 896, batch, 0)))
+        else:
+            print(json.dumps(bench.small_batch_curve(cfg, frames, 2000, 2000, 896, 0)))
     else:
         cname, kp, mv, mf, cidx = LEGS[name]
         print(json.dumps(bench.small_config_leg(name, configs.get(cname), kp, mv, mf, batch, 0, syn.seed_for(cidx, 0) + 31)))
