@@ -295,3 +295,13 @@ def test_camera_frame_sums_are_the_entry_by_entry_normal_equations(oracle, mode)
         assert np.abs(Hn - Ho).max() <= 2e-5 * np.abs(Ho).max()
         assert np.abs(bn - bo).max() <= 2e-5 * max(np.abs(bo).max(), 1e-3 * np.abs(Ho).max())
         assert np.array_equal(Hn, Hn.T)  # the lower triangle is the system, mirrored
+
+
+@pytest.mark.xfail(strict=False, reason="DEVIATION KEPT VISIBLE (advisor r04): tests/test_aligners.cpp:1082 passes camera_50_in_00 through setMovingInFixed, "
+                                        "the inverse of the answer; started there the first search finds 3 of 321 correspondences and no reading of the "
+                                        "external arithmetic converges.  ref_pins.icl_aligner_depth therefore starts at the motion-model slice's estimate "
+                                        "(identity for the empty chunk of :1070-1078); srrg2_slam_interfaces (absent) would have to show that "
+                                        "AlignerSliceMotionModel calls setEstimate for this to be the reference's behaviour, not an assumption")
+def test_icl_aligner_depth_from_the_estimate_the_gtest_sets(oracle):
+    got = rp.icl_aligner_depth(OracleBackend(), guess="as_set")
+    assert got["status"] == 1 and np.all(np.abs(got["error"][:3]) < 0.01) and np.all(np.abs(got["error"][3:]) < 0.01), got["error"]

@@ -35,7 +35,14 @@ def _cells(sweep, guess, **variant):
 def test_shipped_family_meets_every_reference_pose_bound(sweep):
     cells = _cells(sweep, 1)
     assert len(cells) == 17
-    assert all(v < 1.0 for v in cells.values()), {k: round(v, 3) for k, v in cells.items() if v >= 1.0}
+    thin = {k: round(v, 3) for k, v in sorted(cells.items(), key=lambda kv: -kv[1]) if v >= 0.9}
+    # margin-aware failure message: the thin cells (>= 0.9 of their bound; the KITTI tracker's forward axis sits at 0.90 - 0.99) are
+    # named with their values, so that a libm / compiler change that tips one over is diagnosable from the log alone
+    assert all(v < 1.0 for v in cells.values()), "cells at or above their bound: %s; all thin cells: %s" % (
+        {k: round(v, 3) for k, v in cells.items() if v >= 1.0}, thin)
+    if thin:
+        import warnings
+        warnings.warn("a13 family: %d of 17 reference pose bounds are met with less than 10 %% margin: %s" % (len(thin), thin))
 
 
 def test_the_readings_of_rounds_2_and_3_miss_a_tracker_bound(sweep):
