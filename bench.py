@@ -50,6 +50,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VECTOR_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
 FLOP_PER_CORRESPONDENCE = 250.0  # one linearised correspondence of one GN iteration
+GPU_CLOCK_HZ = 2.4e9        # MI355X_MICROARCH.md: peak engine clock (s_memtime totals of one-workgroup kernels here: ~2.3e9)
+N_CU = 256
 
 
 def parse():
@@ -265,6 +267,12 @@ def profile_evidence(frames_per_launch, keypoints):
                 f = pick(summ["pmc_fetch"], pre)[1]["FETCH_SIZE"]
                 w = pick(summ["pmc_write"], pre)[1]["WRITE_SIZE"]
                 out[k] = (2.0 * f["mean"] + w["mean"]) * 1024.0 * (f["launches"] / steps)
+            # wave-instructions per bench step by class (SQ_INSTS_*: the issue roofline of the matcher)
+            try:
+                out["insts"] = {k: {c.replace("SQ_INSTS_", "").lower(): v["mean"] * (v["launches"] / steps)
+                                    for c, v in pick(summ["pmc_sq2"], pre)[1].items()} for k, pre in prefixes.items()}
+            except (KeyError, TypeError):
+                out["insts"] = None
             return out
         except (OSError, KeyError, ValueError, AssertionError):
             continue
@@ -994,8 +1002,11 @@ def main():
         "ms_per_step": ms_search, "ms_by_round": kt["search_ms_by_round"], "searches_per_frame_and_step": searches,
         "algorithmic_bytes_per_frame_and_launch": bytes_search, "frames_per_launch": B,
         "traffic_over_algorithmic": (evidence["search"] / (B * bytes_search * searches)) if evidence and searches > 0 else None,
-        "note": "not bandwidth-bound: vector ALU ~60 % and LDS pipe ~50 % busy at three 512-thread workgroups per CU, HBM traffic at the inputs "
-                "(profiles/r03/align_pmc.txt, rocprof_summary.json); frac prices the algorithmic bytes",
+        "counter_gbps": (evidence["search"] / (ms_search * 1e-3) / 1e9) if evidence and ms_search > 0 else None,
+        "note": "not bandwidth-bound: at three 512-thread workgroups per CU the waves are parked 62 % of their cycles on dependent LDS chains "
+                "(SQ_WAIT_ANY / SQ_WAVE_CYCLES), 27 k vector + 19 k scalar instructions per frame and launch, 77 % of a launch is the candidate scan "
+                "(profiles/r04/align_pmc.txt; round-5 phase stamps and the two scan experiments that did not pay: profiles/r05/search_experiments.txt); "
+                "frac prices the algorithmic bytes, counter_gbps the bytes the PMC passes saw",
     }
     roof_gn = {
         "kernel": "gn_kernel<SLOTS, stereo> (reprojection-error Gauss-Newton rounds: factor linearisation, fixed-shape H / b reduction, "
@@ -1005,8 +1016,9 @@ def main():
         "traffic_source": evidence["source"] if evidence else None,
         "ms_per_step": ms_gn, "ms_by_round": kt["gn_ms_by_round"], "algorithmic_flop_per_step": flops_gn,
         "flop_per_correspondence_iteration": FLOP_PER_CORRESPONDENCE,
-        "note": "fp32 vector arithmetic, no MFMA: 6x6 normal equations are not a dense contraction; the kernel is bound by "
-                "VALU issue (VALU-busy fraction in profiles/), frac prices only the algorithmic flops",
+        "counter_gbps": (evidence["gn"] / (ms_gn * 1e-3) / 1e9) if evidence and ms_gn > 0 else None,
+        "note": "fp32 vector arithmetic, no MFMA: 6x6 normal equations are not a dense contraction; the kernel is bound by vector issue "
+                "(SQ_ACTIVE_INST_VALU = 1.02 of a SIMD's wave cycles / 4, profiles/r04/align_pmc.txt), frac prices only the algorithmic flops",
     }
     roof_match = {
         "kernel": "stereo_match5_kernel<%d> (the kernel BASELINE.json north_star prices; matcher + fused adaptor / triangulator epilogue)" % (1 if N <= 1024 else 2),
@@ -1015,7 +1027,23 @@ def main():
         "traffic_source": evidence["source"] if evidence else None,
         "ms_per_launch": ms_match, "algorithmic_bytes_per_frame": bytes_match, "frames_per_launch": B,
         "traffic_over_algorithmic": (evidence["matcher"] / (B * bytes_match)) if evidence else None,
+        "counter_gbps": (evidence["matcher"] / (ms_match * 1e-3) / 1e9) if evidence and ms_match > 0 else None,
     }
+    # the matcher against its ISSUE roofline (review r04, item 3): wave-instructions per frame from the PMC passes x the issue cost of
+    # their class on gfx950 (profiles/r04/valu_issue_rates.txt: a SIMD retires a full-rate vector instruction every 2.4 cycles and one
+    # of the half-rate class -- popcount, funnel shifts, min / max, packed and three-operand integer: what this kernel is made of --
+    # every 4.3, with >= 2 waves per SIMD), four SIMDs per CU, one frame per CU at a time
+    if evidence and evidence.get("insts") and evidence["insts"].get("matcher") and ms_match > 0:
+        ins = evidence["insts"]["matcher"]
+        valu_frame = ins.get("valu", 0.0) / B
+        cyc_frame = ms_match * 1e-3 * GPU_CLOCK_HZ * N_CU / B
+        lo, hi = valu_frame / 4 * 2.4, valu_frame / 4 * 4.3
+        roof_match["issue_roofline"] = {
+            "vector_instructions_per_frame": valu_frame, "scalar_instructions_per_frame": ins.get("salu", 0.0) / B, "lds_instructions_per_frame": ins.get("lds", 0.0) / B,
+            "issue_bound_cycles_per_frame": [lo, hi], "measured_cycles_per_frame": cyc_frame, "achieved_over_issue_bound": [lo / cyc_frame, hi / cyc_frame],
+            "assumed_clock_hz": GPU_CLOCK_HZ, "compute_units": N_CU, "source": evidence["source"],
+            "note": "all-full-rate / all-half-rate bracket; the kernel keeps one 1024-thread workgroup per CU (151 KB LDS), so the rest of a frame's "
+                    "cycles are its own barriers and single-wave scans (56 % of the wave cycles parked, profiles/r04/matcher_pmc.txt)"}
     dominant = max((ms_search, "search", roof_search), (ms_gn, "gn", roof_gn), (ms_match, "matcher", roof_match))
     total_k = ms_match + ms_search + ms_gn
 

@@ -322,8 +322,9 @@ __device__ __forceinline__ void factor_accumulate(const prs_aligner_params& a, c
   // saturated kernel: a kernelised factor is weighted 1 / chi (round 4: tools/sweep_a13.py; a factor of exactly 1 leaves the
   // unsaturated weights untouched)
   const bool saturated = valid && chi > a.chi_threshold;
-  // (prs_aligner_params.kernel_weight_form: tau / chi instead; the division has the same cost with either numerator)
-  const float ratio    = inlier_only ? 0.0f : (a.kernel_weight_form == PRS_KERNEL_WEIGHT_TAU_OVER_CHI ? a.chi_threshold : 1.0f) / chi;  // inlier-only run: kernelised factors are suppressed
+  // (prs_aligner_params.kernel_weight_form: tau / chi instead.  The instantiations with a compile-time factor type are the shipped
+  // family's: align_batch_launch sends every other reading to the generic ones)
+  const float ratio    = inlier_only ? 0.0f : ((DIM == 0 && a.kernel_weight_form == PRS_KERNEL_WEIGHT_TAU_OVER_CHI) ? a.chi_threshold : 1.0f) / chi;  // inlier-only run: kernelised factors are suppressed
   const float scale    = saturated ? ratio : 1.0f;
   o0 *= scale;
   o1 *= scale;
@@ -2528,7 +2529,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   hipLaunchKernelGGL(split_init_kernel, dim3((batch->batch + 255) / 256), dim3(256), 0, stream, g.ctl, batch->result, g.pending, batch->batch);
   // (the rectified-stereo factor, the one kitti.conf / euroc.conf use, has its own instantiation: the factor type as a
   // compile-time constant removes ~10 selects per linearised correspondence; so does not remembering the factor classes)
-  const bool fast = aligner->factor_type == PRS_FACTOR_STEREO && !aligner->keep_only_inlier_correspondences;
+  const bool fast = aligner->factor_type == PRS_FACTOR_STEREO && !aligner->keep_only_inlier_correspondences && aligner->kernel_weight_form == PRS_KERNEL_WEIGHT_INV_CHI;
   // a batch that cannot fill the chip (fewer frames than two per CU) is bound by the serial chain of each frame, not by occupancy:
   // its instantiation may use the whole register file (WAVES = 1: no spills in the solve, the compiler schedules for latency)
   int n_cu = 0;
