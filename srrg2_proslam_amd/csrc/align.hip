@@ -1809,6 +1809,7 @@ __device__ __forceinline__ bool gn_advance(const prs_aligner_params& a, const in
 
 // The single-wave phase of a Gauss-Newton iteration once the 32 summed slots of the linearisation are in sh.H / b / chi / fcnt:
 // camera frame -> tangent space of X, class counts, (H + damping diag(H)) dx = -b, X <- X * exp(dx); `stid` = lane of the solving wave.
+template <bool SHIPPED_FORMS = false>
 __device__ __forceinline__ void gn_solve_wave(const AlignArgs& g, GnShared& sh, const int frame, const int nc, const int stid, const bool inlier_run) {
   const int lane = stid;
   if (sh.pose_ok) {  // (a pose that is not finite: all sums are zero and stay zero)
@@ -1889,7 +1890,7 @@ __device__ __forceinline__ void gn_solve_wave(const AlignArgs& g, GnShared& sh, 
     }
     auto bcast = [](const float v, const int l) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
     float dx[6];
-    const bool ok = ldlt_solve6(H, b, g.a.damping, dx, g.a.damping_form == PRS_DAMPING_IDENTITY);
+    const bool ok = ldlt_solve6(H, b, g.a.damping, dx, !SHIPPED_FORMS && g.a.damping_form == PRS_DAMPING_IDENTITY);
     float D[16];
     tnq2t(dx, D);
     float4 xn;
@@ -2052,9 +2053,22 @@ __global__ __launch_bounds__(128, WAVES) void gn_kernel(const AlignArgs g) {
     const int c = k * THREADS + tid;
     if (k * THREADS < nc && c < LROWS) {
       float4 z = c < nc ? gops[2 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
-      z.w      = inverse_depth_weight(z, mean_dsp, g.a.translation_weight_form);  // (the factors read x, y, z of the measurement only)
+      z.w      = inverse_depth_weight(z, mean_dsp, DIM != 0 ? 0 : g.a.translation_weight_form);  // (the factors read x, y, z of the measurement only)
       lz[c]    = z;
       lp[c]    = c < nc ? gops[2 * c + 1] : make_float4(0.f, 0.f, 1.f, 1.f);
+    }
+  }
+  // rows beyond the parked ones are streamed from global memory at every iteration: their translation weight goes into the fourth
+  // component of the measurement THERE, once per launch (no factor reads that component; the same thread reads the row back)
+  if (SLOTS > kGnLdsSlots) {
+    float4* wops = g.ops + (size_t) frame * (size_t) g.max_fixed * 2;
+#pragma unroll
+    for (int k = LS; k < SLOTS; ++k) {
+      const int c = k * THREADS + tid;  // (the thread that reads row c back in pass k)
+      if (c >= LROWS && c < nc) {
+        const float4 z = wops[2 * c];
+        wops[2 * c].w  = inverse_depth_weight(z, mean_dsp, DIM != 0 ? 0 : g.a.translation_weight_form);
+      }
     }
   }
   // the summed slot this lane ends up with, and where it goes
@@ -2116,9 +2130,8 @@ __global__ __launch_bounds__(128, WAVES) void gn_kernel(const AlignArgs g) {
               z = lz[c];
               p = lp[c];
             } else {
-              z   = c < nc ? gops[2 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
+              z   = c < nc ? gops[2 * c] : make_float4(0.f, 0.f, 0.f, 1.f);
               p   = c < nc ? gops[2 * c + 1] : make_float4(0.f, 0.f, 1.f, 1.f);
-              z.w = inverse_depth_weight(z, mean_dsp, g.a.translation_weight_form);
             }
             int cls;
             factor_accumulate<DIM, true>(g.a, pose, z, p, mean_dsp, c < nc, acc, code, cls, inlier_run);
@@ -2149,7 +2162,7 @@ __global__ __launch_bounds__(128, WAVES) void gn_kernel(const AlignArgs g) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        gn_solve_wave(g, sh, frame, nc, stid, inlier_run);
+        gn_solve_wave<DIM != 0>(g, sh, frame, nc, stid, inlier_run);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2529,7 +2542,8 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   hipLaunchKernelGGL(split_init_kernel, dim3((batch->batch + 255) / 256), dim3(256), 0, stream, g.ctl, batch->result, g.pending, batch->batch);
   // (the rectified-stereo factor, the one kitti.conf / euroc.conf use, has its own instantiation: the factor type as a
   // compile-time constant removes ~10 selects per linearised correspondence; so does not remembering the factor classes)
-  const bool fast = aligner->factor_type == PRS_FACTOR_STEREO && !aligner->keep_only_inlier_correspondences && aligner->kernel_weight_form == PRS_KERNEL_WEIGHT_INV_CHI;
+  const bool fast = aligner->factor_type == PRS_FACTOR_STEREO && !aligner->keep_only_inlier_correspondences && aligner->kernel_weight_form == PRS_KERNEL_WEIGHT_INV_CHI &&
+                    aligner->damping_form == PRS_DAMPING_DIAG && aligner->translation_weight_form == PRS_TRANSLATION_WEIGHT_OFFSET;
   // a batch that cannot fill the chip (fewer frames than two per CU) is bound by the serial chain of each frame, not by occupancy:
   // its instantiation may use the whole register file (WAVES = 1: no spills in the solve, the compiler schedules for latency)
   int n_cu = 0;
