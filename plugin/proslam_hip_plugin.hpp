@@ -80,6 +80,7 @@ private:
 using PropertyFloat       = Property_<float>;
 using PropertyUnsignedInt = Property_<uint64_t>;
 using PropertyBool        = Property_<bool>;
+using PropertyInt         = Property_<int>;
 
 // one prs_context shared by the plugin objects of a process (one device, one stream)
 class Context {
@@ -524,6 +525,11 @@ public:
   // MultiAligner3DQR flags the RGB-D configurations switch on (configurations/icl.conf:50-64, tum.conf:90-104)
   PropertyBool param_enable_inlier_only_runs{false};
   PropertyBool param_keep_only_inlier_correspondences{false};
+  // readings of the un-vendored srrg2_solver arithmetic (include/proslam_hip.h, prs_aligner_params): 0 = the family
+  // this library ships; a maintainer whose srrg2_solver does otherwise selects the other reading here (or in the .conf)
+  PropertyInt param_robustifier_kernel_weight_form{PRS_KERNEL_WEIGHT_INV_CHI};     // RobustifierSaturated: Omega / chi | Omega * tau / chi
+  PropertyInt param_damping_form{PRS_DAMPING_DIAG};                                // IterationAlgorithmGN: H + lambda diag(H) | H + lambda I
+  PropertyInt param_translation_weight_form{PRS_TRANSLATION_WEIGHT_OFFSET};        // min(0.01 + d / mean, 1) | clamp(d / mean, 0.01, 1)
   // AlignerSliceMotionModel3D (kitti.conf:747-772): prior on movingInFixed around setMotionPriorMean() (identity by default)
   PropertyBool param_enable_motion_model_slice{false};
   float param_motion_model_information[6] = {1, 1, 1, 1, 1, 1};
@@ -568,6 +574,9 @@ public:
     a.keep_only_inlier_correspondences = param_keep_only_inlier_correspondences.value() ? 1 : 0;
     a.with_sensor                      = _with_sensor ? 1 : 0;
     std::memcpy(a.sensor_in_robot, _sensor_in_robot, sizeof(_sensor_in_robot));
+    a.kernel_weight_form      = (int32_t) param_robustifier_kernel_weight_form.value();
+    a.damping_form            = (int32_t) param_damping_form.value();
+    a.translation_weight_form = (int32_t) param_translation_weight_form.value();
     a.enable_motion_prior = param_enable_motion_model_slice.value() ? 1 : 0;
     for (int i = 0; i < 6; ++i) a.motion_prior_info[i] = param_motion_model_information[i];
     std::vector<prs_corr> out(_n_fixed + 1);

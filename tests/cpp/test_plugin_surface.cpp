@@ -185,6 +185,72 @@ static void test_AlignerSliceProcessorProjective(ContextPtr ctx) {
   ASSERT_TRUE(aligner.correspondences().size() > 40);
 }
 
+// the readings of the un-vendored srrg2_solver arithmetic as PARAMs of the aligner adapter (include/proslam_hip.h, prs_aligner_params):
+// the scenario above converges under each of them to the same bounds, the estimates differ in their last bits, and a value the
+// library does not know is refused loudly (the adapter throws like the reference's objects do on a bad configuration)
+static void test_AlignerSolverArithmeticParams(ContextPtr ctx) {
+  SyntheticWorld world(2);
+  const float a = 0.001f, b = 0.001f, c = -0.001f;
+  const float R9[9] = {1, -c, b, c, 1, -a, -b, a, 1};
+  const float t3[3] = {0, 0, -1};
+  PointIntensityDescriptorVectorCloud<2> fixed;
+  std::vector<int> truth;
+  world.project<2>(R9, t3, fixed, truth);
+  using Finder = CorrespondenceFinderProjectiveKDTreeHIP<PointIntensityDescriptorVectorCloud<2>, PointIntensityDescriptorVectorCloud<3>>;
+  const float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  float first[16] = {0};
+  bool any_differs = false;
+  for (int form = 0; form < 3; ++form) {  // 0: shipped, 1: tau / chi kernel weight, 2: H + lambda I
+    AlignerProjectiveHIP<Finder> aligner(ctx);
+    Finder& finder = *aligner.param_finder;
+    finder.param_maximum_descriptor_distance.setValue(75);
+    finder.param_minimum_descriptor_distance.setValue(25);
+    finder.param_maximum_distance_ratio_to_second_best.setValue(0.5f);
+    finder.param_maximum_search_radius_pixels.setValue(50);
+    finder.param_projector->param_canvas_cols.setValue(1000);
+    finder.param_projector->param_canvas_rows.setValue(1000);
+    finder.param_projector->param_range_min.setValue(0.1f);
+    finder.param_projector->param_range_max.setValue(1000);
+    finder.param_projector->setCameraMatrix(world.K);
+    aligner.param_max_iterations.setValue(10);
+    aligner.param_damping.setValue(0.5f);
+    aligner.param_chi_threshold.setValue(1.0f);  // (so that the saturated kernel is active)
+    aligner.param_robustifier_kernel_weight_form.setValue(form == 1 ? PRS_KERNEL_WEIGHT_TAU_OVER_CHI : PRS_KERNEL_WEIGHT_INV_CHI);
+    aligner.param_damping_form.setValue(form == 2 ? PRS_DAMPING_IDENTITY : PRS_DAMPING_DIAG);
+    aligner.setFixed(&fixed);
+    aligner.setMoving(&world.points_in_world);
+    aligner.setMovingInFixed(I16);
+    aligner.compute();
+    ASSERT_EQ(aligner.status(), AlignerProjectiveHIP<Finder>::Success);
+    const float* X = aligner.movingInFixed();
+    for (int r = 0; r < 3; ++r) {
+      const float et = X[4 * r] * t3[0] + X[4 * r + 1] * t3[1] + X[4 * r + 2] * t3[2] + X[4 * r + 3];
+      ASSERT_LT_ABS(et, 0.15f);
+    }
+    if (form == 0) {
+      std::memcpy(first, X, sizeof(first));
+    } else {
+      any_differs = any_differs || std::memcmp(first, X, sizeof(first)) != 0;
+    }
+  }
+  ASSERT_TRUE(any_differs);  // the switches reach the kernels
+  AlignerProjectiveHIP<Finder> bad(ctx);
+  bad.param_finder->param_projector->param_canvas_cols.setValue(1000);
+  bad.param_finder->param_projector->param_canvas_rows.setValue(1000);
+  bad.param_finder->param_projector->setCameraMatrix(world.K);
+  bad.param_damping_form.setValue(7);
+  bad.setFixed(&fixed);
+  bad.setMoving(&world.points_in_world);
+  bad.setMovingInFixed(I16);
+  bool thrown = false;
+  try {
+    bad.compute();
+  } catch (const std::exception&) {
+    thrown = true;
+  }
+  ASSERT_TRUE(thrown);
+}
+
 // SyntheticWorldWithDescriptorsSE3.AlignerSliceProcessorProjectiveDepthWithSensor (tests/test_aligners.cpp:281-426):
 // sensor_in_robot = ((0.2, 0.3, 0.4), a2r(0, 0.05 pi, 0)), robot 1 at (0, 0, -1); the estimate is the ROBOT's motion.
 // The MultiAligner3DQR flags of icl.conf (inlier-only runs, keep only inliers) are switched on as well.
@@ -556,6 +622,7 @@ int main() {
   RUN(test_Epipolar_ThrowsWhenUnset);
   RUN(test_ProjectiveCircle_NoMotionNoNoise);
   RUN(test_AlignerSliceProcessorProjective);
+  RUN(test_AlignerSolverArithmeticParams);
   RUN(test_AlignerSliceProcessorProjectiveDepthWithSensor);
   RUN(test_TriangulatorRigidStereo);
   RUN(test_SceneClipperProjective3D);

@@ -17,7 +17,7 @@ def test_cpp_plugin_surface_program():
     r = subprocess.run([EXE], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=300)
     out = r.stdout.decode()
     assert r.returncode == 0, out
-    assert out.count("[  OK  ]") == 11 and "FAILED" not in out and "0 failure(s)" in out, out
+    assert out.count("[  OK  ]") == 12 and "FAILED" not in out and "0 failure(s)" in out, out
 
 
 def test_cpp_plugin_surface_builds_and_fails_loudly_without_gpu():
