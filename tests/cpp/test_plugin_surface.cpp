@@ -212,9 +212,9 @@ static void test_AlignerSolverArithmeticParams(ContextPtr ctx) {
     finder.param_projector->param_range_min.setValue(0.1f);
     finder.param_projector->param_range_max.setValue(1000);
     finder.param_projector->setCameraMatrix(world.K);
-    aligner.param_max_iterations.setValue(10);
-    aligner.param_damping.setValue(0.5f);
-    aligner.param_chi_threshold.setValue(1.0f);  // (so that the saturated kernel is active)
+    aligner.param_max_iterations.setValue(40);
+    aligner.param_damping.setValue(0.1f);
+    aligner.param_chi_threshold.setValue(25.0f);  // (5 px: the saturated kernel is active in the first iterations)
     aligner.param_robustifier_kernel_weight_form.setValue(form == 1 ? PRS_KERNEL_WEIGHT_TAU_OVER_CHI : PRS_KERNEL_WEIGHT_INV_CHI);
     aligner.param_damping_form.setValue(form == 2 ? PRS_DAMPING_IDENTITY : PRS_DAMPING_DIAG);
     aligner.setFixed(&fixed);
