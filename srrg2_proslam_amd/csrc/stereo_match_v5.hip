@@ -13,8 +13,10 @@
 //     backwards sweep over the <= 4 candidates); the serial cursor chain (one lane per row, 6 of 16
 //     waves) then needs one 4-byte read, one shift and one 2-byte write per left keypoint;
 //   * the right coordinates the epilogue needs are staged in LDS next to the descriptor rows.
-// A window of more than four candidates is scored into a pool of 16-bit entries (LDS left over by the layout) and the chain
-// compares those; rows with a window the pool has no room for are replayed by a second, rarely entered sweep that
+// A window of more than four candidates is scored into a pool of 32-bit entries (LDS left over by the layout); the scoring lane
+// then sweeps its window backwards and leaves, for every position the chain's cursor may stand at, the verdict of the candidates from
+// there on (round 5: the chain looks one word up instead of comparing the window again, which on row-skewed real keypoints was most of
+// the longest row's chain); rows with a window the pool has no room for are replayed by a second, rarely entered sweep that
 // re-scores those windows from global memory.
 #include <type_traits>
 
@@ -33,7 +35,7 @@ struct Args5 {
   int nwords;  // 32-bit words covering cap positions
   uint32_t off_desc_r, off_kp_r, off_sorted_l, off_sorted_r, off_bucket, off_hist, off_rs, off_len, off_rowcnt, off_out, off_bits, off_misc,
     off_tab, off_pool;
-  int pool_cap;  // 16-bit entries of the candidate pool (windows of more than four candidates), 0: none
+  int pool_cap;  // 32-bit entries of the candidate pool (windows of more than four candidates), 0: none
   int best_lim;       // accept iff best < best_lim ...
   int16_t bmax[258];  // ... and best <= bmax[second] (257 = no second candidate), see fill_accept_table
   unsigned long long* stamps;
@@ -44,7 +46,9 @@ constexpr int kT                = 1024;
 constexpr uint32_t kNone        = 0xffffu;
 constexpr uint32_t kOverflow    = 1u << 31;
 constexpr uint32_t kPooled      = 1u << 30;  // ... and its candidates were scored into the pool: res[p].x = pool offset | candidates << 16
-// pool entry of one candidate: distance (0..256) | kept by the stereo adaptor << 12 | pruned by an earlier pass << 13
+// pool entry of one candidate while its window is being scored: distance (0..256) | kept by the stereo adaptor << 12 | pruned by an
+// earlier pass << 13; once the window is swept, entry j holds the verdict of the candidates j .. n-1:
+//   accepted << 31 | best candidate kept << 30 | (best candidate - the window's start) << 9 | best distance
 constexpr uint32_t kPoolPruned  = 1u << 13;
 // candidate record of a sorted-left position (written by the scoring phase):
 //   res[p].x  = verdict[0..3], 4 bit each (bits 16..19 stay zero: "cursor beyond the window")
@@ -91,6 +95,25 @@ __device__ __forceinline__ int below3(const q32& q0, const q32& q1, const q32& q
 }
 __device__ __forceinline__ int below(const q32& q, uint32_t bound) {
   return __popc(below_bits(0u, q, bound));
+}
+
+// The scored candidates of a window of more than four, swept backwards: entry j becomes the verdict of the candidates j .. n-1 --
+// best / second best (epipolar_impl.cpp:158-164: the first of equal distances wins, the second best counts multiplicity) as the smallest
+// and second smallest of the unique keys (distance, position, keep bit), then the acceptance test (:171-173) -- what the chain's cursor
+// finds when it stands at j.  Out of line: crowded windows are rare (a few dozen per real frame, none in most synthetic ones) and the
+// scoring phase around the call is bound by its registers.
+__device__ __attribute__((noinline)) void sweep_pooled_window(uint32_t* w, const int n, const int16_t* tab, const int best_lim) {
+  uint32_t bestk = 0xffffffffu, seck = 0xffffffffu;
+  for (int j = n - 1; j >= 0; --j) {
+    const uint32_t e   = w[j];
+    const uint32_t key = (e & kPoolPruned) ? 0xffffffffu : (((e & 0x1ffu) << 17) | ((uint32_t) j << 1) | ((e >> 12) & 1u));
+    const uint32_t hk  = key > bestk ? key : bestk;
+    seck               = hk < seck ? hk : seck;
+    bestk              = key < bestk ? key : bestk;
+    const uint32_t best = bestk == 0xffffffffu ? kNone : bestk >> 17, second = seck == 0xffffffffu ? kNone : seck >> 17;
+    const bool accept   = best != kNone && (int) best < best_lim && (int) best <= (int) tab[second == kNone ? 257u : second];
+    w[j] = accept ? (1u << 31) | ((bestk & 1u) << 30) | (((bestk >> 1) & 0xffffu) << 9) | best : 0u;
+  }
 }
 
 // inclusive prefix sum over the 64 lanes of a wave on the DPP network (round 4; was six ds_bpermute round trips): Hillis-Steele inside
@@ -223,7 +246,7 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
   uint32_t* bitsR   = bitsL + nwords;                                       // right sorted position matched
   int* misc         = reinterpret_cast<int*>(smem + a.off_misc);            // [0] error, [1] pass matches, [2] pass kept
   int16_t* tab      = reinterpret_cast<int16_t*>(smem + a.off_tab);         // Lowe acceptance table
-  uint16_t* pool    = reinterpret_cast<uint16_t*>(smem + a.off_pool);       // scored candidates of the windows with more than four
+  uint32_t* pool    = reinterpret_cast<uint32_t*>(smem + a.off_pool);       // scored candidates of the windows with more than four
 
   // persistent: grid = CUs, frames strided over the workgroups; the next frame's coordinates are
   // requested while this frame is scored, its descriptor rows when it starts (see stereo_match.hip)
@@ -506,8 +529,9 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
                     entry |= (hd < 0.0f || vd < 0.0f) ? 0u : (1u << 12);
                   }
                 }
-                pool[poff + j] = (uint16_t) entry;
+                pool[poff + j] = entry;
               }
+              sweep_pooled_window(pool + poff, n, tab, best_lim);
               r = make_uint2((uint32_t) poff | ((uint32_t) n << 16), (uint32_t) lo | kOverflow | kPooled);
             }
           } else if (n > 0) {
@@ -588,20 +612,12 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
             // more than four in-window candidates, scored into the pool: best / second best from the cursor on
             const uint32_t poff = w.x & 0xffffu;
             const int hi        = lo + (int) (w.x >> 16);
-            // best / second best (epipolar_impl.cpp:158-164: the first of equal distances wins, the second best counts multiplicity) as
-            // the smallest and second smallest of the unique keys (distance, position, keep bit): no branch in the loop -- the 64 rows
-            // of a wave are at different places of theirs, a divergent branch costs every lane both sides
-            uint32_t bestk = 0xffffffffu, seck = 0xffffffffu;
-            for (int q = c > lo ? c : lo; q < hi; ++q) {
-              const uint32_t e   = pool[poff + (uint32_t) (q - lo)];
-              const uint32_t key = (e & kPoolPruned) ? 0xffffffffu : (((e & 0x1ffu) << 17) | ((uint32_t) q << 1) | ((e >> 12) & 1u));
-              const uint32_t hk  = key > bestk ? key : bestk;
-              seck               = hk < seck ? hk : seck;
-              bestk              = key < bestk ? key : bestk;
-            }
-            const uint32_t best = bestk == 0xffffffffu ? kNone : bestk >> 17, second = seck == 0xffffffffu ? kNone : seck >> 17;
-            const uint32_t best_q = (bestk >> 1) & 0xffffu, best_keep = bestk & 1u;
-            if (best != kNone && (int) best < best_lim && (int) best <= (int) tab[second == kNone ? 257u : second]) {
+            // the verdict of the candidates from the cursor on was left in the pool by the scoring lane
+            const int sfrom       = c > lo ? c - lo : 0;
+            const uint32_t word   = sfrom < hi - lo ? pool[poff + (uint32_t) sfrom] : 0u;
+            const uint32_t best   = word & 0x1ffu;
+            const uint32_t best_q = (uint32_t) lo + ((word >> 9) & 0xffffu), best_keep = (word >> 30) & 1u;
+            if (word >> 31) {
               dist4[p] = (sortedR[best_q] & 0xffffu) | (best << 16);  // (res[p] keeps the pool reference: the row may be replayed)
               outv[p]  = ((8u | best_keep) << 28) | kOutRescored | (kept << 12) | cnt;
               ++cnt;
@@ -854,11 +870,11 @@ int stereo_match_v5_launch(prs_context* ctx, const prs_stereo_params* params, co
   if (off > 160u * 1024u) {
     return 1;
   }
-  // what is left of the 160 KB holds the scored candidates of crowded windows (two bytes each, at most 4096)
+  // what is left of the 160 KB holds the scored candidates of crowded windows (four bytes each, at most 4096)
   a.off_pool = off;
-  a.pool_cap = (int) (((160u * 1024u - off) / 2u) & ~3u);
+  a.pool_cap = (int) (((160u * 1024u - off) / 4u) & ~3u);
   a.pool_cap = a.pool_cap > 4096 ? 4096 : (a.pool_cap < 64 ? 0 : a.pool_cap);
-  off        = up16(off + (uint32_t) a.pool_cap * 2u);
+  off        = up16(off + (uint32_t) a.pool_cap * 4u);
   const size_t lds = off;
   a.p        = *params;
   a.b        = *batch;
