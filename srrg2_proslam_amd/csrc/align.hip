@@ -1809,7 +1809,9 @@ __device__ __forceinline__ bool gn_advance(const prs_aligner_params& a, const in
 
 // The single-wave phase of a Gauss-Newton iteration once the 32 summed slots of the linearisation are in sh.H / b / chi / fcnt:
 // camera frame -> tangent space of X, class counts, (H + damping diag(H)) dx = -b, X <- X * exp(dx); `stid` = lane of the solving wave.
-template <bool SHIPPED_FORMS = false>
+// PLAIN: no additive prior, no motion-model prior, no sensor offset (what align_batch_launch found in the parameters): the branches and
+// their registers are not part of that instantiation
+template <bool SHIPPED_FORMS = false, bool PLAIN = false>
 __device__ __forceinline__ void gn_solve_wave(const AlignArgs& g, GnShared& sh, const int frame, const int nc, const int stid, const bool inlier_run) {
   const int lane = stid;
   if (sh.pose_ok) {  // (a pose that is not finite: all sums are zero and stay zero)
@@ -1869,7 +1871,7 @@ __device__ __forceinline__ void gn_solve_wave(const AlignArgs& g, GnShared& sh, 
     for (int i = 0; i < 6; ++i) {
       b[i] = sh.b[i];
     }
-    if (g.b.prior) {
+    if (!PLAIN && g.b.prior) {
       const float* pr = g.b.prior + (size_t) frame * 42;
 #pragma unroll
       for (int i = 0; i < 36; ++i) {
@@ -1880,7 +1882,7 @@ __device__ __forceinline__ void gn_solve_wave(const AlignArgs& g, GnShared& sh, 
         b[i] += pr[36 + i];
       }
     }
-    if (g.a.enable_motion_prior) {
+    if (!PLAIN && g.a.enable_motion_prior) {
       float X[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -1907,7 +1909,7 @@ __device__ __forceinline__ void gn_solve_wave(const AlignArgs& g, GnShared& sh, 
     const bool any_changed = (__ballot(changed != 0u) & 7ull) != 0ull;
     // points -> camera: X, or sensor_in_robot^-1 * X
     float4 an = xn;
-    if (g.a.with_sensor) {
+    if (!PLAIN && g.a.with_sensor) {
       const float4 sr = *reinterpret_cast<const float4*>(&sh.Sinv[4 * prow]);
       const float4 x0 = {bcast(xn.x, 0), bcast(xn.y, 0), bcast(xn.z, 0), bcast(xn.w, 0)};
       const float4 x1 = {bcast(xn.x, 1), bcast(xn.y, 1), bcast(xn.z, 1), bcast(xn.w, 1)};
@@ -1980,7 +1982,7 @@ constexpr int kGnLdsSlots = 4;
 constexpr size_t gn_lds_bytes(const int lds_slots) {
   return ((sizeof(GnShared) + 15) / 16) * 16 + (size_t) (lds_slots * 128 + 64) * 2 * sizeof(float4);  // shared state + parked operand rows
 }
-template <int SLOTS, int DIM, bool KEEP_CLS, int LDS_SLOTS = kGnLdsSlots, int WAVES = 4>
+template <int SLOTS, int DIM, bool KEEP_CLS, int LDS_SLOTS = kGnLdsSlots, int WAVES = 4, bool PLAIN = false>
 __global__ __launch_bounds__(128, WAVES) void gn_kernel(const AlignArgs g) {
   constexpr int THREADS = 128;
   constexpr int kGnLdsSlots = LDS_SLOTS;  // (shadow the defaults)
@@ -2162,7 +2164,7 @@ __global__ __launch_bounds__(128, WAVES) void gn_kernel(const AlignArgs g) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        gn_solve_wave<DIM != 0>(g, sh, frame, nc, stid, inlier_run);
+        gn_solve_wave<DIM != 0, PLAIN>(g, sh, frame, nc, stid, inlier_run);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2550,9 +2552,10 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   (void) hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
   const bool lone = fast && batch->batch <= 2 * (n_cu > 0 ? n_cu : 256) && !ctx->no_lone_gn;
   const bool five = fast && !lone && max_fixed > 4 * 128;  // (gn_kernel: LDS_SLOTS / WAVES)
+  const bool plain = !batch->prior && !aligner->enable_motion_prior && !aligner->with_sensor;  // (gn_solve_wave: PLAIN)
   auto gnk        = lone ? (max_fixed <= 4 * 128 ? gn_kernel<4, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1> : gn_kernel<8, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1>)
                          : (max_fixed <= 4 * 128 ? (fast ? gn_kernel<4, PRS_FACTOR_STEREO, false> : gn_kernel<4, 0, true>)
-                                                 : (fast ? gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5> : gn_kernel<8, 0, true>));
+                                                 : (fast ? (plain ? gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5, true> : gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5>) : gn_kernel<8, 0, true>));
   const size_t lds_gn = gn_lds_bytes(five ? 3 : kGnLdsSlots);
   // The job lives in the context until align_batch_finish: the rounds are plain launches on the context's stream (no host
   // synchronisation here, the sequence can be captured in a HIP graph once the scratch buffers exist).
