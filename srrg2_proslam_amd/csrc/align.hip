@@ -1809,8 +1809,8 @@ __device__ __forceinline__ bool gn_advance(const prs_aligner_params& a, const in
 
 // The single-wave phase of a Gauss-Newton iteration once the 32 summed slots of the linearisation are in sh.H / b / chi / fcnt:
 // camera frame -> tangent space of X, class counts, (H + damping diag(H)) dx = -b, X <- X * exp(dx); `stid` = lane of the solving wave.
-// PLAIN: no additive prior, no motion-model prior, no sensor offset (what align_batch_launch found in the parameters): the branches and
-// their registers are not part of that instantiation
+// PLAIN: no additive prior, no motion-model prior, no sensor offset, no inlier-only runs (what align_batch_launch found in the
+// parameters): the branches and their registers are not part of that instantiation
 template <bool SHIPPED_FORMS = false, bool PLAIN = false>
 __device__ __forceinline__ void gn_solve_wave(const AlignArgs& g, GnShared& sh, const int frame, const int nc, const int stid, const bool inlier_run) {
   const int lane = stid;
@@ -2081,7 +2081,7 @@ __global__ __launch_bounds__(128, WAVES) void gn_kernel(const AlignArgs g) {
   int it_align = ctl->it_align;
   int executed = ctl->executed;
   bool done    = false;
-  const int extra = inlier_run_length(g.a);  // iterations of the inlier-only run after the max_iterations loop
+  const int extra = PLAIN ? 0 : inlier_run_length(g.a);  // iterations of the inlier-only run after the max_iterations loop
   uint32_t cls_bits = 0;                     // factor classes of this thread's correspondences in the last linearisation (2 bits each)
   bool have_cls     = false;                 // (block-uniform) the last executed iteration linearised
 
@@ -2108,7 +2108,7 @@ __global__ __launch_bounds__(128, WAVES) void gn_kernel(const AlignArgs g) {
       }
       __syncthreads();
     } else {
-      const bool inlier_run = it_align >= g.a.max_iterations;
+      const bool inlier_run = !PLAIN && it_align >= g.a.max_iterations;  // (PLAIN: no inlier-only runs either, so never true)
       have_cls              = true;
       cls_bits              = 0;
       const PoseRegs pose = {sh.A[0], sh.A[1], sh.A[2], sh.A[3], sh.A[4], sh.A[5], sh.A[6], sh.A[7], sh.A[8], sh.A[9], sh.A[10], sh.A[11]};
@@ -2552,7 +2552,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   (void) hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
   const bool lone = fast && batch->batch <= 2 * (n_cu > 0 ? n_cu : 256) && !ctx->no_lone_gn;
   const bool five = fast && !lone && max_fixed > 4 * 128;  // (gn_kernel: LDS_SLOTS / WAVES)
-  const bool plain = !batch->prior && !aligner->enable_motion_prior && !aligner->with_sensor;  // (gn_solve_wave: PLAIN)
+  const bool plain = !batch->prior && !aligner->enable_motion_prior && !aligner->with_sensor && !aligner->enable_inlier_only_runs;  // (gn_kernel / gn_solve_wave: PLAIN)
   auto gnk        = lone ? (max_fixed <= 4 * 128 ? gn_kernel<4, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1> : gn_kernel<8, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1>)
                          : (max_fixed <= 4 * 128 ? (fast ? gn_kernel<4, PRS_FACTOR_STEREO, false> : gn_kernel<4, 0, true>)
                                                  : (fast ? (plain ? gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5, true> : gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5>) : gn_kernel<8, 0, true>));
