@@ -218,7 +218,10 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t* cnt, int n) {
   return __shfl(incl, 63, 64);
 }
 
-template <int KPT>
+// MULTI: epipolar_line_thickness_pixels > 0 (several passes over row offsets 0, +1, -1, .. with the matched keypoints of earlier passes
+// pruned: epipolar_impl.cpp:197-205).  kitti.conf / euroc.conf run ONE pass: their instantiation carries neither the bit sets nor the
+// per-candidate pruning tests (round 5)
+template <int KPT, bool MULTI>
 __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid    = threadIdx.x;
@@ -462,8 +465,8 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
     const int best_lim   = a.best_lim;
     const int max_disp   = a.p.maximum_disparity_pixels;
     const int thickness  = a.p.epipolar_line_thickness_pixels > 0 ? a.p.epipolar_line_thickness_pixels : 0;
-    const int n_offsets  = 1 + 2 * thickness;
-    const bool multipass = n_offsets > 1;
+    const int n_offsets  = MULTI ? 1 + 2 * thickness : 1;
+    const bool multipass = MULTI && n_offsets > 1;
     prs_corr* __restrict__ out = a.b.matches + base;
     int out_base               = 0;
     int fixed_base             = 0;
@@ -819,7 +822,7 @@ inline uint32_t up16(uint32_t v) {
 
 template <int KPT>
 hipError_t launch5(const Args5& a, size_t lds, hipStream_t stream) {
-  auto kernel  = stereo_match5_kernel<KPT>;
+  auto kernel  = a.p.epipolar_line_thickness_pixels > 0 ? stereo_match5_kernel<KPT, true> : stereo_match5_kernel<KPT, false>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
   if (e != hipSuccess) {
     return e;
