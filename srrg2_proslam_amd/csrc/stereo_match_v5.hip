@@ -221,7 +221,8 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t* cnt, int n) {
 // MULTI: epipolar_line_thickness_pixels > 0 (several passes over row offsets 0, +1, -1, .. with the matched keypoints of earlier passes
 // pruned: epipolar_impl.cpp:197-205).  kitti.conf / euroc.conf run ONE pass: their instantiation carries neither the bit sets nor the
 // per-candidate pruning tests (round 5)
-template <int KPT, bool MULTI>
+// EPI: the fused stereo-adaptor + triangulator epilogue is wanted (prs_stereo_batch carries its output buffers)
+template <int KPT, bool MULTI, bool EPI>
 __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid    = threadIdx.x;
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
       if (tid == 0) {
         a.b.n_matches[frame] = 0;
         a.b.status[frame]    = PRS_ERR_RANGE;
-        if (a.epilogue) {
+        if (EPI) {
           a.b.n_fixed[frame] = 0;
         }
       }
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
                 if (!(multipass && ((bitsR[q >> 5] >> (q & 31)) & 1u))) {
                   const int idx_r = (int) (sortedR[q] & 0xffffu);
                   entry           = hamming5(d0, d1, ldR[2 * idx_r], ldR[2 * idx_r + 1]);
-                  if (a.epilogue) {
+                  if (EPI) {
                     const prs_kp2 kr = ldKR[idx_r];
                     const float hd = cL[k].u - kr.u, vd = cL[k].v - kr.v;
                     entry |= (hd < 0.0f || vd < 0.0f) ? 0u : (1u << 12);
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
                 if (!(multipass && ((bitsR[q >> 5] >> (q & 31)) & 1u))) {
                   const int idx_r = (int) (sortedR[q] & 0xffffu);
                   dist[j]         = hamming5(d0, d1, ldR[2 * idx_r], ldR[2 * idx_r + 1]);
-                  if (a.epilogue) {
+                  if (EPI) {
                     // raw_data_preprocessor_stereo_projective.cpp:117-125
                     const prs_kp2 kr = ldKR[idx_r];
                     const float hd = cL[k].u - kr.u, vd = cL[k].v - kr.v;
@@ -662,7 +663,7 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
               const uint32_t idx_r = sortedR[best_q] & 0xffffu;
               res[p].x             = idx_r | (best << 16);
               uint32_t keep        = 0;
-              if (a.epilogue) {
+              if (EPI) {
                 const prs_kp2 kl2 = a.b.left_kp[base + (size_t) idx_l];
                 const prs_kp2 kr2 = ldKR[idx_r];
                 const float hd = kl2.u - kr2.u, vd = kl2.v - kr2.v;
@@ -761,7 +762,7 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
           cr.moving_idx = (int) idx_r;
           cr.response   = (float) best;
           out[out_base + (int) (before & 0xffffu) + (int) (v & 0xfffu)] = cr;  // index inside this pass
-          if (a.epilogue && ((v >> 28) & 1u)) {
+          if (EPI && ((v >> 28) & 1u)) {
             const int slot   = fixed_base + (int) (before >> 16) + (int) ((v >> 12) & 0xfffu);
             const size_t g   = base + (size_t) slot;
             const prs_kp2 kr = ldKR[idx_r];
@@ -808,7 +809,7 @@ __global__ __launch_bounds__(kT) void stereo_match5_kernel(const Args5 a) {
       }
       a.b.n_matches[frame] = out_base;
       a.b.status[frame]    = flags;
-      if (a.epilogue) {
+      if (EPI) {
         a.b.n_fixed[frame] = fixed_base;
       }
     }
@@ -822,7 +823,9 @@ inline uint32_t up16(uint32_t v) {
 
 template <int KPT>
 hipError_t launch5(const Args5& a, size_t lds, hipStream_t stream) {
-  auto kernel  = a.p.epipolar_line_thickness_pixels > 0 ? stereo_match5_kernel<KPT, true> : stereo_match5_kernel<KPT, false>;
+  const bool multi = a.p.epipolar_line_thickness_pixels > 0;
+  auto kernel      = a.epilogue ? (multi ? stereo_match5_kernel<KPT, true, true> : stereo_match5_kernel<KPT, false, true>)
+                                : (multi ? stereo_match5_kernel<KPT, true, false> : stereo_match5_kernel<KPT, false, false>);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
   if (e != hipSuccess) {
     return e;
