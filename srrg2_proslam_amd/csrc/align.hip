@@ -243,6 +243,11 @@ __device__ __forceinline__ float inverse_depth_weight(const float4 z, const floa
   const float wt = 0.01f + dn;
   return wt < 1.0f ? (wt >= kWeightFloor ? wt : 1.0f) : 1.0f;
 }
+// what the Gauss-Newton kernel parks in the fourth component of a measurement (no factor reads it): the translation weight the stereo
+// factor applies, 1 when the weighting is off
+__device__ __forceinline__ float parked_translation_weight(const prs_aligner_params& a, const float4 z, const float mean_dsp, const int form) {
+  return a.enable_inverse_depth_weighting ? inverse_depth_weight(z, mean_dsp, form) : 1.0f;
+}
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kPairs = 16;  // the 29 sums + 3 class counts of one linearisation travel as 16 float pairs (32 "slots")
 // slot (= 2 * pair + component) -> meaning: the upper triangle of the CAMERA-FRAME normal equations row by row (factor_accumulate),
@@ -303,8 +308,12 @@ __device__ __forceinline__ void factor_accumulate(const prs_aligner_params& a, c
     e2 = (valid ? pcz : 0.0f) - z.z;
   }
   float wt = 1.0f;
-  if (dim == PRS_FACTOR_STEREO && a.enable_inverse_depth_weighting) {
-    wt = PRE_WT ? z.w : inverse_depth_weight(z, mean_dsp, a.translation_weight_form);  // always finite
+  if (dim == PRS_FACTOR_STEREO) {
+    if (PRE_WT) {
+      wt = z.w;  // (whoever parked the row wrote 1 there when the weighting is off: parked_translation_weight)
+    } else if (a.enable_inverse_depth_weighting) {
+      wt = inverse_depth_weight(z, mean_dsp, a.translation_weight_form);  // always finite
+    }
   }
   const float alpha = fx * iz, gamma = fy * iz;
   const float beta0 = (cx - u_pred) * iz;
@@ -2055,7 +2064,7 @@ __global__ __launch_bounds__(128, WAVES) void gn_kernel(const AlignArgs g) {
     const int c = k * THREADS + tid;
     if (k * THREADS < nc && c < LROWS) {
       float4 z = c < nc ? gops[2 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
-      z.w      = inverse_depth_weight(z, mean_dsp, DIM != 0 ? 0 : g.a.translation_weight_form);  // (the factors read x, y, z of the measurement only)
+      z.w      = parked_translation_weight(g.a, z, mean_dsp, DIM != 0 ? 0 : g.a.translation_weight_form);  // (the factors read x, y, z of the measurement only)
       lz[c]    = z;
       lp[c]    = c < nc ? gops[2 * c + 1] : make_float4(0.f, 0.f, 1.f, 1.f);
     }
@@ -2069,7 +2078,7 @@ __global__ __launch_bounds__(128, WAVES) void gn_kernel(const AlignArgs g) {
       const int c = k * THREADS + tid;  // (the thread that reads row c back in pass k)
       if (c >= LROWS && c < nc) {
         const float4 z = wops[2 * c];
-        wops[2 * c].w  = inverse_depth_weight(z, mean_dsp, DIM != 0 ? 0 : g.a.translation_weight_form);
+        wops[2 * c].w  = parked_translation_weight(g.a, z, mean_dsp, DIM != 0 ? 0 : g.a.translation_weight_form);
       }
     }
   }
@@ -2554,7 +2563,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   const bool five = fast && !lone && max_fixed > 4 * 128;  // (gn_kernel: LDS_SLOTS / WAVES)
   const bool plain = !batch->prior && !aligner->enable_motion_prior && !aligner->with_sensor && !aligner->enable_inlier_only_runs;  // (gn_kernel / gn_solve_wave: PLAIN)
   auto gnk        = lone ? (max_fixed <= 4 * 128 ? gn_kernel<4, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1> : gn_kernel<8, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1>)
-                         : (max_fixed <= 4 * 128 ? (fast ? gn_kernel<4, PRS_FACTOR_STEREO, false> : gn_kernel<4, 0, true>)
+                         : (max_fixed <= 4 * 128 ? (fast ? (plain ? gn_kernel<4, PRS_FACTOR_STEREO, false, kGnLdsSlots, 4, true> : gn_kernel<4, PRS_FACTOR_STEREO, false>) : gn_kernel<4, 0, true>)
                                                  : (fast ? (plain ? gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5, true> : gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5>) : gn_kernel<8, 0, true>));
   const size_t lds_gn = gn_lds_bytes(five ? 3 : kGnLdsSlots);
   // The job lives in the context until align_batch_finish: the rounds are plain launches on the context's stream (no host

@@ -109,3 +109,24 @@ def test_translation_weight_is_finite_for_hostile_disparities(oracle, hip_ctx):
     of.close()
     gf.close()
 
+
+
+@pytest.mark.parametrize("weighting", [0, 1])
+def test_split_pipeline_with_and_without_translation_weighting(oracle, hip_ctx, weighting):
+    """the Gauss-Newton kernel reads the translation weight from the parked operand row (1 when the weighting is off): both settings
+    against the checker, whole frame loop"""
+    cfg, fixed, dfix, mp, T, X0 = make_align_case("kitti", 61 + weighting, 800, 900)
+    scale = oracle.info_scale_from_nopt(mp["n_opt"])
+    md = oracle.mean_disparity(fixed)
+    of = oracle.ProjectiveFinder(pcf_params_from_cfg(oracle, cfg))
+    of.set_fixed(fixed, dfix)
+    of.set_moving(mp["xyz"], mp["desc"])
+    res, rcorr = oracle.align_frame(of, oracle_aligner_params(oracle, cfg, mean_disparity=md, enable_inverse_depth_weighting=weighting), fixed, mp["xyz"], scale, X0)
+    gf = ops.ProjectiveFinder(hip_ctx, ops.pcf_params(cfg))
+    gf.set_fixed(fixed, dfix)
+    gf.set_moving(mp["xyz"], mp["desc"], scale)
+    Xg, gcorr, _, _ = gf.align(ops.aligner_params(cfg, enable_inverse_depth_weighting=weighting), X0)
+    assert len(rcorr) > 100 and corr_equal(rcorr, gcorr)
+    assert np.array_equal(_bits(Xg), _bits(np.array(res.X, np.float32).reshape(4, 4)))
+    of.close()
+    gf.close()
