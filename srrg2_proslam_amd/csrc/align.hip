@@ -2562,9 +2562,13 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   const bool lone = fast && batch->batch <= 2 * (n_cu > 0 ? n_cu : 256) && !ctx->no_lone_gn;
   const bool five = fast && !lone && max_fixed > 4 * 128;  // (gn_kernel: LDS_SLOTS / WAVES)
   const bool plain = !batch->prior && !aligner->enable_motion_prior && !aligner->with_sensor && !aligner->enable_inlier_only_runs;  // (gn_kernel / gn_solve_wave: PLAIN)
+  // (the depth factor of the RGB-D configurations -- tum.conf / icl.conf: kept classes, inlier-only runs -- as a compile-time constant too)
+  const bool depth = aligner->factor_type == PRS_FACTOR_DEPTH && aligner->kernel_weight_form == PRS_KERNEL_WEIGHT_INV_CHI && aligner->damping_form == PRS_DAMPING_DIAG;
   auto gnk        = lone ? (max_fixed <= 4 * 128 ? gn_kernel<4, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1> : gn_kernel<8, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1>)
-                         : (max_fixed <= 4 * 128 ? (fast ? (plain ? gn_kernel<4, PRS_FACTOR_STEREO, false, kGnLdsSlots, 4, true> : gn_kernel<4, PRS_FACTOR_STEREO, false>) : gn_kernel<4, 0, true>)
-                                                 : (fast ? (plain ? gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5, true> : gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5>) : gn_kernel<8, 0, true>));
+                         : (max_fixed <= 4 * 128 ? (fast ? (plain ? gn_kernel<4, PRS_FACTOR_STEREO, false, kGnLdsSlots, 4, true> : gn_kernel<4, PRS_FACTOR_STEREO, false>)
+                                                         : (depth ? gn_kernel<4, PRS_FACTOR_DEPTH, true> : gn_kernel<4, 0, true>))
+                                                 : (fast ? (plain ? gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5, true> : gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5>)
+                                                         : (depth ? gn_kernel<8, PRS_FACTOR_DEPTH, true> : gn_kernel<8, 0, true>)));
   const size_t lds_gn = gn_lds_bytes(five ? 3 : kGnLdsSlots);
   // The job lives in the context until align_batch_finish: the rounds are plain launches on the context's stream (no host
   // synchronisation here, the sequence can be captured in a HIP graph once the scratch buffers exist).
