@@ -2564,7 +2564,8 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   const bool plain = !batch->prior && !aligner->enable_motion_prior && !aligner->with_sensor && !aligner->enable_inlier_only_runs;  // (gn_kernel / gn_solve_wave: PLAIN)
   // (the depth factor of the RGB-D configurations -- tum.conf / icl.conf: kept classes, inlier-only runs -- as a compile-time constant too)
   const bool depth = aligner->factor_type == PRS_FACTOR_DEPTH && aligner->kernel_weight_form == PRS_KERNEL_WEIGHT_INV_CHI && aligner->damping_form == PRS_DAMPING_DIAG;
-  auto gnk        = lone ? (max_fixed <= 4 * 128 ? gn_kernel<4, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1> : gn_kernel<8, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1>)
+  auto gnk        = lone ? (max_fixed <= 4 * 128 ? (plain ? gn_kernel<4, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1, true> : gn_kernel<4, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1>)
+                                                 : (plain ? gn_kernel<8, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1, true> : gn_kernel<8, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1>))
                          : (max_fixed <= 4 * 128 ? (fast ? (plain ? gn_kernel<4, PRS_FACTOR_STEREO, false, kGnLdsSlots, 4, true> : gn_kernel<4, PRS_FACTOR_STEREO, false>)
                                                          : (depth ? gn_kernel<4, PRS_FACTOR_DEPTH, true> : gn_kernel<4, 0, true>))
                                                  : (fast ? (plain ? gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5, true> : gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5>)
