@@ -1818,9 +1818,10 @@ __device__ __forceinline__ bool gn_advance(const prs_aligner_params& a, const in
 
 // The single-wave phase of a Gauss-Newton iteration once the 32 summed slots of the linearisation are in sh.H / b / chi / fcnt:
 // camera frame -> tangent space of X, class counts, (H + damping diag(H)) dx = -b, X <- X * exp(dx); `stid` = lane of the solving wave.
-// PLAIN: no additive prior, no motion-model prior, no sensor offset, no inlier-only runs (what align_batch_launch found in the
-// parameters): the branches and their registers are not part of that instantiation
-template <bool SHIPPED_FORMS = false, bool PLAIN = false>
+// PLAIN (what align_batch_launch found in the parameters): 1 = no additive prior, no motion-model prior, no sensor offset, no
+// inlier-only runs; 2 = the same with the motion-model prior on (the aligner of kitti.conf's tracker: its AlignerSliceMotionModel3D);
+// 0 = anything.  The branches a parameter set does not take, and their registers, are not part of its instantiation.
+template <bool SHIPPED_FORMS = false, int PLAIN = 0>
 __device__ __forceinline__ void gn_solve_wave(const AlignArgs& g, GnShared& sh, const int frame, const int nc, const int stid, const bool inlier_run) {
   const int lane = stid;
   if (sh.pose_ok) {  // (a pose that is not finite: all sums are zero and stay zero)
@@ -1880,7 +1881,7 @@ __device__ __forceinline__ void gn_solve_wave(const AlignArgs& g, GnShared& sh, 
     for (int i = 0; i < 6; ++i) {
       b[i] = sh.b[i];
     }
-    if (!PLAIN && g.b.prior) {
+    if (PLAIN == 0 && g.b.prior) {
       const float* pr = g.b.prior + (size_t) frame * 42;
 #pragma unroll
       for (int i = 0; i < 36; ++i) {
@@ -1891,7 +1892,7 @@ __device__ __forceinline__ void gn_solve_wave(const AlignArgs& g, GnShared& sh, 
         b[i] += pr[36 + i];
       }
     }
-    if (!PLAIN && g.a.enable_motion_prior) {
+    if (PLAIN == 2 || (PLAIN == 0 && g.a.enable_motion_prior)) {
       float X[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -1918,7 +1919,7 @@ __device__ __forceinline__ void gn_solve_wave(const AlignArgs& g, GnShared& sh, 
     const bool any_changed = (__ballot(changed != 0u) & 7ull) != 0ull;
     // points -> camera: X, or sensor_in_robot^-1 * X
     float4 an = xn;
-    if (!PLAIN && g.a.with_sensor) {
+    if (PLAIN == 0 && g.a.with_sensor) {
       const float4 sr = *reinterpret_cast<const float4*>(&sh.Sinv[4 * prow]);
       const float4 x0 = {bcast(xn.x, 0), bcast(xn.y, 0), bcast(xn.z, 0), bcast(xn.w, 0)};
       const float4 x1 = {bcast(xn.x, 1), bcast(xn.y, 1), bcast(xn.z, 1), bcast(xn.w, 1)};
@@ -1991,7 +1992,7 @@ constexpr int kGnLdsSlots = 4;
 constexpr size_t gn_lds_bytes(const int lds_slots) {
   return ((sizeof(GnShared) + 15) / 16) * 16 + (size_t) (lds_slots * 128 + 64) * 2 * sizeof(float4);  // shared state + parked operand rows
 }
-template <int SLOTS, int DIM, bool KEEP_CLS, int LDS_SLOTS = kGnLdsSlots, int WAVES = 4, bool PLAIN = false>
+template <int SLOTS, int DIM, bool KEEP_CLS, int LDS_SLOTS = kGnLdsSlots, int WAVES = 4, int PLAIN = 0>
 __global__ __launch_bounds__(128, WAVES) void gn_kernel(const AlignArgs g) {
   constexpr int THREADS = 128;
   constexpr int kGnLdsSlots = LDS_SLOTS;  // (shadow the defaults)
@@ -2090,7 +2091,7 @@ __global__ __launch_bounds__(128, WAVES) void gn_kernel(const AlignArgs g) {
   int it_align = ctl->it_align;
   int executed = ctl->executed;
   bool done    = false;
-  const int extra = PLAIN ? 0 : inlier_run_length(g.a);  // iterations of the inlier-only run after the max_iterations loop
+  const int extra = PLAIN != 0 ? 0 : inlier_run_length(g.a);  // iterations of the inlier-only run after the max_iterations loop
   uint32_t cls_bits = 0;                     // factor classes of this thread's correspondences in the last linearisation (2 bits each)
   bool have_cls     = false;                 // (block-uniform) the last executed iteration linearised
 
@@ -2117,7 +2118,7 @@ __global__ __launch_bounds__(128, WAVES) void gn_kernel(const AlignArgs g) {
       }
       __syncthreads();
     } else {
-      const bool inlier_run = !PLAIN && it_align >= g.a.max_iterations;  // (PLAIN: no inlier-only runs either, so never true)
+      const bool inlier_run = PLAIN == 0 && it_align >= g.a.max_iterations;  // (PLAIN: no inlier-only runs, so never true)
       have_cls              = true;
       cls_bits              = 0;
       const PoseRegs pose = {sh.A[0], sh.A[1], sh.A[2], sh.A[3], sh.A[4], sh.A[5], sh.A[6], sh.A[7], sh.A[8], sh.A[9], sh.A[10], sh.A[11]};
@@ -2561,14 +2562,16 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   (void) hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
   const bool lone = fast && batch->batch <= 2 * (n_cu > 0 ? n_cu : 256) && !ctx->no_lone_gn;
   const bool five = fast && !lone && max_fixed > 4 * 128;  // (gn_kernel: LDS_SLOTS / WAVES)
-  const bool plain = !batch->prior && !aligner->enable_motion_prior && !aligner->with_sensor && !aligner->enable_inlier_only_runs;  // (gn_kernel / gn_solve_wave: PLAIN)
+  const bool lean  = !batch->prior && !aligner->with_sensor && !aligner->enable_inlier_only_runs;
+  const bool plain = lean && !aligner->enable_motion_prior;   // (gn_kernel / gn_solve_wave: PLAIN = 1)
+  const bool mprior = lean && aligner->enable_motion_prior;   // (PLAIN = 2)
   // (the depth factor of the RGB-D configurations -- tum.conf / icl.conf: kept classes, inlier-only runs -- as a compile-time constant too)
   const bool depth = aligner->factor_type == PRS_FACTOR_DEPTH && aligner->kernel_weight_form == PRS_KERNEL_WEIGHT_INV_CHI && aligner->damping_form == PRS_DAMPING_DIAG;
-  auto gnk        = lone ? (max_fixed <= 4 * 128 ? (plain ? gn_kernel<4, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1, true> : gn_kernel<4, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1>)
-                                                 : (plain ? gn_kernel<8, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1, true> : gn_kernel<8, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1>))
-                         : (max_fixed <= 4 * 128 ? (fast ? (plain ? gn_kernel<4, PRS_FACTOR_STEREO, false, kGnLdsSlots, 4, true> : gn_kernel<4, PRS_FACTOR_STEREO, false>)
+  auto gnk        = lone ? (max_fixed <= 4 * 128 ? (plain ? gn_kernel<4, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1, 1> : gn_kernel<4, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1>)
+                                                 : (plain ? gn_kernel<8, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1, 1> : gn_kernel<8, PRS_FACTOR_STEREO, false, kGnLdsSlots, 1>))
+                         : (max_fixed <= 4 * 128 ? (fast ? (plain ? gn_kernel<4, PRS_FACTOR_STEREO, false, kGnLdsSlots, 4, 1> : (mprior ? gn_kernel<4, PRS_FACTOR_STEREO, false, kGnLdsSlots, 4, 2> : gn_kernel<4, PRS_FACTOR_STEREO, false>))
                                                          : (depth ? gn_kernel<4, PRS_FACTOR_DEPTH, true> : gn_kernel<4, 0, true>))
-                                                 : (fast ? (plain ? gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5, true> : gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5>)
+                                                 : (fast ? (plain ? gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5, 1> : (mprior ? gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5, 2> : gn_kernel<8, PRS_FACTOR_STEREO, false, 3, 5>))
                                                          : (depth ? gn_kernel<8, PRS_FACTOR_DEPTH, true> : gn_kernel<8, 0, true>)));
   const size_t lds_gn = gn_lds_bytes(five ? 3 : kGnLdsSlots);
   // The job lives in the context until align_batch_finish: the rounds are plain launches on the context's stream (no host
