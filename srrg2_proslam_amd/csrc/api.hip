@@ -120,10 +120,10 @@ unsigned long long* ctx_stamps(prs_context* ctx, size_t bytes) {
   return ctx->d_stamps;
 }
 
-void ctx_report_stamps(prs_context* ctx, int blocks, int n_stamps, const char* legend, bool raw) {
+void ctx_report_stamps(prs_context* ctx, int blocks, int n_stamps, const char* legend, bool raw, size_t first_block) {
   (void) hipStreamSynchronize(ctx->stream);
   std::vector<unsigned long long> h((size_t) blocks * 16);
-  (void) hipMemcpy(h.data(), ctx->d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  (void) hipMemcpy(h.data(), ctx->d_stamps + first_block * 16, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   fprintf(stderr, "[prs stamps] %s\n[prs stamps] mean cycles per phase over %d blocks:", legend, blocks);
   double total = 0;
   for (int i = 1; i < n_stamps; ++i) {

@@ -8,15 +8,17 @@
 // test images (tests/test_ref_pins_gpu.py).  The region grid and the per-region selection by response follow the
 // in-repo code line by line; PRS_SELECT_LIBSTDCXX reproduces the tie order of GNU std::sort there.
 //
-// Three launches per batch of images:
+// Four launches per batch of images:
 //   fast_blur_kernel   one 64x64 pixel tile per workgroup (tile + halo in LDS), four pixels per lane: compass
 //                      test on packed 16-bit lanes, survivors in dense per-wave lists, arc minima on dense
-//                      lanes, non-maximum suppression; suppressed FAST response map (u8) and the 7x7 Gaussian
-//                      (fixed point, what ORB samples) of the tile (u8).  VALU-bound (the image is read once)
-//   nms_compact_kernel one workgroup per image: ordered (raster) compaction of the suppressed response map
+//                      lanes, non-maximum suppression; the tile's suppressed detections are appended to the image's
+//                      list (one atomic per tile) and the 7x7 Gaussian (fixed point, what ORB samples) of the tile
+//                      (u8) is written.  VALU-bound (the image is read once, no response map leaves the CU)
+//   raster_order_kernel one workgroup per image: the appended detections sorted by pixel index = the order
+//                      cv::FAST reports them in (round 5; rounds 2-4 compacted a dense response map)
 //   select_describe_kernel one workgroup per image: region histogram, one bitonic sort of
-//                      (region, response, order) keys in LDS, per-region selection, border filter,
-//                      256 comparisons of smoothed pixels per kept keypoint
+//                      (region, response, order) keys in LDS (or the replay of std::sort), per-region selection, border filter
+//   describe_kernel    one wave per sixteen kept keypoints: 256 comparisons of smoothed pixels per keypoint
 #include "prs_device.h"
 #include "prs_host.h"
 
@@ -29,26 +31,35 @@ constexpr int kDefaultRaw = 8192;       // raw detections per image the selectio
 constexpr int kMaxRawLimit = 32768;     // ... at most (prs_extractor_params.max_raw_detections; 128 KB of LDS keys)
 constexpr int kFeatureBorder = 31;      // cv::ORB edgeThreshold: keypoints closer to the border are removed (runByImageBorder)
 constexpr int kMaxRegions = 256;
-constexpr int kMaxCells = 512;          // 256 pairs name at most 512 distinct cells; 8 x 64 lanes
+constexpr int kSelScratch = 512;        // 16-bit words of LDS scratch per wave of the selection kernel
+constexpr int kWinRadius = 13, kWinWords = 8;  // bit_pattern_31_ stays within +-13 px: 27 rows (32 are fetched) of 8 aligned words
+constexpr int kDescThreads = 256, kDescPerWave = 16;  // describe_kernel: four waves, sixteen keypoints each
 // cv::GaussianBlur(7x7, sigma 2) on 8-bit data: round(256 * exp(-x^2 / 8) / sum), sum of the taps = 257
 constexpr uint32_t kG0 = 18, kG1 = 34, kG2 = 49, kG3 = 55;
 
 struct FeatureArgs {
   prs_extractor_params p;
   prs_extract_batch b;
-  uint8_t* score;     // [batch][rows][cols]
-  uint8_t* blur;      // [batch][rows][cols] smoothed image (defined 3 px inside the border; ORB reads >= 18 px inside)
-  uint32_t* raw;      // [batch][max_raw] response << 24 | pixel index, raster order
-  int32_t* n_raw;     // [batch]
+  // smoothed image (defined 3 px inside the border; ORB reads >= 18 px inside) in 128-byte blocks of 16 columns x 8 rows: the
+  // 27 x 28 window of a keypoint touches ~12 cache lines instead of ~33 rows of a row-major image (the describe pass is bound by
+  // the lines it pulls from L2).  Pixel (y, x) of image i: blur + i * blur_stride + blur_offset(y, x, blur_ncb)
+  uint8_t* blur;
+  int blur_ncb;        // blocks per block row = ceil(cols / 16)
+  size_t blur_stride;  // bytes per image
+  uint32_t* raw;      // [batch][max_raw] response << 24 | pixel index; appended tile by tile, then put in raster order
+  int32_t* n_raw;     // [batch] zeroed before the tile kernel; -1 after raster_order_kernel = more than max_raw
   int max_raw;        // capacity of `raw` and of the selection sort (power of two)
-  // the descriptor's pair table as the distinct smoothed pixels it reads (row-major) and, per comparison, the positions
-  // of its two cells in that list (fill_window_cells)
-  int8_t cell_dy[kMaxCells], cell_dx[kMaxCells];
+  unsigned long long* stamps;  // PRS_STAMPS=1: phase clocks of thread 0 of select_describe_kernel, 16 words per image (diagnostic)
+  uint32_t* kept;     // [batch][stride] pixel index of every selected keypoint, in output order (select -> describe)
+  // the descriptor's pair table as byte offsets into the 27 x 28 window of smoothed pixels around a keypoint (fill_window_offsets)
   uint16_t pair_first[256], pair_second[256];
-  int n_cells;
   float rows_per, cols_per;
   int target_per, regions;
 };
+
+__device__ __forceinline__ uint32_t blur_offset(const int y, const int x, const int ncb) {
+  return (uint32_t) (((y >> 3) * ncb + (x >> 4)) * 128 + (y & 7) * 16 + (x & 15));
+}
 
 // ---- word-parallel helpers: four pixels per 32-bit LDS word, two 16-bit lanes per VALU operation ----
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -70,6 +81,13 @@ __device__ __forceinline__ uint32_t pk_sign_fill(uint32_t a) {  // per lane 0xff
 }
 __device__ __forceinline__ uint32_t bytes_even(uint32_t x) { return x & 0x00ff00ffu; }                          // bytes 0, 2 -> lanes
 __device__ __forceinline__ uint32_t bytes_odd(uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0c030c01u); }  // bytes 1, 3 -> lanes
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t w) {  // bit j <=> byte j of the word is non-zero
+  return ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u) | ((w & 0xff0000u) ? 4u : 0u) | ((w & 0xff000000u) ? 8u : 0u);
+}
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // LDS written by one lane is read by other lanes of the wave
+  __builtin_amdgcn_wave_barrier();
+}
 __device__ __forceinline__ int lanes_below(uint64_t m, int base) {  // base + number of set bits of m below this lane
   return (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, (uint32_t) base));
 }
@@ -115,6 +133,21 @@ __device__ __forceinline__ int arc_best(const uint8_t* c, bool dark) {
   return best;
 }
 
+// the response of one survivor that found its list full, scored by its own lane: bright first, dark only if bright failed.
+// Out of line: the compass pass has twenty places where a list can overflow, and it never does on an image (inlined, these
+// copies made the tile kernel 139 KB of code for a 64 KB instruction cache)
+__device__ __attribute__((noinline)) void score_overflowed(const uint8_t* tile8, uint8_t* resp8, const uint32_t entry, const int t) {
+  constexpr uint32_t kBright = 0x4000u, kDark = 0x8000u;
+  const int id = (int) (entry & 0x1fffu);
+  int best     = (entry & kBright) ? arc_best(tile8 + id, false) : arc_best(tile8 + id, true);
+  if (best <= t && (entry & (kBright | kDark)) == (kBright | kDark)) {
+    best = arc_best(tile8 + id, true);
+  }
+  if (best > t) {
+    resp8[id] = (uint8_t) (best - 1);
+  }
+}
+
 // image tile (+ 4-px halo) in LDS -> compass test on four pixels per lane -> survivors (dense lists, one per wave) ->
 // arc minima on dense lanes -> responses of the tile and its 1-px ring -> non-maximum suppression, four pixels per
 // lane; the separable 7x7 Gaussian of the tile on the side (packed 16-bit horizontal pass, 32-bit vertical pass).
@@ -129,6 +162,12 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
   const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(tile32);
   uint8_t* resp8       = reinterpret_cast<uint8_t*>(resp32);
   constexpr int kWordsAll = kTileRows * kTileWords;  // 1296
+  auto stamp = [&](const int i) {  // PRS_STAMPS=1: one interior tile of every image
+    if (a.stamps && tid == 0 && blockIdx.x == 5 && blockIdx.y == 2) {
+      a.stamps[((size_t) a.b.batch + img) * 16 + i] = (unsigned long long) clock64();
+    }
+  };
+  stamp(0);
   // ---- tile + halo: all loads of a lane in flight before the first LDS store ----
   {
     uint32_t w[6];
@@ -167,6 +206,7 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
     }
   }
   __syncthreads();
+  stamp(1);
   const int t       = a.p.detector_threshold;  // 1 .. 254 (checked by the host)
   const uint32_t T2 = (uint32_t) t * 0x00010001u;
   const int w1 = tid & 15, r0 = tid >> 4;
@@ -176,17 +216,6 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
   // the two ring columns follow pixel by pixel.  Entry = tile byte offset | polarity flags.
   int n_mine         = 0;  // wave-uniform
   uint16_t* my_list  = list[wave];
-  // the response of one survivor, scored by its own lane (list overflow): bright first, dark only if bright failed
-  auto score_now = [&](const uint32_t entry) {
-    const int id = (int) (entry & kIdMask);
-    int best     = (entry & kBrightFlag) ? arc_best(tile8 + id, false) : arc_best(tile8 + id, true);
-    if (best <= t && (entry & (kBrightFlag | kDarkFlag)) == (kBrightFlag | kDarkFlag)) {
-      best = arc_best(tile8 + id, true);
-    }
-    if (best > t) {
-      resp8[id] = (uint8_t) (best - 1);
-    }
-  };
   auto push = [&](uint32_t entry, bool ok) {
     const uint64_t m = __ballot(ok);
     if (ok) {
@@ -194,7 +223,7 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
       if (pos < kListCap) {
         my_list[pos] = (uint16_t) entry;
       } else {
-        score_now(entry);
+        score_overflowed(tile8, resp8, entry, t);
       }
     }
     n_mine += __popcll(m);
@@ -261,6 +290,7 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
     list_n[wave] = n_mine < kListCap ? n_mine : kListCap;
   }
   __syncthreads();
+  stamp(2);
   // ---- arc minima on dense lanes: entry j of the concatenated lists ----
   const int c0 = list_n[0], c1 = c0 + list_n[1], c2 = c1 + list_n[2], total = c2 + list_n[3];
   int n_second          = 0;  // wave-uniform
@@ -288,10 +318,7 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
       if (pos < kSecondCap) {
         my_second[pos] = (uint16_t) again_id;
       } else {  // list full: the lane looks at the dark arcs itself
-        const int best = arc_best(tile8 + again_id, true);
-        if (best > t) {
-          resp8[again_id] = (uint8_t) (best - 1);
-        }
+        score_overflowed(tile8, resp8, (uint32_t) again_id | kDarkFlag, t);
       }
     }
     n_second += __popcll(m);
@@ -308,6 +335,10 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
     }
   }
   __syncthreads();  // the lists are dead: their bytes hold the horizontal sums from here on
+  stamp(3);
+  if (tid == 0) {
+    list_n[0] = 0;  // ... and the first counter counts the tile's detections (two barriers before its first use)
+  }
   // ---- 7x7 Gaussian, horizontal pass: tile rows -3 .. kTileH+2, four sums per lane, stored as packed 16-bit lanes:
   // 55 c + 49 (l1 + r1) + 34 (l2 + r2) + 18 (l3 + r3) <= 257 * 255 = 65535 fits the lane exactly.
 #pragma unroll
@@ -327,8 +358,9 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
     }
   }
   __syncthreads();
+  stamp(4);
   // ---- Gaussian, vertical pass, straight to memory: (sum + 2^15) >> 16, saturated (the taps sum to 257 / 256) ----
-  uint8_t* __restrict__ blur = a.blur + (size_t) img * rows * cols;
+  uint8_t* __restrict__ blur = a.blur + (size_t) img * a.blur_stride;
 #pragma unroll
   for (int k = 0; k < kTileH / 16; ++k) {
     const int ly = r0 + 16 * k, gy = y0 + ly, gx = x0 + 4 * w1;
@@ -355,21 +387,18 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
       acc[3] += taps[6] * (od >> 16);
     }
     const uint32_t out = min(acc[0] >> 16, 255u) | (min(acc[1] >> 16, 255u) << 8) | (min(acc[2] >> 16, 255u) << 16) | (min(acc[3] >> 16, 255u) << 24);
-    if (!BORDER) {
-      __builtin_memcpy(blur + (size_t) gy * cols + gx, &out, 4);
-    } else if (gy < rows) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (gx + j < cols) {
-          blur[(size_t) gy * cols + gx + j] = (uint8_t) (out >> (8 * j));
-        }
-      }
+    if (!BORDER || (gy < rows && gx < 16 * a.blur_ncb)) {  // (the padding columns of the last block take whatever the word holds)
+      *reinterpret_cast<uint32_t*>(blur + blur_offset(gy, gx, a.blur_ncb)) = out;
     }
   }
   __syncthreads();
-  // ---- non-maximum suppression (strictly greater than the 8 neighbours) and the response map, four pixels per lane.
-  // A non-zero response never sits on the outermost 3 pixels, so the ring values are real responses of real pixels.
-  uint8_t* __restrict__ score = a.score + (size_t) img * rows * cols;
+  stamp(5);
+  // ---- non-maximum suppression (strictly greater than the 8 neighbours), four pixels per lane.
+  // A non-zero response never sits on the outermost 3 pixels, so the ring values are real responses of real pixels, and
+  // every non-zero byte of the tile proper is a pixel of the image.  Survivors (a few dozen per tile) go to a list of
+  // the workgroup (in the bytes of the horizontal sums, dead since the last barrier) in no particular order; the
+  // tile reserves its span of the image's list with ONE atomic and copies the list there.  raster_order_kernel sorts.
+  uint32_t* tile_raw = reinterpret_cast<uint32_t*>(hsum64);  // at most 32 x 32 survivors of a 64 x 64 tile
   const bool nms = a.p.enable_non_maximum_suppression != 0;
 #pragma unroll
   for (int k = 0; k < kTileH / 16; ++k) {
@@ -400,14 +429,47 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
       kept[1] = Om & pk_sign_fill(pk_sub(around_odd, Om));
       out = kept[0] | (kept[1] << 8);
     }
-    if (!BORDER) {
-      __builtin_memcpy(score + (size_t) gy * cols + gx, &out, 4);
-    } else if (gy < rows) {
+    if (out != 0u) {  // rare: a tile of a KITTI image keeps ~25 of its 4096 pixels
+      const int present   = __popc(nonzero_bytes(out));
+      const uint32_t pix0 = (uint32_t) gy * (uint32_t) cols + (uint32_t) gx;
+      if (nms) {
+        int pos = atomicAdd(&list_n[0], present);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (gx + j < cols) {
-          score[(size_t) gy * cols + gx + j] = (uint8_t) (out >> (8 * j));
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t sj = (out >> (8 * j)) & 0xffu;
+          if (sj) {
+            tile_raw[pos++] = (sj << 24) | (pix0 + (uint32_t) j);
+          }
         }
+      } else {  // without suppression a tile may hold up to 4096 detections: every lane appends its own
+        int pos = atomicAdd(a.n_raw + img, present);
+        uint32_t* __restrict__ raw = a.raw + (size_t) img * a.max_raw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t sj = (out >> (8 * j)) & 0xffu;
+          if (sj) {
+            if (pos < a.max_raw) {
+              raw[pos] = (sj << 24) | (pix0 + (uint32_t) j);
+            }
+            ++pos;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  stamp(6);
+  const int n_tile = list_n[0];  // (uniform; stays 0 without suppression)
+  if (n_tile > 0) {
+    if (tid == 0) {
+      list_n[1] = atomicAdd(a.n_raw + img, n_tile);
+    }
+    __syncthreads();
+    const int base = list_n[1];
+    uint32_t* __restrict__ raw = a.raw + (size_t) img * a.max_raw;
+    for (int i = tid; i < n_tile; i += kFastThreads) {
+      if (base + i < a.max_raw) {  // beyond: the image fails with PRS_ERR_CAPACITY (raster_order_kernel sees the count)
+        raw[base + i] = tile_raw[i];
       }
     }
   }
@@ -433,118 +495,72 @@ __global__ __launch_bounds__(kFastThreads, 8) void fast_blur_kernel(const Featur
   }
 }
 
-// raster-order compaction of the (already suppressed) response map.
-// Every wave owns a contiguous range of the image; it counts its survivors, the 16 counts are scanned once,
-// then the wave rescans its range (response map still in L2) and writes at its offset: two barriers per image.
-// A lane takes 16 pixels per load, four loads in flight; survivors are the non-zero bytes.
-typedef uint32_t px16 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t w) {  // bit j <=> byte j of the word is non-zero
-  return ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u) | ((w & 0xff0000u) ? 4u : 0u) | ((w & 0xff000000u) ? 8u : 0u);
-}
-
-__global__ __launch_bounds__(kNmsThreads) void nms_compact_kernel(const FeatureArgs a) {
-  __shared__ int wave_tot[kNmsThreads / 64];
-  constexpr int kPerLane = 16, kChunk = 64 * kPerLane, kInFlight = 4;
-  const int rows = a.b.rows, cols = a.b.cols;
-  const int img  = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint8_t* __restrict__ score = a.score + (size_t) img * rows * cols;
-  uint32_t* __restrict__ raw        = a.raw + (size_t) img * a.max_raw;
-  const int n_pix = rows * cols;
-  const int n_chunks = (n_pix + kChunk - 1) / kChunk;
-  const int per_wave = (n_chunks + kNmsThreads / 64 - 1) / (kNmsThreads / 64);
-  const int c_begin = wave * per_wave, c_end = min(c_begin + per_wave, n_chunks);
-  auto load16 = [&](int ch) -> px16 {
-    px16 r     = {0u, 0u, 0u, 0u};
-    const int i = ch * kChunk + kPerLane * lane;
-    if (ch < c_end && i < n_pix) {
-      if (i + kPerLane <= n_pix) {
-        __builtin_memcpy(&r, score + i, kPerLane);  // any alignment
-      } else {  // the last pixels of the image
-        uint32_t w[4] = {0u, 0u, 0u, 0u};
-        for (int j = 0; i + j < n_pix; ++j) {
-          w[j >> 2] |= (uint32_t) score[i + j] << (8 * (j & 3));
-        }
-        r = px16{w[0], w[1], w[2], w[3]};
-      }
+// The detections of an image in the order cv::FAST reports them (row by row): the tiles appended theirs in the order
+// they finished.  Pixel indices are distinct, so raster order is a bucket sort: 1024 equal spans of the image (a monotone
+// function of the pixel index), one counting pass, one scan (a bucket per thread), a scatter into the buckets (LDS) and,
+// per entry, its rank among the handful of entries of its bucket.  One workgroup per image, three barriers; an image with
+// more than max_raw detections is marked (-1) and fails in select_describe_kernel.
+constexpr int kRasterBuckets = kNmsThreads;
+__global__ __launch_bounds__(kNmsThreads) void raster_order_kernel(const FeatureArgs a, const int bucket_shift) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t staged[];  // [max_raw] entries grouped by bucket
+  __shared__ uint32_t count[kRasterBuckets], first[kRasterBuckets], fill[kRasterBuckets];
+  __shared__ uint32_t wave_tot[kNmsThreads / 64];
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t* __restrict__ raw = a.raw + (size_t) img * a.max_raw;
+  const int n = a.n_raw[img];
+  if (n > a.max_raw) {
+    if (tid == 0) {
+      a.n_raw[img] = -1;
     }
-    return r;
-  };
-  int mine = 0;
-  for (int ch = c_begin; ch < c_end; ch += kInFlight) {
-    px16 px[kInFlight];
-#pragma unroll
-    for (int u = 0; u < kInFlight; ++u) {
-      px[u] = load16(ch + u);
-    }
-#pragma unroll
-    for (int u = 0; u < kInFlight; ++u) {
-      if (px[u].x | px[u].y | px[u].z | px[u].w) {
-        mine += __popc(nonzero_bytes(px[u].x) | (nonzero_bytes(px[u].y) << 4) | (nonzero_bytes(px[u].z) << 8) | (nonzero_bytes(px[u].w) << 12));
-      }
-    }
+    return;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    mine += __shfl_xor(mine, o, 64);
+  if (n <= 1) {
+    return;
   }
-  if (lane == 0) {
-    wave_tot[wave] = mine;
+  count[tid] = 0;
+  fill[tid]  = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += kNmsThreads) {
+    atomicAdd(&count[(raw[i] & 0xffffffu) >> bucket_shift], 1u);
   }
   __syncthreads();
-  int offset = 0, total = 0;
+  {  // exclusive scan of the bucket sizes, one bucket per thread
+    const uint32_t c = count[tid];
+    uint32_t incl    = c;
 #pragma unroll
-  for (int w = 0; w < kNmsThreads / 64; ++w) {
-    offset += w < wave ? wave_tot[w] : 0;
-    total += wave_tot[w];
-  }
-  if (total <= a.max_raw) {
-    for (int ch0 = c_begin; ch0 < c_end; ch0 += kInFlight) {
-      px16 px[kInFlight];
-#pragma unroll
-      for (int u = 0; u < kInFlight; ++u) {
-        px[u] = load16(ch0 + u);
-      }
-#pragma unroll
-      for (int u = 0; u < kInFlight; ++u) {
-        const int i          = (ch0 + u) * kChunk + kPerLane * lane;
-        const uint32_t wd[4] = {px[u].x, px[u].y, px[u].z, px[u].w};
-        const bool any       = (wd[0] | wd[1] | wd[2] | wd[3]) != 0u;
-        if (__ballot(any) == 0ull) {
-          continue;  // nothing in these 1024 pixels (wave-uniform)
-        }
-        const uint32_t keep = any ? nonzero_bytes(wd[0]) | (nonzero_bytes(wd[1]) << 4) | (nonzero_bytes(wd[2]) << 8) | (nonzero_bytes(wd[3]) << 12) : 0u;
-        const int cnt = __popc(keep);
-        int incl      = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int v = __shfl_up(incl, o, 64);
-          if (lane >= o) {
-            incl += v;
-          }
-        }
-        int slot = offset + incl - cnt;
-        if (any) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {  // raster order within the lane's 16 pixels
-            if (wd[q]) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const uint32_t s = (wd[q] >> (8 * j)) & 0xffu;
-                if (s) {
-                  raw[slot++] = (s << 24) | (uint32_t) (i + 4 * q + j);
-                }
-              }
-            }
-          }
-        }
-        offset += __shfl(incl, 63, 64);
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = (uint32_t) __shfl_up((int) incl, o, 64);
+      if (lane >= o) {
+        incl += v;
       }
     }
+    if (lane == 63) {
+      wave_tot[wave] = incl;
+    }
+    __syncthreads();
+    uint32_t before = 0;
+#pragma unroll
+    for (int w = 0; w < kNmsThreads / 64; ++w) {
+      before += w < wave ? wave_tot[w] : 0u;
+    }
+    first[tid] = before + incl - c;
   }
-  if (tid == 0) {
-    a.n_raw[img] = total > a.max_raw ? -1 : total;
+  __syncthreads();
+  for (int i = tid; i < n; i += kNmsThreads) {
+    const uint32_t e = raw[i];
+    const uint32_t b = (e & 0xffffffu) >> bucket_shift;
+    staged[first[b] + atomicAdd(&fill[b], 1u)] = e;
+  }
+  __syncthreads();  // (every entry of `raw` has been read: the sorted entries go back to the same place)
+  for (int i = tid; i < n; i += kNmsThreads) {
+    const uint32_t e = staged[i], pix = e & 0xffffffu;
+    const uint32_t b = pix >> bucket_shift;
+    const uint32_t f = first[b], c = count[b];
+    uint32_t rank    = 0;
+    for (uint32_t j = 0; j < c; ++j) {
+      rank += (staged[f + j] & 0xffffffu) < pix ? 1u : 0u;
+    }
+    raw[f + rank] = e;
   }
 }
 
@@ -594,11 +610,6 @@ __device__ void std_heapsort(uint32_t* first, int len) {  // __partial_sort(firs
     first[last]          = first[0];
     std_adjust_heap(first, 0, last, value);
   }
-}
-
-__device__ __forceinline__ void wave_sync_lds() {
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // LDS written by one lane is read by other lanes of the wave
-  __builtin_amdgcn_wave_barrier();
 }
 
 // __unguarded_partition_pivot on [first, last) (more than 16 items) by ONE WAVE, same permutation and same cut as the serial
@@ -944,15 +955,19 @@ __global__ __launch_bounds__(kSelThreads, 8) void select_describe_kernel(const F
   __shared__ uint32_t start[kMaxRegions + 1];
   __shared__ int wave_tot[kSelThreads / 64];
   __shared__ SortQueue sortq;
-  __shared__ uint16_t patch[(kSelThreads / 64) * kMaxCells];  // per wave: the smoothed pixels the pair table reads around the keypoint being described
+  __shared__ uint16_t patch[(kSelThreads / 64) * kSelScratch];  // scratch: per-wave region counts (scatter), partition lists and stack (sort)
   const int rows = a.b.rows, cols = a.b.cols;
   const int img  = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t* __restrict__ raw = a.raw + (size_t) img * a.max_raw;
-  const uint8_t* __restrict__ blur = a.blur + (size_t) img * rows * cols;
-  const uint8_t* __restrict__ src  = a.b.images + (size_t) img * rows * a.b.pitch;
   const bool std_order = a.p.selection_order == PRS_SELECT_LIBSTDCXX;
   const int n = a.n_raw[img];
+  auto stamp = [&](const int i) {
+    if (a.stamps && tid == 0) {
+      a.stamps[(size_t) img * 16 + i] = (unsigned long long) clock64();
+    }
+  };
+  stamp(0);
   if (n < 0) {  // more raw detections than the selection can hold: loud per-image error
     if (tid == 0) {
       a.b.n_features[img] = 0;
@@ -977,7 +992,7 @@ __global__ __launch_bounds__(kSelThreads, 8) void select_describe_kernel(const F
     // ---- libstdc++ order: every region's std::vector before its std::sort = its keypoints in detection order.  A stable
     //      scatter by region: every wave owns a contiguous span of the detections, counts its share of every region, the counts
     //      become offsets (regions x waves), and the wave writes its items behind those of the waves before it.
-    uint32_t* wcnt      = reinterpret_cast<uint32_t*>(patch) + wave * kMaxRegions;  // (the descriptor phase's staging area is not in use yet)
+    uint32_t* wcnt      = reinterpret_cast<uint32_t*>(patch) + wave * kMaxRegions;
     const int span      = (((n + kSelThreads / 64 - 1) / (kSelThreads / 64)) + 63) & ~63;
     const int span_from = wave * span;
     const int span_to   = span_from + span < n ? span_from + span : n;
@@ -1090,6 +1105,7 @@ __global__ __launch_bounds__(kSelThreads, 8) void select_describe_kernel(const F
       }
     }
   }
+  stamp(1);
   if (std_order) {  // the waves of the workgroup replay the reference's std::sort of every region that is sorted at all
     if (tid == 0) {
       sortq.lock = sortq.top = sortq.remaining = sortq.failed = 0;
@@ -1100,7 +1116,7 @@ __global__ __launch_bounds__(kSelThreads, 8) void select_describe_kernel(const F
       }
     }
     __syncthreads();
-    std_sort_worker(keys, sortq, lane, reinterpret_cast<int*>(patch + wave * kMaxCells));  // (the descriptor phase's staging area is not in use yet)
+    std_sort_worker(keys, sortq, lane, reinterpret_cast<int*>(patch + wave * kSelScratch));
     __syncthreads();
     if (sortq.failed) {  // a wave gave up waiting (std_sort_worker): loud per-image error
       if (tid == 0) {
@@ -1110,10 +1126,9 @@ __global__ __launch_bounds__(kSelThreads, 8) void select_describe_kernel(const F
       return;
     }
   }
+  stamp(2);
   // ---- selection + border filter + ordered output slots, 1024 sorted positions at a time ------------------------
-  prs_kp2* __restrict__ out_kp   = a.b.keypoints + (size_t) img * a.b.stride;
-  float* __restrict__ out_int    = a.b.intensity ? a.b.intensity + (size_t) img * a.b.stride : nullptr;
-  uint8_t* __restrict__ out_desc = a.b.descriptors + (size_t) img * a.b.stride * PRS_DESC_BYTES;
+  uint32_t* __restrict__ kept = a.kept + (size_t) img * a.b.stride;
   int running   = 0;
   bool overflow = false;
   for (int p0 = 0; p0 < n; p0 += kSelThreads) {
@@ -1141,11 +1156,10 @@ __global__ __launch_bounds__(kSelThreads, 8) void select_describe_kernel(const F
       before += w < wave ? wave_tot[w] : 0;
       total += wave_tot[w];
     }
-    __syncthreads();  // keys[p0 ..] have been read: the front of the array is reused for the kept list
     if (keep) {
       const int slot = running + before + __popcll(bal & ((1ull << lane) - 1ull));
       if (slot < a.b.stride) {
-        keys[slot] = pix;  // slot <= p: never overtakes the sorted positions still to be read
+        kept[slot] = pix;
       } else {
         overflow = true;
       }
@@ -1153,65 +1167,10 @@ __global__ __launch_bounds__(kSelThreads, 8) void select_describe_kernel(const F
     running += total;
     __syncthreads();
   }
-  const int n_kept = running < a.b.stride ? running : a.b.stride;
-  // ---- descriptors (cv::ORB on provided keypoints: no orientation, unrotated pattern): one wave per keypoint.  The
-  //      smoothed pixels the pair table names are staged in LDS, then every lane evaluates four comparisons and a
-  //      ballot IS eight bytes of the descriptor: bit t lands in byte t / 8, bit t % 8
-  {
-    // Only the distinct cells of the pair table are fetched: the phase scales with the bytes it pulls through the
-    // vector memory path.  Cell e = lane + 64 u.
-    constexpr int kCellLoads = kMaxCells / 64;
-    int o1[4], o2[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      o1[j] = a.pair_first[64 * j + lane];
-      o2[j] = a.pair_second[64 * j + lane];
-    }
-    int cell_off[kCellLoads];
-#pragma unroll
-    for (int u = 0; u < kCellLoads; ++u) {
-      const int e = min(lane + 64 * u, a.n_cells - 1);
-      cell_off[u] = (int) a.cell_dy[e] * cols + (int) a.cell_dx[e];
-    }
-    const int n_loads = (a.n_cells + 63) >> 6;  // (uniform)
-    uint16_t* win = patch + wave * kMaxCells;
-    for (int slot = wave; slot < n_kept; slot += kSelThreads / 64) {
-      const uint32_t pix = keys[slot];
-      const int r = (int) (pix / (uint32_t) cols), c = (int) (pix - (uint32_t) r * (uint32_t) cols);
-      const uint8_t* __restrict__ centre = blur + (size_t) r * cols + c;
-      uint16_t v[kCellLoads];  // all loads are issued before the first one is consumed
-#pragma unroll
-      for (int u = 0; u < kCellLoads; ++u) {
-        v[u] = u < n_loads ? centre[cell_off[u]] : (uint16_t) 0;
-      }
-#pragma unroll
-      for (int u = 0; u < kCellLoads; ++u) {
-        if (u < n_loads) {
-          win[lane + 64 * u] = v[u];
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      unsigned long long bits[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        bits[j] = __ballot(win[o1[j]] < win[o2[j]]);
-      }
-      if (lane < 4) {
-        unsigned long long* d = reinterpret_cast<unsigned long long*>(out_desc + (size_t) slot * PRS_DESC_BYTES);
-        d[lane]               = lane == 0 ? bits[0] : (lane == 1 ? bits[1] : (lane == 2 ? bits[2] : bits[3]));
-      }
-      if (lane == 4) {
-        out_kp[slot] = prs_kp2{(float) c, (float) r};
-        if (out_int) {
-          out_int[slot] = (float) src[(size_t) r * a.b.pitch + c];  // intensity_feature_extractor_base.cpp:80
-        }
-      }
-      __builtin_amdgcn_wave_barrier();  // the window is rewritten for the wave's next keypoint
-    }
-  }
-  if (__syncthreads_or(overflow ? 1 : 0)) {
+  stamp(3);
+  const int any_overflow = __syncthreads_or(overflow ? 1 : 0);
+  stamp(4);
+  if (any_overflow) {
     if (tid == 0) {
       a.b.n_features[img] = 0;
       a.b.status[img]     = PRS_ERR_CAPACITY;
@@ -1224,33 +1183,108 @@ __global__ __launch_bounds__(kSelThreads, 8) void select_describe_kernel(const F
   }
 }
 
+// ---- descriptors (cv::ORB on provided keypoints: no orientation, unrotated pattern): one wave per keypoint, sixteen
+//      keypoints per wave.  The smoothed pixels around the keypoint (27 rows, 32 bytes from the word that holds column
+//      c - 13) come in as 216 aligned words = four loads per lane out of ~12 cache lines of the blocked image; the loads of
+//      the next keypoint are in flight while this one is compared; the window sits in LDS, every lane evaluates four
+//      comparisons and a ballot IS eight bytes of the descriptor: bit t lands in byte t / 8, bit t % 8.
+//      (Rounds 2-4 described inside the selection kernel, one byte load per distinct cell of the pair table from a row-major
+//      image: ~33 cache lines per keypoint.)
+__global__ __launch_bounds__(kDescThreads) void describe_kernel(const FeatureArgs a, const int chunks) {
+  __shared__ uint32_t window[kDescThreads / 64][2][4 * 64];
+  const int cols = a.b.cols;
+  // consecutive workgroups go to consecutive XCDs (eight L2s): the chunks of one image stay on one of them
+  const int group  = (int) blockIdx.x >> 3;
+  const int img    = (group / chunks) * 8 + ((int) blockIdx.x & 7), chunk = group % chunks;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (img >= a.b.batch) {
+    return;
+  }
+  const int n_kept = min(a.b.n_features[img], a.b.stride);  // (0 for an image that failed)
+  const int s0     = (chunk * (kDescThreads / 64) + wave) * kDescPerWave;
+  if (s0 >= n_kept) {
+    return;
+  }
+  const int cnt = min(kDescPerWave, n_kept - s0);
+  const uint8_t* __restrict__ blur = a.blur + (size_t) img * a.blur_stride;
+  const uint8_t* __restrict__ src  = a.b.images + (size_t) img * a.b.rows * a.b.pitch;
+  prs_kp2* __restrict__ out_kp     = a.b.keypoints + (size_t) img * a.b.stride;
+  float* __restrict__ out_int      = a.b.intensity ? a.b.intensity + (size_t) img * a.b.stride : nullptr;
+  uint8_t* __restrict__ out_desc   = a.b.descriptors + (size_t) img * a.b.stride * PRS_DESC_BYTES;
+  const uint32_t my_pix = a.kept[(size_t) img * a.b.stride + s0 + min(lane, cnt - 1)];
+  const int my_r = (int) (my_pix / (uint32_t) cols), my_c = (int) (my_pix - (uint32_t) my_r * (uint32_t) cols);
+  if (lane < cnt) {  // keypoint and intensity of the wave's sixteen slots at once
+    out_kp[s0 + lane] = prs_kp2{(float) my_c, (float) my_r};
+    if (out_int) {
+      out_int[s0 + lane] = (float) src[(size_t) my_r * a.b.pitch + my_c];  // intensity_feature_extractor_base.cpp:80
+    }
+  }
+  int o1[4], o2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    o1[j] = a.pair_first[64 * j + lane];
+    o2[j] = a.pair_second[64 * j + lane];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    asm volatile("" : "+v"(o1[j]), "+v"(o2[j]));  // the offsets have arrived before the loop (its waits then only count the loop's own loads)
+  }
+  const int ncb = a.blur_ncb, block_row = 128 * ncb;
+  // word e = lane + 64 u of the window: row e / 8 (rows 27 .. 31 ride along: they are inside the image too), bytes 4 (e % 8) .. + 3
+  // from the aligned column; eight rows further down is the next row of blocks
+  auto fetch = [&](const int i, uint32_t (&v)[4]) {
+    const int r = __builtin_amdgcn_readlane(my_r, i), c = __builtin_amdgcn_readlane(my_c, i);
+    const uint32_t off = blur_offset(r - kWinRadius + (lane >> 3), ((c - kWinRadius) & ~3) + 4 * (lane & 7), ncb);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u] = *reinterpret_cast<const uint32_t*>(blur + (off + (uint32_t) (u * block_row)));  // a kept keypoint is >= 31 px inside the image
+    }
+  };
+  // dword k of the descriptor = half (k & 1) of the ballot of comparisons 64 (k >> 1) ..: lane k stores it
+  uint32_t* my_word = reinterpret_cast<uint32_t*>(out_desc + (size_t) s0 * PRS_DESC_BYTES) + (lane & 7);
+  auto describe = [&](const int i, const uint32_t (&v)[4], uint32_t* win) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      win[lane + 64 * u] = v[u];
+    }
+    wave_sync_lds();
+    const int c = __builtin_amdgcn_readlane(my_c, i);
+    const uint8_t* win8 = reinterpret_cast<const uint8_t*>(win) + ((c - kWinRadius) & 3);
+    uint32_t word = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned long long bits = __ballot(win8[o1[j]] < win8[o2[j]]);
+      word = lane == 2 * j ? (uint32_t) bits : (lane == 2 * j + 1 ? (uint32_t) (bits >> 32) : word);
+    }
+    if (lane < 8) {
+      my_word[i * (PRS_DESC_BYTES / 4)] = word;
+    }
+  };
+  uint32_t va[4], vb[4];
+  fetch(0, va);
+  // the window of keypoint i + 2 reuses the LDS of keypoint i: LDS operations of a wave complete in order.  The fetches are
+  // unconditional (the last keypoint is fetched again past the end): a branch around them would make the compiler wait for
+  // ALL loads before the compare, the one just issued included
+  for (int i = 0; i < cnt; i += 2) {
+    fetch(min(i + 1, cnt - 1), vb);
+    describe(i, va, window[wave][0]);
+    fetch(min(i + 2, cnt - 1), va);
+    if (i + 1 < cnt) {
+      describe(i + 1, vb, window[wave][1]);
+    }
+  }
+}
+
 static const int8_t kOrbPattern[1024] = {
 #include "orb_pattern.inc"
 };
 
-// the distinct cells of the pair table in row-major order + every comparison's two positions in that list
-static void fill_window_cells(const int8_t* pattern, FeatureArgs* a) {
-  int16_t index[27 * 27];
-  for (int i = 0; i < 27 * 27; ++i) {
-    index[i] = -1;
-  }
+// every comparison's two cells as byte offsets into the 27-row x 28-byte window around the keypoint
+static void fill_window_offsets(const int8_t* pattern, FeatureArgs* a) {
+  auto off = [](int x, int y) { return (uint16_t) ((y + kWinRadius) * 4 * kWinWords + (x + kWinRadius)); };  // + (c - 13) & 3 on the device
   for (int t = 0; t < 256; ++t) {
-    for (int k = 0; k < 2; ++k) {
-      index[((int) pattern[4 * t + 2 * k + 1] + 13) * 27 + ((int) pattern[4 * t + 2 * k] + 13)] = 0;
-    }
-  }
-  int n = 0;
-  for (int i = 0; i < 27 * 27; ++i) {
-    if (index[i] == 0) {
-      a->cell_dy[n] = (int8_t) (i / 27 - 13);
-      a->cell_dx[n] = (int8_t) (i % 27 - 13);
-      index[i]      = (int16_t) n++;
-    }
-  }
-  a->n_cells = n;
-  for (int t = 0; t < 256; ++t) {
-    a->pair_first[t]  = (uint16_t) index[((int) pattern[4 * t + 1] + 13) * 27 + ((int) pattern[4 * t] + 13)];
-    a->pair_second[t] = (uint16_t) index[((int) pattern[4 * t + 3] + 13) * 27 + ((int) pattern[4 * t + 2] + 13)];
+    a->pair_first[t]  = off(pattern[4 * t], pattern[4 * t + 1]);
+    a->pair_second[t] = off(pattern[4 * t + 2], pattern[4 * t + 3]);
   }
 }
 
@@ -1328,33 +1362,56 @@ int extract_features_launch(prs_context* ctx, const prs_extractor_params* params
   a.p = *params;
   a.b = *batch;
   const size_t npix = (size_t) batch->rows * batch->cols;
-  a.score = static_cast<uint8_t*>(ctx_device_scratch_slot(ctx, 0, (size_t) batch->batch * npix));
-  a.blur  = static_cast<uint8_t*>(ctx_device_scratch_slot(ctx, 1, (size_t) batch->batch * npix));
+  a.kept  = static_cast<uint32_t*>(ctx_device_scratch_slot(ctx, 0, (size_t) batch->batch * (size_t) batch->stride * sizeof(uint32_t)));
+  a.blur_ncb    = (batch->cols + 15) / 16;
+  a.blur_stride = (size_t) ((batch->rows + 7) / 8) * a.blur_ncb * 128;
+  a.blur        = static_cast<uint8_t*>(ctx_device_scratch_slot(ctx, 1, (size_t) batch->batch * a.blur_stride));
   uint32_t* rawbuf = static_cast<uint32_t*>(ctx_device_scratch_slot(ctx, 2, (size_t) batch->batch * ((size_t) max_raw + 1) * 4));
-  if (!a.score || !a.blur || !rawbuf) {
+  if (!a.kept || !a.blur || !rawbuf) {
     return ctx_fail(ctx, PRS_ERR_HIP, "prs_extract_features_batch: scratch allocation failed");
   }
   a.raw   = rawbuf;
   a.n_raw   = reinterpret_cast<int32_t*>(rawbuf + (size_t) batch->batch * max_raw);
   a.max_raw = max_raw;
-  fill_window_cells(kOrbPattern, &a);
+  a.stamps  = ctx_stamps(ctx, (size_t) batch->batch * 2 * 16 * sizeof(unsigned long long));
+  fill_window_offsets(kOrbPattern, &a);
   a.rows_per   = (float) batch->rows / (float) params->number_of_detectors_vertical;   // binned.cpp:52-55
   a.cols_per   = (float) batch->cols / (float) params->number_of_detectors_horizontal;
   a.regions    = regions;
   a.target_per = (int) ((float) params->target_number_of_keypoints / (float) regions);  // :72-76
   hipStream_t stream = ctx_stream(ctx);
-  const dim3 tiles((batch->cols + kTileW - 1) / kTileW, (batch->rows + kTileH - 1) / kTileH, batch->batch);
-  hipLaunchKernelGGL(fast_blur_kernel, tiles, dim3(kFastThreads), 0, stream, a);
-  hipLaunchKernelGGL(nms_compact_kernel, dim3(batch->batch), dim3(kNmsThreads), 0, stream, a);
   const size_t lds_keys = (size_t) max_raw * sizeof(uint32_t);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_describe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_keys);
+  hipError_t e = hipMemsetAsync(a.n_raw, 0, (size_t) batch->batch * sizeof(int32_t), stream);
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_extract_features_batch: detection counters");
+  }
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(raster_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_keys);
+  if (e == hipSuccess) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_describe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_keys);
+  }
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_extract_features_batch: LDS for the selection sort");
   }
+  int bucket_shift = 0;  // 1024 spans of 2^shift pixels cover the image
+  while (((npix - 1) >> bucket_shift) >= (size_t) kRasterBuckets) {
+    ++bucket_shift;
+  }
+  const int per_block = (kDescThreads / 64) * kDescPerWave;
+  const int chunks    = (batch->stride + per_block - 1) / per_block;
+  const dim3 tiles((batch->cols + kTileW - 1) / kTileW, (batch->rows + kTileH - 1) / kTileH, batch->batch);
+  hipLaunchKernelGGL(fast_blur_kernel, tiles, dim3(kFastThreads), 0, stream, a);
+  hipLaunchKernelGGL(raster_order_kernel, dim3(batch->batch), dim3(kNmsThreads), lds_keys, stream, a, bucket_shift);
   hipLaunchKernelGGL(select_describe_kernel, dim3(batch->batch), dim3(kSelThreads), lds_keys, stream, a);
+  hipLaunchKernelGGL(describe_kernel, dim3((unsigned) (((batch->batch + 7) / 8) * 8 * chunks), 1, 1), dim3(kDescThreads), 0, stream, a, chunks);
   e = hipGetLastError();
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_extract_features_batch launch");
+  }
+  if (a.stamps) {
+    ctx_report_stamps(ctx, batch->batch, 5, "select_describe_kernel: keys | sort | selection | tail");
+    if (batch->cols > 5 * kTileW && batch->rows > 2 * kTileH) {
+      ctx_report_stamps(ctx, batch->batch, 7, "fast_blur_kernel, tile (5, 2): load | compass | arcs | Gaussian rows | Gaussian columns | suppression", false, (size_t) batch->batch);
+    }
   }
   return PRS_OK;
 }

@@ -69,7 +69,7 @@ const float* ctx_info_scale_table(prs_context* ctx);
 // diagnostic: device buffer for phase stamps when PRS_STAMPS=1, else nullptr
 unsigned long long* ctx_stamps(prs_context* ctx, size_t bytes);
 // synchronises and prints mean per-phase cycle counts (n_stamps consecutive stamps per block)
-void ctx_report_stamps(prs_context* ctx, int blocks, int n_stamps, const char* legend, bool raw = false);  // raw: the words are per-phase totals, not cumulative stamps
+void ctx_report_stamps(prs_context* ctx, int blocks, int n_stamps, const char* legend, bool raw = false, size_t first_block = 0);  // raw: the words are per-phase totals, not cumulative stamps
 
 // exact integer form of `best < max_distance && best / second < max_ratio` (epipolar_impl.cpp:171-173),
 // evaluated on the host with the same IEEE float operations the reference performs:
