@@ -26,7 +26,7 @@ namespace prs {
 
 constexpr int kTileW = 64, kTileH = 64, kFastThreads = 256;
 constexpr int kTilePitch = kTileW + 8;  // 4-px halo on both sides
-constexpr int kNmsThreads = 1024, kSelThreads = 1024;
+constexpr int kNmsThreads = 1024, kSelThreads = 512;
 constexpr int kDefaultRaw = 8192;       // raw detections per image the selection sort holds by default
 constexpr int kMaxRawLimit = 32768;     // ... at most (prs_extractor_params.max_raw_detections; 128 KB of LDS keys)
 constexpr int kFeatureBorder = 31;      // cv::ORB edgeThreshold: keypoints closer to the border are removed (runByImageBorder)
@@ -949,7 +949,7 @@ __device__ __forceinline__ void std_sort_worker(uint32_t* v, SortQueue& sq, cons
   }
 }
 
-__global__ __launch_bounds__(kSelThreads, 8) void select_describe_kernel(const FeatureArgs a) {
+__global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const FeatureArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t keys[];  // [max_raw]
   __shared__ uint32_t count[kMaxRegions + 1];
   __shared__ uint32_t start[kMaxRegions + 1];
