@@ -34,8 +34,7 @@ constexpr int kMaxRegions = 256;
 constexpr int kSelScratch = 512;        // 16-bit words of LDS scratch per wave of the selection kernel
 constexpr int kWinRadius = 13, kWinWords = 8;  // bit_pattern_31_ stays within +-13 px: 27 rows (32 are fetched) of 8 aligned words
 constexpr int kDescThreads = 256, kDescPerWave = 16;  // describe_kernel: four waves, sixteen keypoints each
-// cv::GaussianBlur(7x7, sigma 2) on 8-bit data: round(256 * exp(-x^2 / 8) / sum), sum of the taps = 257
-constexpr uint32_t kG0 = 18, kG1 = 34, kG2 = 49, kG3 = 55;
+// cv::GaussianBlur(7x7, sigma 2) on 8-bit data: round(256 * exp(-x^2 / 8) / sum) = 18 34 49 55 49 34 18, sum of the taps = 257
 
 struct FeatureArgs {
   prs_extractor_params p;
@@ -152,7 +151,7 @@ __device__ __attribute__((noinline)) void score_overflowed(const uint8_t* tile8,
 // arc minima on dense lanes -> responses of the tile and its 1-px ring -> non-maximum suppression, four pixels per
 // lane; the separable 7x7 Gaussian of the tile on the side (packed 16-bit horizontal pass, 32-bit vertical pass).
 template <bool BORDER>
-__device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* tile32, uint32_t* resp32, uint64_t* hsum64, uint16_t (*list)[kListCap],
+__device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* tile32, uint32_t* resp32, uint16_t (*list)[kListCap],
                                               uint16_t (*second)[kSecondCap], int* list_n) {
   const int rows = a.b.rows, cols = a.b.cols, pitch = a.b.pitch;
   const int img = blockIdx.z;
@@ -162,6 +161,10 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
   const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(tile32);
   uint8_t* resp8       = reinterpret_cast<uint8_t*>(resp32);
   constexpr int kWordsAll = kTileRows * kTileWords;  // 1296
+  if (tid == 0) {
+    list_n[4] = 0;  // words with a detection / detections of the tile (suppression pass)
+    list_n[5] = 0;
+  }
   auto stamp = [&](const int i) {  // PRS_STAMPS=1: one interior tile of every image
     if (a.stamps && tid == 0 && blockIdx.x == 5 && blockIdx.y == 2) {
       a.stamps[((size_t) a.b.batch + img) * 16 + i] = (unsigned long long) clock64();
@@ -334,75 +337,74 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
       }
     }
   }
-  __syncthreads();  // the lists are dead: their bytes hold the horizontal sums from here on
+  // ---- 7x7 Gaussian on the matrix cores (round 5; rounds 2-4: packed 16-bit / v_dot vector passes through LDS, a fifth of the
+  // kernel's vector instructions -- and the kernel is bound by exactly those).  Separable, fixed point, both passes as
+  // v_mfma_i32_16x16x32_i8 against a banded matrix of the taps; integer products and sums: exact.  Wave w owns the tile's
+  // columns 16 w .. 16 w + 15 and needs nobody else's data, so nothing goes through LDS and there is no barrier:
+  //   rows:    H[80 x 16] = P[80 x 32] * Bh[32 x 16], five MFMAs; P = the tile's rows -3 .. 76 (beyond the halo: whatever
+  //            the clamped row holds, those sums feed no output), columns 16 w - 4 .. 16 w + 27, as signed bytes p - 128;
+  //            the accumulator starts at 128 * 257 (the taps sum to 257), so H is the true sum 0 .. 65535.  An MFMA result has
+  //            its column on the lane and four consecutive rows in its registers = the A operand of a product that sums over rows;
+  //   columns: out^T[16 x 16] = H^T[16 x 32] * Bv[32 x 16] per 16 output rows, H split into its two bytes (each as b - 128, two
+  //            MFMAs, recombined with a shift); the K order inside the operand is the one the first result arrives in (rows
+  //            4 g + r of two row blocks), Bv is built for that order.  Result: four consecutive pixels of one row per lane.
+  // Lane maps checked with exact integer data: tools/probes/mfma_i8_probe.hip.
+  {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    constexpr unsigned long long kTaps = 0x0012223137312212ull;  // bytes 0 .. 6 = 18 34 49 55 49 34 18
+    auto taps_from = [](const int d) -> unsigned long long {       // byte j = tap j + d (0 outside 0 .. 6)
+      return d >= 0 ? (d < 8 ? kTaps >> (8 * d) : 0ull) : (d > -8 ? kTaps << (-8 * d) : 0ull);
+    };
+    const int li = lane & 15, g = lane >> 4;
+    // Bh[k][n]: input column k (tile byte 16 w + k) feeds output column n (tile byte 16 w + 4 + n) with tap k - n - 1
+    const long bh = (long) taps_from(8 * g - li - 1);
+    // Bv[k][q]: byte t < 4 of lane group g is H row 4 g + t of the first row block, t >= 4 row 16 + 4 g + t - 4 (second block);
+    // H row h feeds output row q with tap h - q
+    const long bv = (long) ((taps_from(4 * g - li) & 0xffffffffull) | (taps_from(16 + 4 * g - li) << 32));
+    const uint8_t* strip = tile8 + 16 * wave + 8 * min(g, 2);  // (the fourth lane group's columns carry no tap: any bytes will do)
+    uint32_t hlo[5], hhi[5];
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+      const int ty = min(16 * b + li + 1, kTileRows - 1);
+      const uint64_t p = *reinterpret_cast<const uint64_t*>(strip + ty * kTilePitch);  // (8-byte aligned: the pitch is 72)
+      const v4i h = __builtin_amdgcn_mfma_i32_16x16x32_i8((long) (p ^ 0x8080808080808080ull), bh, v4i{32896, 32896, 32896, 32896}, 0, 0, 0);
+      const uint32_t p01 = __builtin_amdgcn_perm((uint32_t) h[1], (uint32_t) h[0], 0x05010400u);  // h0.b0 h1.b0 h0.b1 h1.b1
+      const uint32_t p23 = __builtin_amdgcn_perm((uint32_t) h[3], (uint32_t) h[2], 0x05010400u);
+      hlo[b] = __builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u;
+      hhi[b] = __builtin_amdgcn_perm(p23, p01, 0x07060302u) ^ 0x80808080u;
+    }
+    uint8_t* __restrict__ blur = a.blur + (size_t) img * a.blur_stride;
+#pragma unroll
+    for (int j = 0; j < kTileH / 16; ++j) {
+      const long alo = (long) (((uint64_t) hlo[j + 1] << 32) | hlo[j]), ahi = (long) (((uint64_t) hhi[j + 1] << 32) | hhi[j]);
+      // sum g H = sum g (lo - 128) + 256 sum g (hi - 128) + 257 * 128 * 257; + 2^15 for the rounding
+      const v4i slo = __builtin_amdgcn_mfma_i32_16x16x32_i8(alo, bv, v4i{65664, 65664, 65664, 65664}, 0, 0, 0);
+      const v4i shi = __builtin_amdgcn_mfma_i32_16x16x32_i8(ahi, bv, v4i{32896, 32896, 32896, 32896}, 0, 0, 0);
+      uint32_t v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = min((uint32_t) slo[r] + ((uint32_t) shi[r] << 8), 0x00ffffffu);  // (sum + 2^15) >> 16, saturated (the taps sum to 257 / 256)
+      }
+      const uint32_t out = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u) | (__builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u) << 16);
+      const int gy = y0 + 16 * j + li, gx = x0 + 16 * wave + 4 * g;
+      if (!BORDER || (gy < rows && gx < 16 * a.blur_ncb)) {  // (the padding columns of the last block take whatever the word holds)
+        *reinterpret_cast<uint32_t*>(blur + blur_offset(gy, gx, a.blur_ncb)) = out;
+      }
+    }
+  }
   stamp(3);
-  if (tid == 0) {
-    list_n[0] = 0;  // ... and the first counter counts the tile's detections (two barriers before its first use)
-  }
-  // ---- 7x7 Gaussian, horizontal pass: tile rows -3 .. kTileH+2, four sums per lane, stored as packed 16-bit lanes:
-  // 55 c + 49 (l1 + r1) + 34 (l2 + r2) + 18 (l3 + r3) <= 257 * 255 = 65535 fits the lane exactly.
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int h = r0 + 16 * k;
-    if (h < kTileH + 6) {
-      const int wi      = (h + 1) * kTileWords + 1 + w1;
-      const uint32_t C = tile32[wi], L = tile32[wi - 1], R = tile32[wi + 1];
-      // pixel x = 4 w + j: bytes x-3 .. x against (18, 34, 49, 55) and bytes x+1 .. x+4 against (49, 34, 18, 0), two v_dot4_u32_u8
-      constexpr uint32_t kTapsLeft = kG0 | (kG1 << 8) | (kG2 << 16) | (kG3 << 24), kTapsRight = kG2 | (kG1 << 8) | (kG0 << 16);
-      const uint32_t s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, L, 1), kTapsLeft, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 1), kTapsRight, 0u, false), false);
-      const uint32_t s1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, L, 2), kTapsLeft, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 2), kTapsRight, 0u, false), false);
-      const uint32_t s2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, L, 3), kTapsLeft, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 3), kTapsRight, 0u, false), false);
-      const uint32_t s3 = __builtin_amdgcn_udot4(C, kTapsLeft, __builtin_amdgcn_udot4(R, kTapsRight, 0u, false), false);
-      const uint32_t sum[2] = {s0 | (s2 << 16), s1 | (s3 << 16)};
-      hsum64[h * 16 + w1] = ((uint64_t) sum[1] << 32) | sum[0];  // lanes: pixel 0 | pixel 2 , pixel 1 | pixel 3
-    }
-  }
-  __syncthreads();
+  __syncthreads();  // the lists are dead: their bytes hold the tile's words with a detection from here on
   stamp(4);
-  // ---- Gaussian, vertical pass, straight to memory: (sum + 2^15) >> 16, saturated (the taps sum to 257 / 256) ----
-  uint8_t* __restrict__ blur = a.blur + (size_t) img * a.blur_stride;
-#pragma unroll
-  for (int k = 0; k < kTileH / 16; ++k) {
-    const int ly = r0 + 16 * k, gy = y0 + ly, gx = x0 + 4 * w1;
-    const uint64_t* h = hsum64 + ly * 16 + w1;  // row ly of the tile is horizontal row ly + 3: rows ly .. ly + 6
-    uint32_t acc[4] = {1u << 15, 1u << 15, 1u << 15, 1u << 15};
-    constexpr uint32_t taps[7] = {kG0, kG1, kG2, kG3, kG2, kG1, kG0};
-    // two rows per step: the same pixel of rows i and i + 1 side by side (v_perm), one v_dot2_u32_u16 against (tap i, tap i + 1)
-#pragma unroll
-    for (int i = 0; i < 6; i += 2) {
-      const uint64_t ha = h[16 * i], hb = h[16 * (i + 1)];
-      const uint32_t ea = (uint32_t) ha, oa = (uint32_t) (ha >> 32), eb = (uint32_t) hb, ob = (uint32_t) (hb >> 32);
-      const us2 tp = __builtin_bit_cast(us2, taps[i] | (taps[i + 1] << 16));
-      acc[0] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(eb, ea, 0x05040100u)), tp, acc[0], false);
-      acc[1] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(ob, oa, 0x05040100u)), tp, acc[1], false);
-      acc[2] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(eb, ea, 0x07060302u)), tp, acc[2], false);
-      acc[3] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(ob, oa, 0x07060302u)), tp, acc[3], false);
-    }
-    {
-      const uint64_t hv = h[16 * 6];
-      const uint32_t ev = (uint32_t) hv, od = (uint32_t) (hv >> 32);
-      acc[0] += taps[6] * (ev & 0xffffu);
-      acc[1] += taps[6] * (od & 0xffffu);
-      acc[2] += taps[6] * (ev >> 16);
-      acc[3] += taps[6] * (od >> 16);
-    }
-    const uint32_t out = min(acc[0] >> 16, 255u) | (min(acc[1] >> 16, 255u) << 8) | (min(acc[2] >> 16, 255u) << 16) | (min(acc[3] >> 16, 255u) << 24);
-    if (!BORDER || (gy < rows && gx < 16 * a.blur_ncb)) {  // (the padding columns of the last block take whatever the word holds)
-      *reinterpret_cast<uint32_t*>(blur + blur_offset(gy, gx, a.blur_ncb)) = out;
-    }
-  }
-  __syncthreads();
-  stamp(5);
   // ---- non-maximum suppression (strictly greater than the 8 neighbours), four pixels per lane.
   // A non-zero response never sits on the outermost 3 pixels, so the ring values are real responses of real pixels, and
-  // every non-zero byte of the tile proper is a pixel of the image.  Survivors (a few dozen per tile) go to a list of
-  // the workgroup (in the bytes of the horizontal sums, dead since the last barrier) in no particular order; the
-  // tile reserves its span of the image's list with ONE atomic and copies the list there.  raster_order_kernel sorts.
-  uint32_t* tile_raw = reinterpret_cast<uint32_t*>(hsum64);  // at most 32 x 32 survivors of a 64 x 64 tile
+  // every non-zero byte of the tile proper is a pixel of the image.  Words with a survivor (a few dozen per tile) go to a
+  // list of the workgroup (in the bytes of the horizontal sums, dead since the last barrier) in no particular order;
+  // raster_order_kernel sorts.
+  uint2* tile_words = reinterpret_cast<uint2*>(list);  // (response word, row << 4 | word of the tile): at most 1024 of 8 bytes
   const bool nms = a.p.enable_non_maximum_suppression != 0;
 #pragma unroll
   for (int k = 0; k < kTileH / 16; ++k) {
-    const int ly = r0 + 16 * k, gy = y0 + ly, gx = x0 + 4 * w1;
+    const int ly = r0 + 16 * k;
     const int wi = (ly + 4) * kTileWords + 1 + w1;
     const uint32_t Cm = resp32[wi];
     uint32_t out = Cm;
@@ -429,26 +431,49 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
       kept[1] = Om & pk_sign_fill(pk_sub(around_odd, Om));
       out = kept[0] | (kept[1] << 8);
     }
-    if (out != 0u) {  // rare: a tile of a KITTI image keeps ~25 of its 4096 pixels
-      const int present   = __popc(nonzero_bytes(out));
-      const uint32_t pix0 = (uint32_t) gy * (uint32_t) cols + (uint32_t) gx;
-      if (nms) {
-        int pos = atomicAdd(&list_n[0], present);
+    if (out != 0u) {
+      // ~25 of a KITTI tile's 4096 pixels survive, but four out of five waves have SOME lane in here: the wave-wide cost of this
+      // block is what counts, so it only files the word (PMC: the per-byte version was a fifth of the kernel's vector instructions)
+      const int at = atomicAdd(&list_n[4], 1);
+      tile_words[at] = make_uint2(out, (uint32_t) ((ly << 4) | w1));
+    }
+  }
+  __syncthreads();
+  stamp(5);
+  // ---- the listed words -> the image's list: every entry counts its survivors and takes its place in the tile's span, the
+  //      tile reserves the span with ONE atomic, the entries are unpacked there
+  const int n_words = list_n[4];  // (uniform)
+  if (n_words > 0) {
+    constexpr int kPerThread = (kTileW / 4) * kTileH / kFastThreads;  // 4: a tile has 1024 words
+    uint2 e[kPerThread];
+    int off[kPerThread];
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u) {
+      const int i = tid + kFastThreads * u;
+      e[u]        = make_uint2(0u, 0u);
+      off[u]      = 0;
+      if (i < n_words) {
+        e[u]   = tile_words[i];
+        off[u] = atomicAdd(&list_n[5], __popc(nonzero_bytes(e[u].x)));
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      list_n[1] = atomicAdd(a.n_raw + img, list_n[5]);
+    }
+    __syncthreads();
+    const int base = list_n[1];
+    uint32_t* __restrict__ raw = a.raw + (size_t) img * a.max_raw;
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u) {
+      if (tid + kFastThreads * u < n_words) {
+        const uint32_t pix0 = (uint32_t) (y0 + (int) (e[u].y >> 4)) * (uint32_t) cols + (uint32_t) (x0 + 4 * (int) (e[u].y & 15u));
+        int pos             = base + off[u];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const uint32_t sj = (out >> (8 * j)) & 0xffu;
+          const uint32_t sj = (e[u].x >> (8 * j)) & 0xffu;
           if (sj) {
-            tile_raw[pos++] = (sj << 24) | (pix0 + (uint32_t) j);
-          }
-        }
-      } else {  // without suppression a tile may hold up to 4096 detections: every lane appends its own
-        int pos = atomicAdd(a.n_raw + img, present);
-        uint32_t* __restrict__ raw = a.raw + (size_t) img * a.max_raw;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t sj = (out >> (8 * j)) & 0xffu;
-          if (sj) {
-            if (pos < a.max_raw) {
+            if (pos < a.max_raw) {  // beyond: the image fails with PRS_ERR_CAPACITY (raster_order_kernel sees the count)
               raw[pos] = (sj << 24) | (pix0 + (uint32_t) j);
             }
             ++pos;
@@ -457,41 +482,24 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
       }
     }
   }
-  __syncthreads();
-  stamp(6);
-  const int n_tile = list_n[0];  // (uniform; stays 0 without suppression)
-  if (n_tile > 0) {
-    if (tid == 0) {
-      list_n[1] = atomicAdd(a.n_raw + img, n_tile);
-    }
-    __syncthreads();
-    const int base = list_n[1];
-    uint32_t* __restrict__ raw = a.raw + (size_t) img * a.max_raw;
-    for (int i = tid; i < n_tile; i += kFastThreads) {
-      if (base + i < a.max_raw) {  // beyond: the image fails with PRS_ERR_CAPACITY (raster_order_kernel sees the count)
-        raw[base + i] = tile_raw[i];
-      }
-    }
-  }
 }
 
 __global__ __launch_bounds__(kFastThreads, 8) void fast_blur_kernel(const FeatureArgs a) {  // 8 workgroups of 4 waves per CU
   __shared__ __attribute__((aligned(16))) uint32_t tile32[kTileRows * kTileWords];
   __shared__ __attribute__((aligned(16))) uint32_t resp32[kTileRows * kTileWords];  // same geometry as the tile
-  // the survivor lists (compass -> arc passes) and the Gaussian's horizontal sums (horizontal -> vertical pass) share their bytes
+  // the survivor lists (compass -> arc passes) and the words with a detection (suppression pass) share their bytes
   constexpr size_t kListBytes = sizeof(uint16_t) * (kFastThreads / 64) * (kListCap + kSecondCap);
-  constexpr size_t kHsumBytes = sizeof(uint64_t) * (kTileH + 6) * 16;
-  __shared__ __attribute__((aligned(16))) unsigned char shared_bytes[kListBytes > kHsumBytes ? kListBytes : kHsumBytes];
-  uint64_t* hsum64 = reinterpret_cast<uint64_t*>(shared_bytes);  // horizontal 7-tap sums, four u16 per item
+  constexpr size_t kWordBytes = sizeof(uint2) * (kTileW / 4) * kTileH;
+  __shared__ __attribute__((aligned(16))) unsigned char shared_bytes[kListBytes > kWordBytes ? kListBytes : kWordBytes];
   uint16_t (*list)[kListCap]     = reinterpret_cast<uint16_t (*)[kListCap]>(shared_bytes);
   uint16_t (*second)[kSecondCap] = reinterpret_cast<uint16_t (*)[kSecondCap]>(shared_bytes + sizeof(uint16_t) * (kFastThreads / 64) * kListCap);
-  __shared__ int list_n[kFastThreads / 64];
+  __shared__ int list_n[kFastThreads / 64 + 2];
   const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
   // a tile whose halo lies inside the image needs no coordinate checks at all (block-uniform)
   if (x0 >= 4 && x0 + kTileW + 4 <= a.b.cols && y0 >= 4 && y0 + kTileH + 4 <= a.b.rows) {
-    fast_blur_tile<false>(a, tile32, resp32, hsum64, list, second, list_n);
+    fast_blur_tile<false>(a, tile32, resp32, list, second, list_n);
   } else {
-    fast_blur_tile<true>(a, tile32, resp32, hsum64, list, second, list_n);
+    fast_blur_tile<true>(a, tile32, resp32, list, second, list_n);
   }
 }
 
@@ -1410,7 +1418,7 @@ int extract_features_launch(prs_context* ctx, const prs_extractor_params* params
   if (a.stamps) {
     ctx_report_stamps(ctx, batch->batch, 5, "select_describe_kernel: keys | sort | selection | tail");
     if (batch->cols > 5 * kTileW && batch->rows > 2 * kTileH) {
-      ctx_report_stamps(ctx, batch->batch, 7, "fast_blur_kernel, tile (5, 2): load | compass | arcs | Gaussian rows | Gaussian columns | suppression", false, (size_t) batch->batch);
+      ctx_report_stamps(ctx, batch->batch, 6, "fast_blur_kernel, tile (5, 2): load | compass | arcs + Gaussian | barrier | suppression", false, (size_t) batch->batch);
     }
   }
   return PRS_OK;

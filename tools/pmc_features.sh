@@ -11,7 +11,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY" "SQ_WAIT_INST_ANY SQ_ACTI
            "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM" \
            "SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD" "GRBM_GUI_ACTIVE TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/tools/bench_features.py $B > $OUT/p$i.log 2>&1
+  timeout 200 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/tools/bench_features.py $B kitti libstdcxx > $OUT/p$i.log 2>&1
   echo "pass $i ($set) rc=$?"
 done
 python3 - <<PY
