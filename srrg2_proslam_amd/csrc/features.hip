@@ -162,8 +162,9 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
   uint8_t* resp8       = reinterpret_cast<uint8_t*>(resp32);
   constexpr int kWordsAll = kTileRows * kTileWords;  // 1296
   if (tid == 0) {
-    list_n[4] = 0;  // words with a detection / detections of the tile (suppression pass)
+    list_n[4] = 0;  // detections of the tile (suppression pass; after a list overflow: words with a detection / detections)
     list_n[5] = 0;
+    list_n[6] = 0;  // set when a compass list overflows
   }
   auto stamp = [&](const int i) {  // PRS_STAMPS=1: one interior tile of every image
     if (a.stamps && tid == 0 && blockIdx.x == 5 && blockIdx.y == 2) {
@@ -227,6 +228,7 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
         my_list[pos] = (uint16_t) entry;
       } else {
         score_overflowed(tile8, resp8, entry, t);
+        list_n[6] = 1;
       }
     }
     n_mine += __popcll(m);
@@ -320,7 +322,7 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
       const int pos = lanes_below(m, n_second);
       if (pos < kSecondCap) {
         my_second[pos] = (uint16_t) again_id;
-      } else {  // list full: the lane looks at the dark arcs itself
+      } else {  // list full: the lane looks at the dark arcs itself (the pixel is on a first list: nothing to flag)
         score_overflowed(tile8, resp8, (uint32_t) again_id | kDarkFlag, t);
       }
     }
@@ -395,13 +397,67 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
   stamp(3);
   __syncthreads();  // the lists are dead: their bytes hold the tile's words with a detection from here on
   stamp(4);
-  // ---- non-maximum suppression (strictly greater than the 8 neighbours), four pixels per lane.
-  // A non-zero response never sits on the outermost 3 pixels, so the ring values are real responses of real pixels, and
-  // every non-zero byte of the tile proper is a pixel of the image.  Words with a survivor (a few dozen per tile) go to a
-  // list of the workgroup (in the bytes of the horizontal sums, dead since the last barrier) in no particular order;
-  // raster_order_kernel sorts.
-  uint2* tile_words = reinterpret_cast<uint2*>(list);  // (response word, row << 4 | word of the tile): at most 1024 of 8 bytes
+  // ---- non-maximum suppression (strictly greater than the 8 neighbours).  A non-zero response never sits on the outermost
+  // 3 pixels, so the ring values are real responses of real pixels, and every non-zero byte of the tile proper is a pixel of
+  // the image.  Every response belongs to a pixel of the compass lists (unless a list overflowed), so the lists are walked once
+  // more on dense lanes: a pixel with a response looks at its eight neighbours (round 5; the sweep over all 4096 pixels below,
+  // four per lane, was a sixth of the kernel's vector instructions).  Survivors go to a list of the workgroup (in the tile's
+  // pixels, dead since the last barrier) in no particular order; raster_order_kernel sorts.
   const bool nms = a.p.enable_non_maximum_suppression != 0;
+  if (list_n[6] == 0) {  // (uniform)
+    uint32_t* found = tile32;  // at most 32 x 32 survivors of a 64 x 64 tile
+    for (int base = 0; base < total; base += kFastThreads) {
+      const int j = base + tid;
+      if (j < total) {
+        const int seg = (j >= c0) + (j >= c1) + (j >= c2);
+        const int off = j - (seg == 0 ? 0 : (seg == 1 ? c0 : (seg == 2 ? c1 : c2)));
+        const int id  = (int) (list[seg][off] & kIdMask);
+        const uint32_t sc = resp8[id];
+        const int ty = (id * 3641) >> 18, tx = id - ty * kTilePitch;  // id / 72 (exact below 5184)
+        if (sc != 0u && (unsigned) (ty - 4) < (unsigned) kTileH && (unsigned) (tx - 4) < (unsigned) kTileW) {
+          bool keep = true;
+          if (nms) {
+            constexpr int P = kTilePitch;
+            const uint8_t* c = resp8 + id;
+            const uint32_t m = max(max(max((uint32_t) c[-P - 1], (uint32_t) c[-P]), max((uint32_t) c[-P + 1], (uint32_t) c[-1])),
+                                   max(max((uint32_t) c[1], (uint32_t) c[P - 1]), max((uint32_t) c[P], (uint32_t) c[P + 1])));
+            keep = sc > m;
+          }
+          if (keep) {
+            const uint32_t entry = (sc << 24) | ((uint32_t) (y0 + ty - 4) * (uint32_t) cols + (uint32_t) (x0 + tx - 4));
+            if (nms) {
+              found[atomicAdd(&list_n[4], 1)] = entry;
+            } else {  // without suppression a tile may hold up to 4096 detections: every lane appends its own
+              const int pos = atomicAdd(a.n_raw + img, 1);
+              if (pos < a.max_raw) {
+                a.raw[(size_t) img * a.max_raw + pos] = entry;
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    stamp(5);
+    const int n_found = list_n[4];  // (uniform)
+    if (n_found > 0) {
+      if (tid == 0) {
+        list_n[1] = atomicAdd(a.n_raw + img, n_found);  // the tile's span of the image's list: ONE atomic
+      }
+      __syncthreads();
+      const int base = list_n[1];
+      uint32_t* __restrict__ raw = a.raw + (size_t) img * a.max_raw;
+      for (int i = tid; i < n_found; i += kFastThreads) {
+        if (base + i < a.max_raw) {  // beyond: the image fails with PRS_ERR_CAPACITY (raster_order_kernel sees the count)
+          raw[base + i] = found[i];
+        }
+      }
+    }
+    return;
+  }
+  // ---- a list overflowed (more than half of a wave's pixels passed the compass test: noise, not an image): the sweep over
+  // all pixels, four per lane.  Words with a survivor go to a list of the workgroup (in the bytes of the compass lists).
+  uint2* tile_words = reinterpret_cast<uint2*>(list);  // (response word, row << 4 | word of the tile): at most 1024 of 8 bytes
 #pragma unroll
   for (int k = 0; k < kTileH / 16; ++k) {
     const int ly = r0 + 16 * k;
@@ -493,7 +549,7 @@ __global__ __launch_bounds__(kFastThreads, 8) void fast_blur_kernel(const Featur
   __shared__ __attribute__((aligned(16))) unsigned char shared_bytes[kListBytes > kWordBytes ? kListBytes : kWordBytes];
   uint16_t (*list)[kListCap]     = reinterpret_cast<uint16_t (*)[kListCap]>(shared_bytes);
   uint16_t (*second)[kSecondCap] = reinterpret_cast<uint16_t (*)[kSecondCap]>(shared_bytes + sizeof(uint16_t) * (kFastThreads / 64) * kListCap);
-  __shared__ int list_n[kFastThreads / 64 + 2];
+  __shared__ int list_n[kFastThreads / 64 + 3];
   const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
   // a tile whose halo lies inside the image needs no coordinate checks at all (block-uniform)
   if (x0 >= 4 && x0 + kTileW + 4 <= a.b.cols && y0 >= 4 && y0 + kTileH + 4 <= a.b.rows) {

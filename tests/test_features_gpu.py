@@ -56,6 +56,23 @@ def test_raw_detection_capacity_is_a_loud_error(hip_ctx):
     assert st[0] == -2 and n[0] == 0
 
 
+@pytest.mark.parametrize("nms", [1, 0])
+def test_noise_overflows_the_compass_lists(oracle, hip_ctx, nms):
+    """White noise at a low threshold: more than half of a wave's pixels pass the compass test, the tile kernel's survivor
+    lists overflow (lanes score their pixel themselves) and suppression falls back from the walk over the lists to the
+    sweep over all pixels; with nms = 0 every corner is a detection.  Same features as the checker, in the same order."""
+    rng = np.random.default_rng(77)
+    images = [rng.integers(0, 256, (200, 264), dtype=np.uint8), rng.integers(90, 166, (131, 197), dtype=np.uint8)]
+    for order_o, order_g in ((of.SELECT_LIBSTDCXX, ops.SELECT_LIBSTDCXX), (of.SELECT_CANONICAL, ops.SELECT_CANONICAL)):
+        po = of.extractor_params(4, nms, 600, 2, 2, order_o)
+        pg = ops.extractor_params(4, nms, 600, 2, 2, order_g, 32768)
+        for img in images:
+            kp, desc, inten, n, st = _run(hip_ctx, pg, [img], 2048)
+            uv, oi, od = of.extract_features(po, img, capacity=2048)
+            assert st[0] == 0 and n[0] == len(uv) and len(uv) > 100, (st[0], n[0], len(uv))
+            assert np.array_equal(kp[0, : n[0]], uv) and np.array_equal(desc[0, : n[0]], od) and np.array_equal(inten[0, : n[0]], oi)
+
+
 def test_small_odd_sized_and_flat_images(oracle, hip_ctx):
     rng = np.random.default_rng(5)
     po, pg = of.extractor_params(12, 1, 200, 2, 2), ops.extractor_params(12, 1, 200, 2, 2)
