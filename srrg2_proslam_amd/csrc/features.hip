@@ -33,7 +33,7 @@ constexpr int kFeatureBorder = 31;      // cv::ORB edgeThreshold: keypoints clos
 constexpr int kMaxRegions = 256;
 constexpr int kSelScratch = 512;        // 16-bit words of LDS scratch per wave of the selection kernel
 constexpr int kWinRadius = 13, kWinWords = 8;  // bit_pattern_31_ stays within +-13 px: 27 rows (32 are fetched) of 8 aligned words
-constexpr int kDescThreads = 256, kDescPerWave = 16;  // describe_kernel: four waves, sixteen keypoints each
+constexpr int kDescThreads = 256, kDescPerWave = 24;  // describe_kernel: four waves, 24 keypoints each (at most 64: one per lane of the wave's slot list); 4 .. 64 measured, flat within 3 %
 // cv::GaussianBlur(7x7, sigma 2) on 8-bit data: round(256 * exp(-x^2 / 8) / sum) = 18 34 49 55 49 34 18, sum of the taps = 257
 
 struct FeatureArgs {
@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const Feat
 //      comparisons and a ballot IS eight bytes of the descriptor: bit t lands in byte t / 8, bit t % 8.
 //      (Rounds 2-4 described inside the selection kernel, one byte load per distinct cell of the pair table from a row-major
 //      image: ~33 cache lines per keypoint.)
-__global__ __launch_bounds__(kDescThreads) void describe_kernel(const FeatureArgs a, const int chunks) {
+__global__ __launch_bounds__(kDescThreads) void describe_kernel(const FeatureArgs a, const int chunks, const int per_wave) {
   __shared__ uint32_t window[kDescThreads / 64][2][4 * 64];
   const int cols = a.b.cols;
   // consecutive workgroups go to consecutive XCDs (eight L2s): the chunks of one image stay on one of them
@@ -1265,11 +1265,11 @@ __global__ __launch_bounds__(kDescThreads) void describe_kernel(const FeatureArg
     return;
   }
   const int n_kept = min(a.b.n_features[img], a.b.stride);  // (0 for an image that failed)
-  const int s0     = (chunk * (kDescThreads / 64) + wave) * kDescPerWave;
+  const int s0     = (chunk * (kDescThreads / 64) + wave) * per_wave;
   if (s0 >= n_kept) {
     return;
   }
-  const int cnt = min(kDescPerWave, n_kept - s0);
+  const int cnt = min(per_wave, n_kept - s0);
   const uint8_t* __restrict__ blur = a.blur + (size_t) img * a.blur_stride;
   const uint8_t* __restrict__ src  = a.b.images + (size_t) img * a.b.rows * a.b.pitch;
   prs_kp2* __restrict__ out_kp     = a.b.keypoints + (size_t) img * a.b.stride;
@@ -1460,13 +1460,14 @@ int extract_features_launch(prs_context* ctx, const prs_extractor_params* params
   while (((npix - 1) >> bucket_shift) >= (size_t) kRasterBuckets) {
     ++bucket_shift;
   }
-  const int per_block = (kDescThreads / 64) * kDescPerWave;
+  const int per_wave  = kDescPerWave;
+  const int per_block = (kDescThreads / 64) * per_wave;
   const int chunks    = (batch->stride + per_block - 1) / per_block;
   const dim3 tiles((batch->cols + kTileW - 1) / kTileW, (batch->rows + kTileH - 1) / kTileH, batch->batch);
   hipLaunchKernelGGL(fast_blur_kernel, tiles, dim3(kFastThreads), 0, stream, a);
   hipLaunchKernelGGL(raster_order_kernel, dim3(batch->batch), dim3(kNmsThreads), lds_keys, stream, a, bucket_shift);
   hipLaunchKernelGGL(select_describe_kernel, dim3(batch->batch), dim3(kSelThreads), lds_keys, stream, a);
-  hipLaunchKernelGGL(describe_kernel, dim3((unsigned) (((batch->batch + 7) / 8) * 8 * chunks), 1, 1), dim3(kDescThreads), 0, stream, a, chunks);
+  hipLaunchKernelGGL(describe_kernel, dim3((unsigned) (((batch->batch + 7) / 8) * 8 * chunks), 1, 1), dim3(kDescThreads), 0, stream, a, chunks, per_wave);
   e = hipGetLastError();
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_extract_features_batch launch");
