@@ -9,16 +9,17 @@
 // in-repo code line by line; PRS_SELECT_LIBSTDCXX reproduces the tie order of GNU std::sort there.
 //
 // Four launches per batch of images:
-//   fast_blur_kernel   one 64x64 pixel tile per workgroup (tile + halo in LDS), four pixels per lane: compass
-//                      test on packed 16-bit lanes, survivors in dense per-wave lists, arc minima on dense
-//                      lanes, non-maximum suppression; the tile's suppressed detections are appended to the image's
-//                      list (one atomic per tile) and the 7x7 Gaussian (fixed point, what ORB samples) of the tile
-//                      (u8) is written.  VALU-bound (the image is read once, no response map leaves the CU)
+//   fast_blur_kernel   one 64x64 pixel tile per workgroup (tile + halo in LDS): compass test on packed 16-bit lanes, four
+//                      pixels per lane, survivors in dense per-wave lists; arc minima on dense lanes; the 7x7 Gaussian
+//                      (fixed point, what ORB samples) of the tile on the matrix cores (v_mfma_i32_16x16x32_i8, exact),
+//                      written in 128-byte blocks; non-maximum suppression as a second walk over the lists; the tile's
+//                      detections appended to the image's list (one atomic per tile).  Bound by vector issue
+//                      (one vector instruction per cycle and CU: profiles/r05/features_pmc.txt)
 //   raster_order_kernel one workgroup per image: the appended detections sorted by pixel index = the order
-//                      cv::FAST reports them in (round 5; rounds 2-4 compacted a dense response map)
+//                      cv::FAST reports them in (bucket sort; rounds 2-4 compacted a dense response map)
 //   select_describe_kernel one workgroup per image: region histogram, one bitonic sort of
 //                      (region, response, order) keys in LDS (or the replay of std::sort), per-region selection, border filter
-//   describe_kernel    one wave per sixteen kept keypoints: 256 comparisons of smoothed pixels per keypoint
+//   describe_kernel    one wave per 24 kept keypoints: 256 comparisons of smoothed pixels per keypoint
 #include "prs_device.h"
 #include "prs_host.h"
 
