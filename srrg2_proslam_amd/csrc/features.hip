@@ -901,7 +901,12 @@ __device__ __forceinline__ void sort_queue_unlock(SortQueue& sq) {
   __hip_atomic_store(&sq.lock, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__device__ __forceinline__ void std_sort_worker(uint32_t* v, SortQueue& sq, const int lane, int* q) {
+// `region_start` / `keep` (round 5): the caller only reads the first `keep` positions of every region (start[key >> 23] is where the
+// region of a key begins).  The ranges __introsort_loop recurses into are disjoint and the final insertion sort never moves an item
+// across a cut, so a range that begins at or behind the region's `keep`-th position cannot change what is read: it is dropped
+// unsorted (a region of ~330 detections with 111 kept: about half of the partitions and register passes).  nullptr: sort everything.
+__device__ __forceinline__ void std_sort_worker(uint32_t* v, SortQueue& sq, const int lane, int* q, const uint32_t* region_start = nullptr,
+                                                const int keep = 0) {
   int* tl    = q;
   int* tr    = q + 64;
   int* stack = q + 128;  // private (first, last, depth) triples: the right siblings along this wave's path, at most 2 lg + 1 <= 31
@@ -956,6 +961,7 @@ __device__ __forceinline__ void std_sort_worker(uint32_t* v, SortQueue& sq, cons
       last              = __builtin_amdgcn_readfirstlane((int) e.y);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // the items of the range were written by another wave
     }
+    const int limit = region_start ? (int) region_start[v[first] >> 23] + keep : 0x7fffffff;  // (one region per range)
     int finished = 0;  // items of ranges this chain has finished
     for (;;) {
       const int size = last - first;
@@ -977,7 +983,9 @@ __device__ __forceinline__ void std_sort_worker(uint32_t* v, SortQueue& sq, cons
       --depth;
       const int cut   = std_partition_wave(v, first, last, lane, tl, tr);
       const int rsize = last - cut;
-      if (rsize <= 64) {
+      if (cut >= limit) {
+        finished += rsize;  // nobody reads these positions
+      } else if (rsize <= 64) {
         if (rsize > 1) {
           std_sort_small_wave(v, cut, rsize, depth, lane);
         }
@@ -1181,7 +1189,7 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const Feat
       }
     }
     __syncthreads();
-    std_sort_worker(keys, sortq, lane, reinterpret_cast<int*>(patch + wave * kSelScratch));
+    std_sort_worker(keys, sortq, lane, reinterpret_cast<int*>(patch + wave * kSelScratch), start, a.target_per);
     __syncthreads();
     if (sortq.failed) {  // a wave gave up waiting (std_sort_worker): loud per-image error
       if (tid == 0) {
