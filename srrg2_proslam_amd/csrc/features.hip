@@ -161,7 +161,6 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(tile32);
   uint8_t* resp8       = reinterpret_cast<uint8_t*>(resp32);
-  constexpr int kWordsAll = kTileRows * kTileWords;  // 1296
   if (tid == 0) {
     list_n[4] = 0;  // detections of the tile (suppression pass; after a list overflow: words with a detection / detections)
     list_n[5] = 0;
@@ -173,19 +172,22 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
     }
   };
   stamp(0);
-  // ---- tile + halo: all loads of a lane in flight before the first LDS store ----
+  // ---- tile + halo: all loads of a lane in flight before the first LDS store.  252 lanes take 14 rows of 18 words at a
+  //      time (one division per lane; the six loads differ by a uniform 14 rows) ----
   {
-    uint32_t w[6];
+    constexpr int kLoadRows = kFastThreads / kTileWords, kLoaders = kLoadRows * kTileWords, kLoads = (kTileRows + kLoadRows - 1) / kLoadRows;  // 14, 252, 6
+    const int ty0 = tid / kTileWords, tw = tid - ty0 * kTileWords;
+    const int gx = x0 - 4 + 4 * tw;
+    uint32_t w[kLoads];
 #pragma unroll
-    for (int u = 0; u < 6; ++u) {
-      const int i = tid + 256 * u;
-      w[u]        = 0;
-      if (i < kWordsAll) {
-        const int ty = i / kTileWords, tw = i - ty * kTileWords;
+    for (int u = 0; u < kLoads; ++u) {
+      const int ty = ty0 + kLoadRows * u;
+      w[u]         = 0;
+      if (tid < kLoaders && ty < kTileRows) {
         int gy = y0 + ty - 4;
-        const int gx = x0 - 4 + 4 * tw;
         if (!BORDER) {
-          __builtin_memcpy(&w[u], src + (size_t) gy * pitch + gx, 4);  // global loads may be unaligned, the LDS stores are not
+          const uint8_t* rows_u = src + (size_t) (y0 - 4 + kLoadRows * u) * pitch;  // (uniform)
+          __builtin_memcpy(&w[u], rows_u + ((size_t) ty0 * pitch + gx), 4);  // global loads may be unaligned, the LDS stores are not
         } else {
           gy = gy < 0 ? 0 : (gy >= rows ? rows - 1 : gy);  // clamped pixels never reach an output
           const uint8_t* row = src + (size_t) gy * pitch;
@@ -202,11 +204,10 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
       }
     }
 #pragma unroll
-    for (int u = 0; u < 6; ++u) {
-      const int i = tid + 256 * u;
-      if (i < kWordsAll) {
-        tile32[i] = w[u];
-        resp32[i] = 0;
+    for (int u = 0; u < kLoads; ++u) {
+      if (tid < kLoaders && ty0 + kLoadRows * u < kTileRows) {
+        tile32[tid + kLoaders * u] = w[u];
+        resp32[tid + kLoaders * u] = 0;
       }
     }
   }
@@ -275,10 +276,32 @@ __device__ __forceinline__ void fast_blur_tile(const FeatureArgs& a, uint32_t* t
       ok2 = ok2 && gxm3 + 2u <= lim;
       ok3 = ok3 && gxm3 + 3u <= lim;
     }
-    push(e0, ok0);  // every lane of the wave takes part: the list position is a wave-wide count
-    push(e1, ok1);
-    push(e2, ok2);
-    push(e3, ok3);
+    // every lane of the wave takes part: the list position is a wave-wide count.  As long as the list has room for all of the
+    // iteration's candidates (a scalar test; always, on an image) a lane's entries go side by side behind those of the lanes
+    // below it: one chain of eight v_mbcnt instead of four position computations with a capacity test each
+    const uint64_t m0 = __ballot(ok0), m1 = __ballot(ok1), m2 = __ballot(ok2), m3 = __ballot(ok3);
+    const int coming = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+    if (n_mine + coming <= kListCap) {
+      uint16_t* slot = my_list + lanes_below(m0, lanes_below(m1, lanes_below(m2, lanes_below(m3, n_mine))));
+      if (ok0) {
+        *slot++ = (uint16_t) e0;
+      }
+      if (ok1) {
+        *slot++ = (uint16_t) e1;
+      }
+      if (ok2) {
+        *slot++ = (uint16_t) e2;
+      }
+      if (ok3) {
+        *slot = (uint16_t) e3;
+      }
+      n_mine += coming;
+    } else {
+      push(e0, ok0);
+      push(e1, ok1);
+      push(e2, ok2);
+      push(e3, ok3);
+    }
   }
   if (wave < 3) {  // ring columns: response column 0 (tile x = 3) and 65 (tile x = 68), one pixel per lane
     const int row = min(tid >> 1, kTileH + 1), tx = (tid & 1) ? kTileW + 4 : 3;
