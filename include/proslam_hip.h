@@ -746,9 +746,10 @@ PRS_API int prs_motion_predict_batch(prs_context* ctx, int32_t batch, const floa
  * ============================================================================================== */
 /* which of several EQUAL responses survive the per-region cut (intensity_feature_extractor_binned.cpp:179-195 uses
  * std::sort with a response-only comparator, so the answer is implementation defined):
- *   PRS_SELECT_CANONICAL  ties in detection (raster) order; parallel sort, the fast path
- *   PRS_SELECT_LIBSTDCXX  the permutation GNU libstdc++'s std::sort produces; one lane per region runs the same
- *                         introsort sequentially (slower), results identical to a reference built with GCC */
+ *   PRS_SELECT_CANONICAL  ties in detection (raster) order; one bitonic sort of all detections of the image
+ *   PRS_SELECT_LIBSTDCXX  the permutation GNU libstdc++'s std::sort produces: its introsort replayed by the waves of a
+ *                         workgroup (only the ranges that reach a region's kept prefix); results identical to a reference
+ *                         built with GCC, and since round 5 the faster of the two (profiles/r05/features_kitti_images.txt) */
 enum { PRS_SELECT_CANONICAL = 0, PRS_SELECT_LIBSTDCXX = 1 };
 
 typedef struct {
