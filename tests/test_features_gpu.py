@@ -73,6 +73,28 @@ def test_noise_overflows_the_compass_lists(oracle, hip_ctx, nms):
             assert np.array_equal(kp[0, : n[0]], uv) and np.array_equal(desc[0, : n[0]], od) and np.array_equal(inten[0, : n[0]], oi)
 
 
+def test_batch_of_21_images_keeps_every_image_to_itself(oracle, hip_ctx):
+    """A batch that is not a multiple of eight (the describe pass folds image and chunk into the workgroup index, eight images at
+    a time; the tile pass appends to per-image lists with atomics): seven different images in shuffled triplicate, every copy
+    must equal the checker's extraction of its own image, in the reference's order."""
+    cfg = configs.get("kitti")
+    rng = np.random.default_rng(3)
+    distinct = []
+    for seed in (21, 22, 23, 24):
+        l, r, _ = syn.stereo_images(np.random.default_rng(seed), cfg)
+        distinct += [l, r]
+    distinct = distinct[:7]
+    order = rng.permutation(np.repeat(np.arange(7), 3))
+    po = of.extractor_params(15, 1, 1000, 3, 3, of.SELECT_LIBSTDCXX)
+    pg = ops.extractor_params(15, 1, 1000, 3, 3, ops.SELECT_LIBSTDCXX)
+    want = [of.extract_features(po, img, capacity=2048) for img in distinct]
+    kp, desc, inten, n, st = _run(hip_ctx, pg, [distinct[i] for i in order], 2048)
+    for b, i in enumerate(order):
+        uv, oi, od = want[i]
+        assert st[b] == 0 and n[b] == len(uv), (b, i, st[b], n[b], len(uv))
+        assert np.array_equal(kp[b, : n[b]], uv) and np.array_equal(desc[b, : n[b]], od) and np.array_equal(inten[b, : n[b]], oi), (b, i)
+
+
 def test_small_odd_sized_and_flat_images(oracle, hip_ctx):
     rng = np.random.default_rng(5)
     po, pg = of.extractor_params(12, 1, 200, 2, 2), ops.extractor_params(12, 1, 200, 2, 2)
