@@ -289,7 +289,7 @@ __device__ __forceinline__ void factor_accumulate(const prs_aligner_params& a, c
   const float pcz = fmaf(X.R22, p_in.z, fmaf(X.R21, p_in.y, fmaf(X.R20, p_in.x, X.t2)));
   const float hx_r = fmaf(fx, pcx, cx * pcz);
   const float hy_r = fmaf(fy, pcy, cy * pcz);
-  const float iz_r = 1.0f / pcz;
+  const float iz_r = recip_exact(pcz);  // (= 1.0f / pcz, bit for bit: prs_device.h)
   const float u_r = hx_r * iz_r, v_r = hy_r * iz_r;
   const bool valid = active && pcz > 0.0f && !(u_r < 0.0f || u_r > a.image_cols || v_r < 0.0f || v_r > a.image_rows);
   // the stand-in of an invalid / inactive correspondence: inverse depth 0 (the predicted image point and D are then zeros: hx_r,
@@ -333,7 +333,12 @@ __device__ __forceinline__ void factor_accumulate(const prs_aligner_params& a, c
   const bool saturated = valid && chi > a.chi_threshold;
   // (prs_aligner_params.kernel_weight_form: tau / chi instead.  The instantiations with a compile-time factor type are the shipped
   // family's: align_batch_launch sends every other reading to the generic ones)
-  const float ratio    = inlier_only ? 0.0f : ((DIM == 0 && a.kernel_weight_form == PRS_KERNEL_WEIGHT_TAU_OVER_CHI) ? a.chi_threshold : 1.0f) / chi;  // inlier-only run: kernelised factors are suppressed
+  float ratio;  // inlier-only run: kernelised factors are suppressed
+  if (DIM != 0) {
+    ratio = inlier_only ? 0.0f : recip_exact(chi);  // (= 1.0f / chi, bit for bit)
+  } else {
+    ratio = inlier_only ? 0.0f : (a.kernel_weight_form == PRS_KERNEL_WEIGHT_TAU_OVER_CHI ? a.chi_threshold : 1.0f) / chi;
+  }
   const float scale    = saturated ? ratio : 1.0f;
   o0 *= scale;
   o1 *= scale;

@@ -13,6 +13,22 @@ namespace prs {
 
 // 256-bit Hamming distance of two 32-byte rows held as 2 x uint4 each
 // (replaces srrg2_core PointDescriptorField::distance; call site CF/..epipolar_impl.cpp:157)
+// 1.0f / x, correctly rounded (the value the IEEE division of the CPU side produces), in 3 + 2 instructions instead of the twelve of
+// the compiler's expansion (v_div_scale x 2, v_rcp, 4 x v_fma, v_div_fmas, v_div_fixup).  tools/probes/rcp_exact_probe.hip runs ALL 2^32
+// bit patterns on gfx950: v_rcp_f32 followed by ONE Newton step in fused multiply-adds equals the IEEE quotient for every x whose biased
+// exponent is 1 .. 252 (2^-126 <= |x| < 2^126; both signs, every mantissa); zeros, denormals, the two largest binades (denormal
+// quotients), infinities and NaNs differ.  A wave that holds such an operand takes the compiler's division instead (never, on
+// the values the aligner divides by: depths and chi-squares).
+__device__ __forceinline__ float recip_exact(const float x) {
+  const float ax  = __builtin_fabsf(x);
+  const bool plain = ax >= 0x1p-126f && ax < 0x1p126f;
+  if (__builtin_expect(__ballot(!plain) != 0ull, 0)) {
+    return 1.0f / x;
+  }
+  const float y = __builtin_amdgcn_rcpf(x);
+  return __builtin_fmaf(__builtin_fmaf(-x, y, 1.0f), y, y);
+}
+
 __device__ __forceinline__ int hamming256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
   int d = __popc(a0.x ^ b0.x);
   d += __popc(a0.y ^ b0.y);

@@ -203,7 +203,7 @@ __device__ __forceinline__ bool ldlt_solve6(const float* H, const float* b, cons
       }
     }
     ok     = ok && d > 0.0f;  // (no early exit: a failed pivot only poisons values that are dropped)
-    inv[j] = 1.0f / d;
+    inv[j] = recip_exact(d);  // (= 1.0f / d, bit for bit: prs_device.h)
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       if (i > j) {
