@@ -671,7 +671,7 @@ __device__ bool smoother_iterate(const prs_estimator_params& P, const float* pos
         ph[i] = (Km[3 * i + 0] * pc[0] + Km[3 * i + 1] * pc[1]) + Km[3 * i + 2] * pc[2];
       }
       const float c      = ph[2];
-      const float inv_c  = 1.0f / c;
+      const float inv_c  = recip_exact(c);  // (= 1.0f / c, bit for bit: prs_device.h)
       const float inv_c2 = inv_c * inv_c;
       const float pi0 = ph[0] / c, pi1 = ph[1] / c;  // :71
       const float e[3] = {pi0 - u, pi1 - v, c - d};  // :74-76
