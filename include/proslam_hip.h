@@ -442,6 +442,13 @@ PRS_API int prs_gn_step(prs_context* ctx, const float* H36, const float* b6, flo
 /* the same with the damping form chosen (prs_aligner_params.damping_form: PRS_DAMPING_DIAG or PRS_DAMPING_IDENTITY) */
 PRS_API int prs_gn_step_ex(prs_context* ctx, const float* H36, const float* b6, float damping, int32_t damping_form, float* X16);
 
+/* Self-test of the reciprocal the aligner kernels use (csrc/prs_device.h, recip_exact: v_rcp_f32 + one Newton step in fused
+ * multiply-adds where that equals the IEEE quotient, the compiler's division elsewhere): every one of the 2^32 float bit patterns
+ * through the function as shipped, compared with 1.0f / x of the same device (NaNs compare equal).  counts[0] = operands that differ
+ * (must be 0), counts[1] = operands that went through the short form (waves that held only operands of 2^-126 <= |x| < 2^126).
+ * About a second on an MI355X; not part of the tracking path. */
+PRS_API int prs_selftest_reciprocal(prs_context* ctx, uint64_t counts[2]);
+
 /* host helper: information scale column from landmark ages
  * (aligner_slice_processor_projective.cpp:46-52: n > 2 ? 1 + log(n) : 1) */
 PRS_API void prs_info_scale_from_nopt(const uint32_t* n_opt, int32_t n, float* scale);

@@ -300,6 +300,7 @@ SYMBOLS = {
     "prs_pcf_linearize": (C.c_int, [_vp, C.POINTER(AlignerParams), _vp, _vp, C.c_int32, C.POINTER(AlignResult)]),
     "prs_gn_step": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp]),
     "prs_gn_step_ex": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_int32, _vp]),
+    "prs_selftest_reciprocal": (C.c_int, [_vp, _vp]),
     "prs_info_scale_from_nopt": (None, [_vp, C.c_int32, _vp]),
     "prs_triangulate": (C.c_int, [_vp, C.POINTER(TriangulatorParams), _vp, C.c_int32, _vp, _vp]),
     "prs_triangulate_dev": (C.c_int, [_vp, C.POINTER(TriangulatorParams), _vp, C.c_int64, _vp]),

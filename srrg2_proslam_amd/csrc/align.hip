@@ -2712,6 +2712,34 @@ bool align_job_active(const prs_context* ctx) {
   return job && job->active;
 }
 
+// prs_selftest_reciprocal: all 2^32 operands through recip_exact as the kernels above use it
+__global__ __launch_bounds__(256) void recip_selftest_kernel(unsigned long long* counts) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  unsigned long long differ = 0, fast = 0;
+  for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+    const float x  = __uint_as_float((uint32_t) i);
+    const float ax = __builtin_fabsf(x);
+    const bool short_form = __ballot(!(ax >= 0x1p-126f && ax < 0x1p126f)) == 0ull;  // (the test recip_exact makes)
+    const uint32_t got = __float_as_uint(recip_exact(x)), want = __float_as_uint(1.0f / x);
+    const bool both_nan = (got & 0x7fffffffu) > 0x7f800000u && (want & 0x7fffffffu) > 0x7f800000u;
+    differ += (got != want && !both_nan) ? 1ull : 0ull;
+    fast += short_form ? 1ull : 0ull;
+  }
+  if (differ) {
+    atomicAdd(&counts[0], differ);
+  }
+  atomicAdd(&counts[1], fast);
+}
+
+int recip_selftest_launch(prs_context* ctx, unsigned long long* d_counts) {
+  hipLaunchKernelGGL(recip_selftest_kernel, dim3(256 * 32), dim3(256), 0, ctx_stream(ctx), d_counts);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    return ctx_fail_hip(ctx, e, "prs_selftest_reciprocal launch");
+  }
+  return PRS_OK;
+}
+
 int gn_step_launch(prs_context* ctx, const float* dH, const float* db, float damping, int damping_form, float* dX, int* dok) {
   hipLaunchKernelGGL(gn_step_kernel, dim3(1), dim3(1), 0, ctx_stream(ctx), dH, db, damping, damping_form == PRS_DAMPING_IDENTITY ? 1 : 0, dX, dok);
   hipError_t e = hipGetLastError();

@@ -414,6 +414,37 @@ int prs_gn_step(prs_context* ctx, const float* H36, const float* b6, float dampi
   return prs_gn_step_ex(ctx, H36, b6, damping, PRS_DAMPING_DIAG, X16);
 }
 
+int prs_selftest_reciprocal(prs_context* ctx, uint64_t counts[2]) {
+  if (!ctx || !counts) {
+    return PRS_ERR_NULL;
+  }
+  (void) hipSetDevice(ctx->device);
+  unsigned long long* d = static_cast<unsigned long long*>(prs::ctx_device_scratch_slot(ctx, 2, 512));
+  if (!d) {
+    return prs::ctx_fail(ctx, PRS_ERR_HIP, "prs_selftest_reciprocal: scratch allocation failed");
+  }
+  hipStream_t s = ctx->stream;
+  hipError_t e  = hipMemsetAsync(d, 0, 2 * sizeof(unsigned long long), s);
+  if (e != hipSuccess) {
+    return prs::ctx_fail_hip(ctx, e, "prs_selftest_reciprocal");
+  }
+  const int rc = prs::recip_selftest_launch(ctx, d);
+  if (rc != PRS_OK) {
+    return rc;
+  }
+  unsigned long long h[2] = {0, 0};
+  e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) {
+    e = hipStreamSynchronize(s);
+  }
+  if (e != hipSuccess) {
+    return prs::ctx_fail_hip(ctx, e, "prs_selftest_reciprocal download");
+  }
+  counts[0] = h[0];
+  counts[1] = h[1];
+  return PRS_OK;
+}
+
 int prs_gn_step_ex(prs_context* ctx, const float* H36, const float* b6, float damping, int32_t damping_form, float* X16) {
   if (!ctx || !H36 || !b6 || !X16) {
     return PRS_ERR_NULL;

@@ -82,6 +82,7 @@ int align_batch_finish(prs_context* ctx);
 int align_batch_rearm(prs_context* ctx, hipStream_t replay_stream);
 bool align_job_active(const prs_context* ctx);
 int gn_step_launch(prs_context* ctx, const float* dH, const float* db, float damping, int damping_form, float* dX, int* dok);
+int recip_selftest_launch(prs_context* ctx, unsigned long long* d_counts);
 int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* params, const prs_bruteforce_batch* batch);
 int selection_order_launch(prs_context* ctx, const uint8_t* response_dev, int n, int32_t* order_dev, int32_t* status_dev);
 int extract_features_launch(prs_context* ctx, const prs_extractor_params* params, const prs_extract_batch* batch);

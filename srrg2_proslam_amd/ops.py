@@ -857,6 +857,14 @@ def extract_features(ctx, params, image, capacity=4096):
     return uv[:k].copy(), inten[:k].copy(), desc[:k].copy()
 
 
+def selftest_reciprocal(ctx):
+    """(operands that differ from 1.0f / x, operands that took the short form) over all 2^32 float bit patterns (prs_selftest_reciprocal)"""
+    counts = np.zeros(2, dtype=np.uint64)
+    rc = _lib.load().prs_selftest_reciprocal(ctx._h, _p(counts))
+    _check(ctx, rc, "prs_selftest_reciprocal")
+    return int(counts[0]), int(counts[1])
+
+
 def selection_order(ctx, response):
     """responses (1..255) of one region's keypoints in detection order -> the permutation the reference's std::sort leaves
     (order[k] = keypoint at position k; intensity_feature_extractor_binned.cpp:182-186); host arrays, synchronises"""
