@@ -1018,7 +1018,9 @@ def main():
         "flop_per_correspondence_iteration": FLOP_PER_CORRESPONDENCE,
         "counter_gbps": (evidence["gn"] / (ms_gn * 1e-3) / 1e9) if evidence and ms_gn > 0 else None,
         "note": "fp32 vector arithmetic, no MFMA: 6x6 normal equations are not a dense contraction; the kernel is bound by vector issue "
-                "(SQ_ACTIVE_INST_VALU = 1.02 of a SIMD's wave cycles / 4, profiles/r04/align_pmc.txt), frac prices only the algorithmic flops",
+                "(SQ_INSTS_VALU per launch / (launch cycles x CUs) = 1.07 vector instructions per cycle and CU, profiles/r05/rocprof_summary.json "
+                "pmc_sq2; round 5 took the IEEE reciprocals of the iteration to v_rcp_f32 + one Newton step where all 2^32 operands show it equal, "
+                "tests/test_reciprocal_gpu.py), frac prices only the algorithmic flops",
     }
     roof_match = {
         "kernel": "stereo_match5_kernel<%d> (the kernel BASELINE.json north_star prices; matcher + fused adaptor / triangulator epilogue)" % (1 if N <= 1024 else 2),
