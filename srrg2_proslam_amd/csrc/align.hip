@@ -34,6 +34,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 namespace prs {
@@ -103,7 +104,7 @@ struct AlignArgs {
   uint32_t off_db, off_inv, off_cellstart, off_cfix, off_cmov, off_cls, off_sh;  // persistent for the whole frame loop
   const float* prior_mean;  // optional [batch][16]: mean of the motion prior (NULL = identity)
   uint32_t off_u;                                              // phase-exclusive union region:
-  uint32_t off_fdesc, off_fuv, off_best, off_second, off_lut;  //   search phase (relative to the LDS base)
+  uint32_t off_fdesc, off_fuv, off_best, off_second, off_lut, off_surv;  //   search phase (relative to the LDS base)
   uint32_t off_terms;                                          //   GN phase / database build / disparity column
 };
 
@@ -545,10 +546,14 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
   float4* cmov        = reinterpret_cast<float4*>(smem + g.off_cmov);      // per-correspondence moving point + information scale
   au32x4* fdesc       = reinterpret_cast<au32x4*>(smem + g.off_fdesc);    // fixed descriptor rows (search phase only): first halves of all rows, then second halves
   au32x4* fdesc_hi    = fdesc + g.max_fixed;                               // (16-byte stride: a gather of first halves spreads over all 32 LDS banks; 32-byte rows hit 16)
+  // Lattice patterns keep the rows in LATTICE order (row of db[pos] at fdesc[pos]): the scan reads an entry and its half row
+  // with two independent LDS reads instead of entry -> fixed index -> row.  The KD-tree finder keeps them in fixed-index order.
   float2* fuv         = reinterpret_cast<float2*>(smem + g.off_fuv);      // fixed (u,v) in index order (KD-tree variant)
   uint32_t* bestkey   = reinterpret_cast<uint32_t*>(smem + g.off_best);
   uint32_t* second    = reinterpret_cast<uint32_t*>(smem + g.off_second);
   uint16_t* lut       = reinterpret_cast<uint16_t*>(smem + g.off_lut);
+  constexpr int kSurvivors = 4;                                            // survivors of the irrelevance bound a query may park (lattice scan)
+  uint16_t* surv      = reinterpret_cast<uint16_t*>(smem + g.off_surv) + kSurvivors * tid;
   float* terms        = reinterpret_cast<float*>(smem + g.off_terms);     // aliases the search-phase arrays
   uint8_t* clsbuf     = smem + g.off_cls;                                  // factor class per correspondence (last linearisation)
   AlignShared& sh     = *reinterpret_cast<AlignShared*>(smem + g.off_sh);
@@ -561,7 +566,6 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
   if (split_search && (ctl->done || !ctl->need_search)) {
     return;  // this frame does not wait for a search (block-uniform)
   }
-  float4* gops = split_search ? g.ops + (size_t) frame * (size_t) g.max_fixed * 2 : nullptr;
 
   // ---- load the persistent state ---------------------------------------------------------------
   if (tid < 16) {
@@ -1152,10 +1156,18 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
             bestkey[i] = kNoneU32;
             second[i]  = kNoneU32;
           }
-          for (int i = tid; i < 2 * nF; i += T) {
-            (i & 1 ? fdesc_hi : fdesc)[i >> 1] = gfd[i];  // coalesced 16 B/lane; the rows are re-read ~10x per query from LDS
-          }
-          if (!lattice) {
+          if (lattice) {
+            // rows in lattice order (the entry at db[pos] owns fdesc[pos] / fdesc_hi[pos]); the fixed cloud of the stereo adaptor is
+            // row-sorted like the cells, so neighbouring positions read neighbouring rows
+            for (int pos = tid; pos < nF; pos += T) {
+              const int fi  = (int) (db[pos].y & 0xffffu);
+              fdesc[pos]    = gfd[2 * fi];
+              fdesc_hi[pos] = gfd[2 * fi + 1];
+            }
+          } else {
+            for (int i = tid; i < 2 * nF; i += T) {
+              (i & 1 ? fdesc_hi : fdesc)[i >> 1] = gfd[i];  // coalesced 16 B/lane
+            }
             for (int i = tid; i < nF; i += T) {
               const float4 c = gfix[i];
               fuv[i]         = make_float2(c.x, c.y);
@@ -1304,12 +1316,37 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                 // the lattice scan: two entries per trip (the entry behind the last one of a segment is read but not used).  ONE loop over
                 // the entries of all cell rows of the query: a lane that has finished a cell row's segment moves on to the next row
                 // while its neighbours are still inside theirs, so a wave makes max over lanes of (sum over rows) trips instead of
-                // sum over rows of (max over lanes) -- the segments hold 3 +- 2 entries, which nearly halves the trips
-                auto scan = [&](auto accepts, auto visit) {
+                // sum over rows of (max over lanes) -- the segments hold 3 +- 2 entries, which nearly halves the trips.
+                // Round 6 (the kernel issues 0.84 vector instructions per cycle and CU: only their number counts).  With the
+                // irrelevance bound on, a trip reads the two HALF ROWS only (one LDS round trip, the address depends on the position
+                // alone) and compares their distances with the bound; the entry itself -- row, column, indices -- and the pattern test
+                // are looked at for the survivors only (a true match and next to nothing else: 1.4 % of the scanned entries).  The
+                // set of candidates that reach the full score is the same as with the pattern test first: both tests are conjuncts.
+                const bool lean_circle = stype == PRS_SEARCH_CIRCLE && circle_exact;
+                auto score_at = [&](const int p) {  // full distance of the entry at lattice position p
+                  const uint32_t ey = db[p].y;       // fixed index | canonical lattice position << 16
+                  const uint32_t d  = (uint32_t) hamming_regs(fdesc[p], fdesc_hi[p], q0, q1);
+                  // best / second best (circle_impl.cpp:64-72) as min / second-min of unique keys
+                  const uint32_t key = (d << 16) | (ey >> 16);
+                  const uint32_t hi  = key > bestk ? key : bestk;
+                  seck               = hi < seck ? hi : seck;
+                  bestk              = key < bestk ? key : bestk;
+                };
+                typedef __attribute__((address_space(3))) unsigned char lds_byte;
+                const uint32_t fd_lds = (uint32_t) (uintptr_t) (lds_byte*) fdesc;  // LDS byte offset of the half rows
+                // (PRUNED as a compile-time flag: the loop body is one basic block up to the rare survivor.)  Survivors of the
+                // irrelevance bound go to this thread's four LDS slots (lattice positions); the only loop-carried register they touch
+                // is their count, which the straight line updates: a survivor kept in registers -- with the pattern test and the full
+                // score of an evicted one inside the loop -- made the compiler copy best / second best / survivors around every trip.
+                // Pattern test + full score after the scan; a fifth survivor (never on random rows) sends the query through the
+                // unpruned scan instead.
+                auto scan = [&](auto accepts, auto pruned_tag) {
+                  constexpr bool PRUNED = decltype(pruned_tag)::value;
                   const uint16_t* cs = cellstart + (r0 >> g.cell_sy) * g.cell_ncx + cx0;  // bounds of the next cell row's segment
                   const int width    = cx1 + 1 - cx0;
                   int rows_left      = (r1 >> g.cell_sy) - (r0 >> g.cell_sy) + 1;
                   int pos = 0, seg1 = 0;
+                  int n_surv = 0;
                   for (;;) {
                     if (pos >= seg1) {
                       if (rows_left <= 0) {
@@ -1321,60 +1358,57 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                       --rows_left;
                     }
                     if (pos < seg1) {
-                      // (whole entries at once: the fixed index of an accepted entry must not be a second, dependent LDS read)
-                      const unsigned long long wa = reinterpret_cast<const unsigned long long*>(db)[pos];
-                      const unsigned long long wb = reinterpret_cast<const unsigned long long*>(db)[pos + 1];
-                      const uint2 ea = make_uint2((uint32_t) wa, (uint32_t) (wa >> 32)), eb = make_uint2((uint32_t) wb, (uint32_t) (wb >> 32));
-                      const bool in_a = accepts(ea);
-                      const bool in_b = (pos + 1 < seg1) & accepts(eb);
-                      if (in_a) {
-                        visit(ea.y);
-                      }
-                      if (in_b) {
-                        visit(eb.y);
+                      if (PRUNED) {
+                        // (the two reads back to back behind one wait; the half row behind the last entry of a segment is read, not used)
+                        au32x4 la, lb;
+                        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(la), "=&v"(lb)
+                                     : "v"(fd_lds + 16u * (uint32_t) pos));
+                        const bool hit_a = hamming_half(la, q0) < prune_at;
+                        const bool hit_b = (pos + 1 < seg1) & (hamming_half(lb, q0) < prune_at);
+                        if (hit_a) {
+                          surv[n_surv < kSurvivors ? n_surv : kSurvivors - 1] = (uint16_t) pos;
+                        }
+                        n_surv += hit_a ? 1 : 0;
+                        if (hit_b) {
+                          surv[n_surv < kSurvivors ? n_surv : kSurvivors - 1] = (uint16_t) (pos + 1);
+                        }
+                        n_surv += hit_b ? 1 : 0;
+                      } else {
+                        const unsigned long long wa = reinterpret_cast<const unsigned long long*>(db)[pos];
+                        const unsigned long long wb = reinterpret_cast<const unsigned long long*>(db)[pos + 1];
+                        const uint2 ea = make_uint2((uint32_t) wa, (uint32_t) (wa >> 32)), eb = make_uint2((uint32_t) wb, (uint32_t) (wb >> 32));
+                        const bool in_a = accepts(ea);
+                        const bool in_b = (pos + 1 < seg1) & accepts(eb);
+                        if (in_a) {
+                          score_at(pos);
+                        }
+                        if (in_b) {
+                          score_at(pos + 1);
+                        }
                       }
                       pos += 2;
                     }
                   }
+                  return n_surv;
                 };
-                const bool lean_circle = stype == PRS_SEARCH_CIRCLE && circle_exact;
-                auto score = [&](const uint32_t ey) {  // ey: fixed index | canonical lattice position << 16
-                  const int fi     = (int) (ey & 0xffffu);
-                  const uint32_t d = (uint32_t) hamming_regs(fdesc[fi], fdesc_hi[fi], q0, q1);
-                  // best / second best (circle_impl.cpp:64-72) as min / second-min of unique keys
-                  const uint32_t key = (d << 16) | (ey >> 16);
-                  const uint32_t hi  = key > bestk ? key : bestk;
-                  seck               = hi < seck ? hi : seck;
-                  bestk              = key < bestk ? key : bestk;
+                auto scan_pattern = [&](auto pruned_tag) {
+                  return lean_circle ? scan(accepts_circle, pruned_tag) : scan(accepts_any, pruned_tag);
                 };
                 if (prune_at > 0) {
-                  // first half of the descriptor only; the few candidates whose partial distance stays below the
-                  // irrelevance bound (irrelevant_distance) are remembered and scored in full after the scan
-                  uint32_t kept = 0xffffffffu;  // canonical lattice positions of up to two such candidates (0xffff: none)
-                  auto prescore = [&](const uint32_t ey) {
-                    if (hamming_half(fdesc[(int) (ey & 0xffffu)], q0) < prune_at) {
-                      const uint32_t evicted = kept >> 16;
-                      if (evicted != 0xffffu) {
-                        score((uint32_t) inv[evicted] | (evicted << 16));
-                      }
-                      kept = (kept << 16) | (ey >> 16);
-                    }
-                  };
-                  if (lean_circle) {
-                    scan(accepts_circle, prescore);
+                  const int n_surv = scan_pattern(std::true_type{});
+                  if (n_surv > kSurvivors) {
+                    scan_pattern(std::false_type{});  // (nothing has been scored yet)
                   } else {
-                    scan(accepts_any, prescore);
+                    for (int i = 0; i < n_surv; ++i) {
+                      const int p = (int) surv[i];
+                      if (lean_circle ? accepts_circle(db[p]) : accepts_any(db[p])) {
+                        score_at(p);
+                      }
+                    }
                   }
-                  if ((kept & 0xffffu) != 0xffffu) {
-                    score((uint32_t) inv[kept & 0xffffu] | (kept << 16));
-                  }
-                  if ((kept >> 16) != 0xffffu) {
-                    score((uint32_t) inv[kept >> 16] | (kept & 0xffff0000u));
-                  }
-                } else if (lean_circle) {
-                  scan(accepts_circle, score);
                 } else {
-                  scan(accepts_any, score);
+                  scan_pattern(std::false_type{});
                 }
               }
               if (bestk != kNoneU32) {  // circle_impl.cpp:78-92 / kdtree_impl.cpp:72-78 (best only)
@@ -1510,10 +1544,9 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
             if (g.mode == PRS_MODE_ALIGN) {
               cfix[slot] = gfix[f];
               cmov[slot] = gmov[m];
-            } else if (split_search) {
-              gops[2 * slot]     = gfix[f];
-              gops[2 * slot + 1] = gmov[m];
             }
+            // (split pipeline: the Gauss-Newton kernel gathers its operand rows through the correspondence vector itself;
+            // round 5 wrote them here, 32 B per correspondence and search, behind two gathers that missed the L2)
           }
         }
         __syncthreads();
@@ -2065,26 +2098,42 @@ __global__ __launch_bounds__(128, WAVES) void gn_kernel(const AlignArgs g) {
   float4* lz = reinterpret_cast<float4*>(smem + ((sizeof(GnShared) + 15) / 16) * 16);
   constexpr int LROWS = SLOTS <= kGnLdsSlots ? SLOTS * THREADS : kGnLdsRows;  // rows parked in LDS
   float4* lp = lz + LROWS;
+  // Round 6: the rows are GATHERED here through the correspondence vector the search kernel committed (fixed measurement of
+  // fixed_idx, moving point + information scale of moving_idx): the search kernel no longer writes 32 B per correspondence that
+  // this kernel read back, and its own two gathers are gone with them.
+  const size_t fbase = (size_t) frame * (size_t) g.b.fixed_stride;
+  const prs_corr* __restrict__ gcorr_in = g.b.corr + fbase;
+  const float4* __restrict__ gfix       = reinterpret_cast<const float4*>(g.b.fixed) + fbase;
+  const float4* __restrict__ gmov       = reinterpret_cast<const float4*>(g.b.moving) + (size_t) frame * (size_t) g.b.moving_stride;
 #pragma unroll
   for (int k = 0; k < LS + 1; ++k) {
     const int c = k * THREADS + tid;
     if (k * THREADS < nc && c < LROWS) {
-      float4 z = c < nc ? gops[2 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
-      z.w      = parked_translation_weight(g.a, z, mean_dsp, DIM != 0 ? 0 : g.a.translation_weight_form);  // (the factors read x, y, z of the measurement only)
-      lz[c]    = z;
-      lp[c]    = c < nc ? gops[2 * c + 1] : make_float4(0.f, 0.f, 1.f, 1.f);
+      float4 z = make_float4(0.f, 0.f, 0.f, 0.f), p = make_float4(0.f, 0.f, 1.f, 1.f);
+      if (c < nc) {
+        const int fi = gcorr_in[c].fixed_idx, mi = gcorr_in[c].moving_idx;
+        z            = gfix[fi];
+        p            = gmov[mi];
+      }
+      z.w   = parked_translation_weight(g.a, z, mean_dsp, DIM != 0 ? 0 : g.a.translation_weight_form);  // (the factors read x, y, z of the measurement only)
+      lz[c] = z;
+      lp[c] = p;
     }
   }
-  // rows beyond the parked ones are streamed from global memory at every iteration: their translation weight goes into the fourth
-  // component of the measurement THERE, once per launch (no factor reads that component; the same thread reads the row back)
+  // rows beyond the parked ones are streamed from global memory at every iteration: gathered once per launch into this frame's
+  // operand rows, the translation weight in the fourth component of the measurement (no factor reads that component; the same
+  // thread reads the row back)
   if (SLOTS > kGnLdsSlots) {
     float4* wops = g.ops + (size_t) frame * (size_t) g.max_fixed * 2;
 #pragma unroll
     for (int k = LS; k < SLOTS; ++k) {
       const int c = k * THREADS + tid;  // (the thread that reads row c back in pass k)
       if (c >= LROWS && c < nc) {
-        const float4 z = wops[2 * c];
-        wops[2 * c].w  = parked_translation_weight(g.a, z, mean_dsp, DIM != 0 ? 0 : g.a.translation_weight_form);
+        const int fi    = gcorr_in[c].fixed_idx, mi = gcorr_in[c].moving_idx;
+        float4 z        = gfix[fi];
+        z.w             = parked_translation_weight(g.a, z, mean_dsp, DIM != 0 ? 0 : g.a.translation_weight_form);
+        wops[2 * c]     = z;
+        wops[2 * c + 1] = gmov[mi];
       }
     }
   }
@@ -2464,6 +2513,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
     g.off_best   = u; u = align_up16(u + nf * 4);
     g.off_second = u; u = align_up16(u + nf * 4);
     g.off_lut    = u; u = align_up16(u + lut_cap * 2);
+    g.off_surv   = u; u = align_up16(u + (uint32_t) (with_operands ? kAlignThreads : kSearchThreads) * 4 * 2);  // kSurvivors x u16 per thread
     // GN-phase terms; the region also serves the database build (hist + slot + bucket) and the disparity column
     g.off_terms = off;
     uint32_t terms_bytes       = kTerms * kAlignThreads * 4;
