@@ -150,6 +150,15 @@ __device__ __forceinline__ int hamming_half(const au32x4& a0, const au32x4& b0) 
   d = popc_acc(a0.w ^ b0.w, d);
   return (int) d;
 }
+// the first 96 bits only: what the lattice scan compares with the irrelevance bound.  ANY partial distance that reaches the bound
+// proves the candidate irrelevant; 96 bits of unrelated rows differ in 48 +- 5, so a bound of <= 36 still rejects all but ~1 %
+// of them at three quarters of the instructions
+__device__ __forceinline__ int hamming_96(const au32x4& a0, const au32x4& b0) {
+  uint32_t d = (uint32_t) __popc(a0.x ^ b0.x);
+  d = popc_acc(a0.y ^ b0.y, d);
+  d = popc_acc(a0.z ^ b0.z, d);
+  return (int) d;
+}
 
 // _filterCorrespondences accepts a fixed point's best candidate when response < dd and response / second-lowest < ratio
 // (correspondence_finder_projective_base_impl.cpp:57-99).  A candidate whose descriptor distance is >= B, B the smallest
@@ -1364,8 +1373,8 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                         asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
                                      : "=&v"(la), "=&v"(lb)
                                      : "v"(fd_lds + 16u * (uint32_t) pos));
-                        const bool hit_a = hamming_half(la, q0) < prune_at;
-                        const bool hit_b = (pos + 1 < seg1) & (hamming_half(lb, q0) < prune_at);
+                        const bool hit_a = hamming_96(la, q0) < prune_at;
+                        const bool hit_b = (pos + 1 < seg1) & (hamming_96(lb, q0) < prune_at);
                         if (hit_a) {
                           surv[n_surv < kSurvivors ? n_surv : kSurvivors - 1] = (uint16_t) pos;
                         }
@@ -2045,6 +2054,21 @@ __global__ __launch_bounds__(128, WAVES) void gn_kernel(const AlignArgs g) {
   const int solver = frame & 1;
   const int stid   = tid - 64 * solver;  // 0..63 on the solving wave
   FrameCtl* ctl    = g.ctl + frame;
+  // Round 6: the operand rows are gathered through the correspondence vector the search kernel committed.  The index pairs of this
+  // thread's rows are requested before anything else -- together with the control word and the count, which say whether and how
+  // many of them mean something (every slot below fixed_stride is addressable) -- so that the gather is the second trip to memory
+  // of a launch, as the coalesced operand rows of round 5 were.
+  constexpr int LS_IDX = (SLOTS < LDS_SLOTS ? SLOTS : LDS_SLOTS) + 1;
+  const size_t fbase                    = (size_t) frame * (size_t) g.b.fixed_stride;
+  const prs_corr* __restrict__ gcorr_in = g.b.corr + fbase;
+  int fi[LS_IDX], mi[LS_IDX];
+#pragma unroll
+  for (int k = 0; k < LS_IDX; ++k) {
+    const int c  = k * 128 + tid;
+    const int cc = c < g.b.fixed_stride ? c : 0;
+    fi[k]        = gcorr_in[cc].fixed_idx;
+    mi[k]        = gcorr_in[cc].moving_idx;
+  }
   if (ctl->done || ctl->need_search) {
     return;  // finished, or waiting for the search kernel (block-uniform)
   }
@@ -2101,23 +2125,26 @@ __global__ __launch_bounds__(128, WAVES) void gn_kernel(const AlignArgs g) {
   // Round 6: the rows are GATHERED here through the correspondence vector the search kernel committed (fixed measurement of
   // fixed_idx, moving point + information scale of moving_idx): the search kernel no longer writes 32 B per correspondence that
   // this kernel read back, and its own two gathers are gone with them.
-  const size_t fbase = (size_t) frame * (size_t) g.b.fixed_stride;
-  const prs_corr* __restrict__ gcorr_in = g.b.corr + fbase;
-  const float4* __restrict__ gfix       = reinterpret_cast<const float4*>(g.b.fixed) + fbase;
-  const float4* __restrict__ gmov       = reinterpret_cast<const float4*>(g.b.moving) + (size_t) frame * (size_t) g.b.moving_stride;
+  const float4* __restrict__ gfix = reinterpret_cast<const float4*>(g.b.fixed) + fbase;
+  const float4* __restrict__ gmov = reinterpret_cast<const float4*>(g.b.moving) + (size_t) frame * (size_t) g.b.moving_stride;
+  if (nc > 0) {
+    static_assert(LS_IDX == LS + 1, "index pairs of the parked rows");
+    float4 zr[LS + 1], pr[LS + 1];
 #pragma unroll
-  for (int k = 0; k < LS + 1; ++k) {
-    const int c = k * THREADS + tid;
-    if (k * THREADS < nc && c < LROWS) {
-      float4 z = make_float4(0.f, 0.f, 0.f, 0.f), p = make_float4(0.f, 0.f, 1.f, 1.f);
-      if (c < nc) {
-        const int fi = gcorr_in[c].fixed_idx, mi = gcorr_in[c].moving_idx;
-        z            = gfix[fi];
-        p            = gmov[mi];
+    for (int k = 0; k < LS + 1; ++k) {
+      const bool live = k * THREADS + tid < nc;  // (rows past the end read point 0 of both clouds: what their slots hold is not an index)
+      zr[k]           = gfix[live ? fi[k] : 0];
+      pr[k]           = gmov[live ? mi[k] : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < LS + 1; ++k) {
+      const int c = k * THREADS + tid;
+      if (k * THREADS < nc && c < LROWS) {
+        float4 z = c < nc ? zr[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        z.w      = parked_translation_weight(g.a, z, mean_dsp, DIM != 0 ? 0 : g.a.translation_weight_form);  // (the factors read x, y, z of the measurement only)
+        lz[c]    = z;
+        lp[c]    = c < nc ? pr[k] : make_float4(0.f, 0.f, 1.f, 1.f);
       }
-      z.w   = parked_translation_weight(g.a, z, mean_dsp, DIM != 0 ? 0 : g.a.translation_weight_form);  // (the factors read x, y, z of the measurement only)
-      lz[c] = z;
-      lp[c] = p;
     }
   }
   // rows beyond the parked ones are streamed from global memory at every iteration: gathered once per launch into this frame's
@@ -2196,8 +2223,11 @@ __global__ __launch_bounds__(128, WAVES) void gn_kernel(const AlignArgs g) {
               z = lz[c];
               p = lp[c];
             } else {
-              z   = c < nc ? gops[2 * c] : make_float4(0.f, 0.f, 0.f, 1.f);
-              p   = c < nc ? gops[2 * c + 1] : make_float4(0.f, 0.f, 1.f, 1.f);
+              // (an opaque copy of the row number: the addresses of the streamed rows are formed here, not kept -- spilled -- across
+              // the iteration loop of the frames that never stream a row)
+              const int cs = cold_copy(c);
+              z   = c < nc ? gops[2 * cs] : make_float4(0.f, 0.f, 0.f, 1.f);
+              p   = c < nc ? gops[2 * cs + 1] : make_float4(0.f, 0.f, 1.f, 1.f);
             }
             int cls;
             factor_accumulate<DIM, true>(g.a, pose, z, p, mean_dsp, c < nc, acc, code, cls, inlier_run);
