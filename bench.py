@@ -435,6 +435,151 @@ def small_config_leg(name, cfg, keypoints, moving, max_fixed, batch, device_inde
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# the rows SURVEY 8 marks "next" (f1-f4), each with its own roofline object in the driver-run line
+# ---------------------------------------------------------------------------------------------------------------------
+I8_MFMA_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2 x the dense BF16 rate (~2.5 PF)
+
+
+def f_rows_leg():
+    """f1 merger + landmark estimators, f2 scene clipper, f3 feature extraction, f4 brute-force matcher: one launch shape each (the
+    shapes of tools/bench_{merge,clip,features,bruteforce}.py), inputs resident in HBM, time = HIP events around the operator's
+    launches on the launch stream, algorithmic bytes / operations as defined beside each figure."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_bruteforce
+    import bench_clip
+    import bench_features
+    import bench_merge
+    from srrg2_proslam_amd import ops
+    out = {}
+
+    def hbm(achieved_gbps, extra):
+        d = {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": None}
+        d.update(extra)
+        return d
+
+    try:
+        rows = [bench_merge.run(2048, 704, 2000, est, name, quiet=True) for est, name in
+                ((ops.EST_SMOOTHER, "pose-based smoother (kitti.conf)"), (ops.EST_WEIGHTED_MEAN, "weighted mean"), (ops.EST_EKF, "stereo EKF (f64)"))]
+        out["roofline_f1"] = hbm(rows[0]["gbps"], {
+            "kernel": "merge_kernel + smoother_kernel + tail (MergerCorrespondenceProjective + LandmarkEstimatorPoseBasedSmoother, kitti.conf; one frame of 704 "
+                      "measurements into a 2000-point map per launch and map)",
+            "ms_per_launch": rows[0]["ms_per_launch"], "frames_per_s": rows[0]["frames_per_s"], "algorithmic_bytes_per_launch": rows[0]["algorithmic_bytes_per_launch"],
+            "algorithmic_bytes": "48 B per measurement + 12 B per correspondence + 2 x (112 B + 28 B per kept measurement) per merged landmark + 140 B per added one",
+            "estimators": rows,
+            "note": "not bandwidth-bound: the smoother runs up to 100 Gauss-Newton iterations per merged landmark on its measurement history "
+                    "(one lane per landmark, serial), the EKF a 3 x 3 f64 update; frac prices the landmark rows a merge touches"})
+    except (SystemExit, RuntimeError, AssertionError) as exc:
+        out["roofline_f1"] = {"error": str(exc)}
+    try:
+        c = bench_clip.run(2048, 2000, True, quiet=True)
+        c8 = bench_clip.run(2048, 16000, True, quiet=True)
+        out["roofline_f2"] = hbm(c8["gbps"], {
+            "kernel": "scene_clip_kernel (SceneClipperProjective3D::compute: transform, pinhole projection, frustum test, ordered compaction with descriptors)",
+            "ms_per_launch": c8["ms_per_launch"], "algorithmic_bytes_per_launch": c8["algorithmic_bytes_per_launch"],
+            "algorithmic_bytes": "48 B per scene point read (xyzw + 256-bit row) + 52 B per kept point written (+ global index) + 64 B per scene",
+            "shapes": [c, c8],
+            "note": "2048 local maps of 16000 points per launch (the headline figure) and of 2000 points (a KITTI local map; launch-latency share larger)"})
+    except (SystemExit, RuntimeError, AssertionError) as exc:
+        out["roofline_f2"] = {"error": str(exc)}
+    try:
+        f = bench_features.run(4096, "kitti", "libstdcxx", quiet=True)
+        out["roofline_f3"] = hbm(f["gbps"], {
+            "kernel": "fast_blur_kernel + raster_order_kernel + select_describe_kernel + describe_kernel (FAST-9 + NMS, 3 x 3 binned selection in the reference's "
+                      "std::sort order, 7x7 Gaussian on v_mfma_i32_16x16x32_i8, ORB-256)",
+            "ms_per_launch": f["ms_per_launch"], "images_per_s": f["images_per_s"], "algorithmic_bytes_per_launch": f["algorithmic_bytes_per_launch"],
+            "algorithmic_bytes": "the 8-bit image once (1241 x 376) + 44 B per kept feature (keypoint, descriptor, counters)",
+            "detail": f,
+            "note": "bound by vector issue, not by HBM: the tile kernel retires one vector instruction per cycle and CU (profiles/r05/features_pmc.txt); "
+                    "frac prices the pixels and the features only"})
+    except (SystemExit, RuntimeError, AssertionError, OSError) as exc:
+        out["roofline_f3"] = {"error": str(exc)}
+    try:
+        b = bench_bruteforce.run(1024, 2000, 50.0, quiet=True)
+        b1 = bench_bruteforce.run(1024, 1000, 50.0, quiet=True)
+        tops = b["pairs_per_s"] * 512.0 / 1e12
+        out["roofline_f4"] = {
+            "kernel": "bruteforce dense phase + registration (CorrespondenceFinderDescriptorBasedBruteforce::compute: all N_f x N_m Hamming distances, pools by "
+                      "distance, uniqueness, Lowe's ratio on both sides)",
+            "bound": "mfma", "achieved": tops, "peak": I8_MFMA_TOPS, "unit": "TOP/s", "frac": tops / I8_MFMA_TOPS, "traffic": None,
+            "operations_per_descriptor_pair": 512, "descriptor_pairs_per_s": b["pairs_per_s"], "ms_per_launch": b["ms_per_launch"],
+            "shapes": [b, b1],
+            "note": "hamming(a, b) = pop(a) + pop(b) - 2 a.b: the binary dot product of 256-bit rows is 256 multiply-adds = 512 operations per pair, "
+                    "priced against the dense I8 MFMA rate (2 x BF16); includes the registration phases of every cloud pair"}
+    except (SystemExit, RuntimeError, AssertionError) as exc:
+        out["roofline_f4"] = {"error": str(exc)}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a13_alt: the headline step under the OTHER readings of the external srrg2_solver arithmetic (SURVEY 8 rows a13 / a14)
+# ---------------------------------------------------------------------------------------------------------------------
+A13_VARIANTS = (
+    ("shipped", {}, {}),
+    ("damping_identity", {"damping_form": 1}, {"damping_form": 1}),                                # H + lambda I
+    ("kernel_tau_over_chi", {"kernel_weight_form": 1}, {"kernel_form": 1}),                        # Omega * tau / chi
+    ("translation_weight_clamp", {"translation_weight_form": 1}, {"idw_form": 1}),                 # clamp(d / mean, 0.01, 1)
+    ("identity_and_tau_over_chi", {"damping_form": 1, "kernel_weight_form": 1}, {"damping_form": 1, "kernel_form": 1}),
+)
+
+
+def a13_alt_leg(cfg, frames, keypoints, moving, max_fixed, batch, device_index, steps=3, check=4):
+    """What the headline costs under each reading of the un-vendored solver arithmetic that prs_aligner_params exposes
+    (kernel_weight_form, damping_form, translation_weight_form; include/proslam_hip.h): the same frames, the same step, `batch`
+    frames per step; frames/s, searches per frame, per-kernel ms, iterations, and parity of `check` frames against the CPU checker
+    switched to the SAME reading (orc_set_variant).  The damping form sets how far a step moves the pose, hence how many projective
+    searches and Gauss-Newton rounds a frame needs: a maintainer who holds srrg2_solver reads the price of either reading here."""
+    import copy
+    import torch
+    from oracle import binding as ob
+    rows = {}
+    for name, dev_forms, orc_forms in A13_VARIANTS:
+        vcfg = copy.deepcopy(cfg)
+        vcfg["aligner"].update(dev_forms)
+        w = FrameWorkload(vcfg, device_index, batch, keypoints, moving, max_fixed, len(frames), 0, frames=frames)
+        stream = torch.cuda.Stream(device=w.dev)
+        with torch.cuda.stream(stream):
+            w.ctx.use_torch_stream()
+            w.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                w.step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            snap = w.snapshot()
+            ok, it_exec = w.check(snap)
+            kt = w.kernel_times(2)
+        try:
+            ob.set_variant(**orc_forms)
+            _, _, poses = cpu_baseline(vcfg, frames[:check], check)
+        finally:
+            ob.set_variant()  # back to the shipped definition
+        par = w.parity(snap, poses)
+        Xs = snap["X"][:check]
+        rows[name] = {"forms": dev_forms or {"kernel_weight_form": 0, "damping_form": 0, "translation_weight_form": 0},
+                      "value": batch * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3,
+                      "searches_per_frame": snap["searches_per_frame"], "gn_iterations_executed_mean": it_exec,
+                      "ms_per_kernel": {"stereo_match5_kernel": kt["matcher_ms"], "align_kernel (search)": kt["search_ms"], "gn_kernel": kt["gn_ms"]},
+                      "search_ms_by_round": kt["search_ms_by_round"], "gn_ms_by_round": kt["gn_ms_by_round"],
+                      "aligner_correspondences_per_frame": snap["n_corr"], "aligner_success_fraction": ok,
+                      "parity_vs_checker_same_reading": par,
+                      "_X": Xs}
+        w.close()
+        del w
+        torch.cuda.empty_cache()
+    # how far the poses of the readings lie apart (relative Frobenius against the shipped family's pose of the same frame)
+    X0 = rows["shipped"]["_X"]
+    for name, r in rows.items():
+        X = r.pop("_X")
+        r["pose_rel_frobenius_vs_shipped_max"] = float(max(np.linalg.norm(X[i] - X0[i]) / np.linalg.norm(X0[i]) for i in range(len(X0))))
+    return {"frames_per_step": batch, "steps": steps, "readings": rows,
+            "note": "row a13 of SURVEY 8 is external to the reference tree (srrg2_solver): the shipped family is the one that meets all 17 pose "
+                    "bounds of the reference's own tests (tests/test_sweep_a13.py); every other reading is a run-time field of prs_aligner_params, "
+                    "bit-exact against the checker switched the same way (tests/test_a13_forms_gpu.py); the fast Gauss-Newton instantiations carry "
+                    "the shipped forms at compile time, the others run the generic one"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # small batches: what a caller with few sequences gets from the device-resident batch API (between latency_b1 and the headline)
 # ---------------------------------------------------------------------------------------------------------------------
 def small_batch_curve(cfg, frames, keypoints, moving, max_fixed, device_index, batches=(1, 2, 4, 8, 16, 64, 256, 2048), steps=8):
@@ -1137,6 +1282,13 @@ def main():
                 others[name] = small_config_leg(name, configs.get(cname), kp, mv, mf, small, local_rank, syn.seed_for(cidx, 0) + 31)
             except SystemExit as exc:  # a loud per-frame error of a side leg must not take the headline line with it
                 others[name] = {"error": str(exc)}
+        out.update(f_rows_leg())
+        if not args.no_cpu_baseline:
+            try:
+                out["a13_alt"] = a13_alt_leg(cfg, uniq_frames[:13] if uniq_frames is not None else make_unique_frames(cfg, 13, N, NM, syn.seed_for(1, 0)),
+                                             N, NM, args.max_fixed, small, local_rank)
+            except (SystemExit, RuntimeError) as exc:
+                out["a13_alt"] = {"error": str(exc)}
         try:
             out["small_batch"] = small_batch_curve(cfg, uniq_frames if uniq_frames is not None else make_unique_frames(cfg, 13, N, NM, syn.seed_for(1, 0)),
                                                    N, NM, args.max_fixed, local_rank)

@@ -87,6 +87,15 @@ PRS_API int prs_context_get_align_round_timing(prs_context* ctx, double* search_
 PRS_API const char* prs_last_error(const prs_context* ctx);
 PRS_API const char* prs_status_string(int status);
 PRS_API int prs_version(void);
+/* The parameter structs below carry no size field and grow at their END between versions (round 5 added three int32 fields to
+ * prs_aligner_params).  PRS_ABI_VERSION is what this header describes, prs_version() what the loaded library was built from; a
+ * client checks that they agree once (prs_abi_check: also the sizes of the structs it will pass, as the client's compiler laid
+ * them out) instead of finding out through a library that reads past a shorter struct.  Callers memset() parameter structs before
+ * filling them, so that fields they do not know select the shipped defaults (all zero). */
+#define PRS_ABI_VERSION 101
+PRS_API int prs_abi_check(int32_t header_version, uint64_t sizeof_stereo_params, uint64_t sizeof_pcf_params, uint64_t sizeof_aligner_params,
+                          uint64_t sizeof_align_batch);
+#define PRS_ABI_CHECK() prs_abi_check(PRS_ABI_VERSION, sizeof(prs_stereo_params), sizeof(prs_pcf_params), sizeof(prs_aligner_params), sizeof(prs_align_batch))
 
 /* ================================================================================================
  * Stereo epipolar matcher

@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libproslam_oracle.so")
+# PRS_ORACLE_LIB: another build of the same sources (e.g. `make -C oracle san`: AddressSanitizer + UBSan, see tools/run_san.sh)
+_LIB_PATH = os.environ.get("PRS_ORACLE_LIB") or os.path.join(_HERE, "libproslam_oracle.so")
 
 CORR_DTYPE = np.dtype([("fixed_idx", np.int32), ("moving_idx", np.int32), ("response", np.float32)])
 
@@ -141,7 +142,7 @@ def build(force=False):
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc")) or f == "Makefile"]
     stale = force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs)
     if stale:
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libproslam_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(_LIB_PATH)], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 

@@ -86,6 +86,11 @@ using PropertyInt         = Property_<int>;
 class Context {
 public:
   explicit Context(int device = 0) {
+    // the header this adapter was compiled against and the library it loaded must describe the same structs
+    if (PRS_ABI_CHECK() != PRS_OK) {
+      throw std::runtime_error("proslam_hip::Context|ERROR: libproslam_hip.so (version " + std::to_string(prs_version()) +
+                               ") does not match proslam_hip.h (version " + std::to_string(PRS_ABI_VERSION) + "): rebuild the plugin");
+    }
     const int rc = prs_context_create(device, &_ctx);
     if (rc != PRS_OK) throw std::runtime_error(std::string("proslam_hip::Context|ERROR: ") + prs_status_string(rc));
   }

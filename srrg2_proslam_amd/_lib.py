@@ -9,6 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libproslam_hip.so")
+ABI_VERSION = 101  # PRS_ABI_VERSION of include/proslam_hip.h
 
 # status codes (include/proslam_hip.h)
 OK = 0
@@ -268,6 +269,7 @@ _vp = C.c_void_p
 _i32p = C.POINTER(C.c_int32)
 SYMBOLS = {
     "prs_version": (C.c_int, []),
+    "prs_abi_check": (C.c_int, [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
     "prs_status_string": (C.c_char_p, [C.c_int]),
     "prs_context_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "prs_context_destroy": (C.c_int, [_vp]),
@@ -358,5 +360,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
+    # the ctypes mirrors above and the library must describe the same structs (include/proslam_hip.h, PRS_ABI_VERSION)
+    rc = lib.prs_abi_check(ABI_VERSION, C.sizeof(StereoParams), C.sizeof(PcfParams), C.sizeof(AlignerParams), C.sizeof(AlignBatch))
+    if rc != 0:
+        raise ImportError("libproslam_hip.so (version %d) does not match the Python binding (version %d, struct sizes %d/%d/%d/%d): "
+                          "rebuild with `python -c 'import __graft_entry__ as g; g.build()'`"
+                          % (lib.prs_version(), ABI_VERSION, C.sizeof(StereoParams), C.sizeof(PcfParams), C.sizeof(AlignerParams), C.sizeof(AlignBatch)))
     _lib = lib
     return lib

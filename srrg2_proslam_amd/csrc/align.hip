@@ -2412,7 +2412,8 @@ struct SplitJob {
   // brute-force matcher, merger), and a caller may run any of them between the two halves.  Grow-only; freed with the context.
   void* own[3]        = {nullptr, nullptr, nullptr};
   size_t own_bytes[3] = {0, 0, 0};
-  hipStream_t stream  = nullptr;  // the stream the rounds were enqueued on (finish synchronises this one)
+  hipStream_t stream  = nullptr;  // the stream the rounds run on: where they were enqueued, or where the captured graph was last replayed (finish synchronises this one)
+  hipStream_t capture_stream = nullptr;  // the stream align_batch_launch enqueued / captured on (what a rearm without a stream goes back to)
   ~SplitJob() {
     for (void* p : own) {
       if (p) {
@@ -2663,6 +2664,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   // synchronisation here, the sequence can be captured in a HIP graph once the scratch buffers exist).
   job->active      = true;
   job->stream      = stream;
+  job->capture_stream = stream;
   job->g           = g;
   job->gs          = gs;
   job->search      = reinterpret_cast<void (*)(AlignArgs)>(skernel);
@@ -2777,9 +2779,7 @@ int align_batch_rearm(prs_context* ctx, hipStream_t replay_stream) {
   if (job->active) {
     return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_rearm: the previous batch has not been finished");
   }
-  if (replay_stream) {
-    job->stream = replay_stream;
-  }
+  job->stream       = replay_stream ? replay_stream : job->capture_stream;  // (NULL: back to the capture stream, whatever the last replay used)
   job->active       = true;
   job->total        = job->enqueued;  // the rounds the captured enqueue holds
   job->ev_used      = 0;

@@ -148,7 +148,17 @@ using namespace prs;
 extern "C" {
 
 int prs_version(void) {
-  return 100;  // 0.1.0
+  return PRS_ABI_VERSION;  // 0.1.1: prs_aligner_params grew by three fields in round 5 (kernel_weight_form, damping_form, translation_weight_form)
+}
+
+int prs_abi_check(int32_t header_version, uint64_t sizeof_stereo_params, uint64_t sizeof_pcf_params, uint64_t sizeof_aligner_params,
+                  uint64_t sizeof_align_batch) {
+  // (no context: the answer is the status alone)
+  if (header_version != PRS_ABI_VERSION || sizeof_stereo_params != sizeof(prs_stereo_params) || sizeof_pcf_params != sizeof(prs_pcf_params) ||
+      sizeof_aligner_params != sizeof(prs_aligner_params) || sizeof_align_batch != sizeof(prs_align_batch)) {
+    return PRS_ERR_UNSUPPORTED;
+  }
+  return PRS_OK;
 }
 
 const char* prs_status_string(int status) {

@@ -17,8 +17,10 @@ namespace prs {
 // the compiler's expansion (v_div_scale x 2, v_rcp, 4 x v_fma, v_div_fmas, v_div_fixup).  tools/probes/rcp_exact_probe.hip runs ALL 2^32
 // bit patterns on gfx950: v_rcp_f32 followed by ONE Newton step in fused multiply-adds equals the IEEE quotient for every x whose biased
 // exponent is 1 .. 252 (2^-126 <= |x| < 2^126; both signs, every mantissa); zeros, denormals, the two largest binades (denormal
-// quotients), infinities and NaNs differ.  A wave that holds such an operand takes the compiler's division instead (never, on
-// the values the aligner divides by: depths and chi-squares).
+// quotients), infinities and NaNs differ.  A wave that holds such an operand takes the compiler's division instead: the depths and
+// chi-squares of live correspondences never are, but the stand-in rows of a partially filled wave and of points behind the camera
+// carry chi = 0, so those waves take the long form (same bits).  Feeding the unread lanes a benign operand was measured slower
+// (round 5: 13.54 / 13.64 ms against 13.34 / 13.38: the select costs every wave what the long form costs a few).
 __device__ __forceinline__ float recip_exact(const float x) {
   const float ax  = __builtin_fabsf(x);
   const bool plain = ax >= 0x1p-126f && ax < 0x1p126f;

@@ -41,7 +41,14 @@ def test_library_exports_every_declared_symbol(built):
 def test_python_binding_covers_header(built):
     assert sorted(built.SYMBOLS.keys()) == declared_symbols()
     lib = built.load()
-    assert lib.prs_version() >= 100
+    assert lib.prs_version() == built.ABI_VERSION
+    header = open(os.path.join(ROOT, "include", "proslam_hip.h")).read()
+    assert "#define PRS_ABI_VERSION %d" % built.ABI_VERSION in header
+    # a client built against another header, or with a shorter parameter struct, is refused instead of read past
+    sizes = [C.sizeof(built.StereoParams), C.sizeof(built.PcfParams), C.sizeof(built.AlignerParams), C.sizeof(built.AlignBatch)]
+    assert lib.prs_abi_check(built.ABI_VERSION, *sizes) == 0
+    assert lib.prs_abi_check(built.ABI_VERSION - 1, *sizes) < 0
+    assert lib.prs_abi_check(built.ABI_VERSION, sizes[0], sizes[1], sizes[2] - 12, sizes[3]) < 0
     assert lib.prs_status_string(-1).decode().startswith("required")
 
 

@@ -25,12 +25,12 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-def _run(cfg_name, keypoints, moving, max_fixed, batch, seed, steps=2):
+def _run(cfg_name, keypoints, moving, max_fixed, batch, seed, steps=2, unique=UNIQUE, corr_of=None):
     import torch
     import bench
     from srrg2_proslam_amd import configs
     cfg = configs.get(cfg_name)
-    w = bench.FrameWorkload(cfg, 0, batch, keypoints, moving, max_fixed, UNIQUE, seed)
+    w = bench.FrameWorkload(cfg, 0, batch, keypoints, moving, max_fixed, unique, seed)
     stream = torch.cuda.Stream(device=w.dev)
     with torch.cuda.stream(stream):
         w.ctx.use_torch_stream()
@@ -41,7 +41,8 @@ def _run(cfg_name, keypoints, moving, max_fixed, batch, seed, steps=2):
         ok, _ = w.check(snap)
         X_all = w.aframes.X.cpu().numpy()
         n_corr_all = w.aframes.n_corr.cpu().numpy()
-        corr_all = [w.aframes.corr_of(b) for b in range(batch)] if batch <= 2048 else None
+        corr_all = ({b: w.aframes.corr_of(b) for b in corr_of} if corr_of is not None else
+                    ([w.aframes.corr_of(b) for b in range(batch)] if batch <= 2048 else None))
         n_match_all = w.sframes.n_matches.cpu().numpy() if w.stereo else None
     _, _, poses = bench.cpu_baseline(cfg, w.uniq, len(w.uniq))
     out = {"snap": snap, "ok": ok, "X": X_all, "n_corr": n_corr_all, "corr": corr_all, "n_match": n_match_all, "poses": poses, "uniq": w.uniq,
@@ -96,3 +97,32 @@ def test_euroc_and_tum_bench_shapes(cfg_name, max_fixed, seed):
     r = _run(cfg_name, 1000, 1000, max_fixed, batch, seed)
     assert r["ok"] > 0.9
     _check(r, batch)
+
+
+def test_full_bench_batch_every_distinct_frame_and_every_replica():
+    """bench.py's own allocation: B = 55296 frames per step tiled from 251 distinct ones (its --unique default), two steps.  Every
+    distinct frame against the CPU checker (correspondences bit-exact incl. order, pose bit-exact and <= 1e-4); pose, correspondence
+    count and stereo match count of ALL 55296 replicas against their source frame; the correspondence vectors of a strided sample."""
+    import bench
+    batch, unique = 55296, 251
+    sample = sorted(set(range(unique)) | set(range(unique, batch, 397)))
+    from srrg2_proslam_amd import synthetic as syn
+    r = _run("kitti", 2000, 2000, 896, batch, syn.seed_for(1, 0), unique=unique, corr_of=sample)  # (the seed of bench.py's rank 0)
+    assert r["ok"] > 0.9
+    poses = r["poses"]
+    assert len(poses) == unique
+    for u, (Xr, c) in enumerate(poses):
+        gc = r["corr"][u]
+        assert len(gc) == len(c) and np.array_equal(gc["fixed_idx"], c["fixed_idx"]) and np.array_equal(gc["moving_idx"], c["moving_idx"]), "frame %d" % u
+        assert np.array_equal(gc["response"].view(np.uint32), c["response"].view(np.uint32)), "frame %d" % u
+        Xg = r["X"][u].reshape(4, 4)
+        Xr = np.asarray(Xr, np.float32).reshape(4, 4)
+        assert np.linalg.norm(Xg.astype(np.float64) - Xr) / np.linalg.norm(Xr) <= POSE_TOL, "frame %d" % u
+        assert np.array_equal(_bits(Xg), _bits(Xr)), "frame %d: pose not bit-identical" % u
+    src = np.arange(batch) % unique
+    X = _bits(r["X"]).reshape(batch, -1)
+    bad = np.nonzero((X != X[src]).any(axis=1) | (r["n_corr"] != r["n_corr"][src]) | (r["n_match"] != r["n_match"][src]))[0]
+    assert bad.size == 0, "replicas that differ from their source frame: %s" % bad[:10]
+    for b in sample:
+        gb, gu = r["corr"][b], r["corr"][b % unique]
+        assert np.array_equal(gb["fixed_idx"], gu["fixed_idx"]) and np.array_equal(gb["moving_idx"], gu["moving_idx"]), "replica %d" % b

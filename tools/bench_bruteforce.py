@@ -11,7 +11,7 @@ import torch  # noqa: E402
 from srrg2_proslam_amd import ops  # noqa: E402
 
 
-def run(B, N, max_dist=50.0, iters=5):
+def run(B, N, max_dist=50.0, iters=5, quiet=False):
     ctx = ops.Context(0)
     ctx.use_torch_stream()
     clouds = ops.BruteforceClouds(0, B, N, N)
@@ -41,11 +41,16 @@ def run(B, N, max_dist=50.0, iters=5):
     # 2 VALU per 32-bit word (v_xor + accumulating v_bcnt), 8 words, + 1 compare = 17 lane-ops per pair;
     # VALU peak: 256 CUs x 4 SIMD x 16 lanes x 2.4 GHz
     valu_peak = 256 * 4 * 16 * 2.4e9
-    print("B=%d N=%d max_dist=%.0f matches/pair=%.0f ok=%d: %.3f ms/launch, %.2f G pairs/s, %.1f us/pair-of-clouds, "
-          "%.1f%% of the 17-op/pair VALU bound" % (
-              B, N, max_dist, clouds.n_matches.float().mean().item(), int((clouds.status >= 0).all().item()), ms,
-              pairs / ms / 1e6, ms * 1e3 / B, 100 * (pairs * 17 / (ms * 1e-3)) / valu_peak))
+    matches, ok = clouds.n_matches.float().mean().item(), int((clouds.status >= 0).all().item())
+    if not quiet:
+        print("B=%d N=%d max_dist=%.0f matches/pair=%.0f ok=%d: %.3f ms/launch, %.2f G pairs/s, %.1f us/pair-of-clouds, "
+              "%.1f%% of the 17-op/pair VALU bound" % (
+                  B, N, max_dist, matches, ok, ms, pairs / ms / 1e6, ms * 1e3 / B, 100 * (pairs * 17 / (ms * 1e-3)) / valu_peak))
     ctx.close()
+    del clouds
+    torch.cuda.empty_cache()
+    return {"cloud_pairs_per_launch": B, "points_per_cloud": N, "maximum_descriptor_distance": max_dist, "matches_per_cloud_pair": matches,
+            "all_status_ok": bool(ok), "ms_per_launch": ms, "descriptor_pairs_per_launch": pairs, "pairs_per_s": pairs / (ms * 1e-3)}
 
 
 if __name__ == "__main__":

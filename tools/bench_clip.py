@@ -12,7 +12,7 @@ import torch  # noqa: E402
 from srrg2_proslam_amd import _lib, configs, ops  # noqa: E402
 
 
-def run(B, N, with_desc=True, iters=20):
+def run(B, N, with_desc=True, iters=20, quiet=False):
     ctx = ops.Context(0)
     ctx.use_torch_stream()
     cam = configs.get("kitti")["camera"]
@@ -42,9 +42,14 @@ def run(B, N, with_desc=True, iters=20):
     kept = scenes.n_clipped.float().mean().item()
     per_in, per_out = (48 if with_desc else 16), (52 if with_desc else 20)
     bytes_ = B * (N * per_in + kept * per_out + 64)
-    print("B=%d N=%d desc=%d kept=%.0f (%.0f%%): %.3f ms/launch, %.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (
-        B, N, with_desc, kept, 100 * kept / N, ms, bytes_ / ms / 1e6, 100 * bytes_ / ms / 1e6 / 8000))
+    if not quiet:
+        print("B=%d N=%d desc=%d kept=%.0f (%.0f%%): %.3f ms/launch, %.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (
+            B, N, with_desc, kept, 100 * kept / N, ms, bytes_ / ms / 1e6, 100 * bytes_ / ms / 1e6 / 8000))
     ctx.close()
+    del scenes
+    torch.cuda.empty_cache()
+    return {"scenes_per_launch": B, "points_per_scene": N, "kept_per_scene": kept, "ms_per_launch": ms, "algorithmic_bytes_per_launch": bytes_,
+            "bytes_per_point_in": per_in, "bytes_per_point_out": per_out, "gbps": bytes_ / ms / 1e6}
 
 
 if __name__ == "__main__":

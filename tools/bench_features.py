@@ -18,6 +18,10 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
     source = sys.argv[2] if len(sys.argv) > 2 else "synthetic"
     order = sys.argv[3] if len(sys.argv) > 3 else "canonical"
+    run(B, source, order)
+
+
+def run(B, source="kitti", order="libstdcxx", quiet=False):
     cfg = configs.get("kitti")
     uniq = []
     if source == "kitti":
@@ -54,10 +58,16 @@ def main():
     assert int(st.min().item()) >= 0
     nf = n.float().mean().item()
     algo = B * (rows * cols + nf * 44)  # image read once + keypoints (8 B) + descriptors (32 B) + counters written
-    print("source=%s (%d distinct images) selection=%s" % (source, len(uniq), order))
-    print("B=%d images %dx%d, %.0f features/image: %.3f ms/launch, %.2f M images/s, %.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (
-        B, cols, rows, nf, ms, B / ms / 1e3, algo / ms / 1e6, 100 * algo / ms / 1e6 / 8000))
+    if not quiet:
+        print("source=%s (%d distinct images) selection=%s" % (source, len(uniq), order))
+        print("B=%d images %dx%d, %.0f features/image: %.3f ms/launch, %.2f M images/s, %.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (
+            B, cols, rows, nf, ms, B / ms / 1e3, algo / ms / 1e6, 100 * algo / ms / 1e6 / 8000))
     ctx.close()
+    del img, kp, desc, stage
+    torch.cuda.empty_cache()
+    return {"images_per_launch": B, "image": "%dx%d" % (cols, rows), "source": source, "distinct_images": len(uniq), "selection_order": order,
+            "features_per_image": nf, "ms_per_launch": ms, "images_per_s": B / (ms * 1e-3), "algorithmic_bytes_per_launch": float(algo),
+            "gbps": float(algo) / ms / 1e6}
 
 
 if __name__ == "__main__":

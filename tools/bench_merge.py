@@ -34,7 +34,7 @@ def merger_params(cfg, est_type):
     return p
 
 
-def run(B, NM, NS, est_type, name, history=6):
+def run(B, NM, NS, est_type, name, history=6, quiet=False):
     cfg = configs.get("kitti")
     cam = cfg["camera"]
     ctx = ops.Context(0)
@@ -102,9 +102,15 @@ def run(B, NM, NS, est_type, name, history=6):
     merged, added = r[:, 0].mean(), r[:, 1].mean()
     per_lm = 16 + 16 + 36 + 32 + 12 + 28 * (history + 1 if est_type == ops.EST_SMOOTHER else 0)  # row bytes touched per merged landmark
     bytes_ = B * (NM * 48 + n_c * 12 + merged * 2 * per_lm + added * (16 + 16 + 36 + 32 + 12 + 28))
-    print("%-14s B=%d measured=%d scene=%d merged=%.0f added=%.0f: %.3f ms/launch, %.2f M frames/s, %.0f GB/s of landmark-row traffic" % (
-        name, B, NM, NS, merged, added, ms, B / ms / 1e3, bytes_ / ms / 1e6))
+    if not quiet:
+        print("%-14s B=%d measured=%d scene=%d merged=%.0f added=%.0f: %.3f ms/launch, %.2f M frames/s, %.0f GB/s of landmark-row traffic" % (
+            name, B, NM, NS, merged, added, ms, B / ms / 1e3, bytes_ / ms / 1e6))
     ctx.close()
+    del maps
+    torch.cuda.empty_cache()
+    return {"estimator": name, "maps_per_launch": B, "measurements_per_frame": NM, "scene_points": NS, "history_per_landmark": history,
+            "merged_per_frame": float(merged), "added_per_frame": float(added), "ms_per_launch": ms, "frames_per_s": B / (ms * 1e-3),
+            "algorithmic_bytes_per_launch": float(bytes_), "gbps": float(bytes_) / ms / 1e6}
 
 
 if __name__ == "__main__":
