@@ -18,6 +18,7 @@
 //   phase 3: the levels in ascending order: pool membership, uniqueness counts, registration;
 //   phase 4: emit ordered by (distance, fixed index) -- the canonical order this build defines for the
 //            reference's unstable std::sort by response only (:94-97).
+#include <stdlib.h>
 #include <type_traits>
 
 #include "prs_device.h"
@@ -368,6 +369,323 @@ __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) 
   }
 }
 
+// ---- round 6: the dense phase on the matrix cores --------------------------------------------------------------------
+// hamming(a, b) = pop(a) + pop(b) - 2 a.b.  With the fixed rows as 0 / 1 bytes and the moving rows as +1 / -1 bytes (b' = 1 - 2 b),
+//     sum_k a_k b'_k = pop(a) - 2 a.b,     so     hamming(a, b) = (A B'^T)[a][b] + pop(b):
+// a 16 x 16 tile of distances is four v_mfma_i32_16x16x64_i8 (K = 256 bits) and "candidate" (d < lim, bruteforce_impl.cpp:52) is
+// acc < lim - pop(b), one compare per accumulator against a per-lane threshold (a lane's four accumulators share their column).
+// Integer products and sums: exact, the candidate set is the one the popcount kernel finds.
+// Shape: 1024 threads = 16 waves per workgroup, a wave owns 64 fixed rows (4 A tiles, expanded once into 64 registers), the workgroup
+// walks the moving cloud in chunks of 64 rows that all waves expand into LDS (double-buffered, one barrier per chunk: 64 MFMAs per
+// wave).  The operand layout inside K is free as long as A and B agree (a dot product does not care about the order of its terms):
+// lane (i = l & 15, g = l >> 4) holds, for K block kb, the 16 bits [64 kb + 16 g, +16) of row i as 16 bytes; the result layout is the
+// one tools/probes/mfma_i8_probe.hip pins (register r of lane l = row 4 (l >> 4) + r, column l & 15).
+// Candidates (one per fixed point, give or take) go through the same global counters / bitmaps / list as the split popcount shape
+// (MODE kBfDense); bruteforce_kernel<.., kBfRegister> then registers them pair by pair.
+typedef int bf_v4i __attribute__((ext_vector_type(4)));
+constexpr int kBfmThreads  = 512;                                  // 8 waves; two workgroups per CU: one scores while the other flushes / waits at its barrier
+constexpr int kBfmRowsWave = 64;                                   // fixed rows per wave (4 A tiles)
+constexpr int kBfmRowsWg   = kBfmRowsWave * (kBfmThreads / 64);    // 1024 fixed rows per workgroup
+constexpr int kBfmChunk    = 64;                                   // moving rows per LDS chunk (4 B tiles; 128 rows per chunk: two more registers, spills, slower)
+// LDS image of a chunk: four planes (one per 16-bit slice g of a 64-bit K block), a row of a plane = its four K blocks (64 B) + 16 B of
+// pad.  A ds_read_b128 is served in groups of 16 lanes that mix two values of g ({0-3, 12-15, 20-27}, ...): with the planes a multiple
+// of 256 B apart the bank of a lane depends on its row alone, and 16 rows at an 80-byte stride cover the 64 banks exactly once
+// (rows of 272 B with the slices side by side: a two-way conflict in every group, SQ_LDS_BANK_CONFLICT = a third of the LDS cycles)
+constexpr int kBfmPlaneRow = 64 + 16;
+constexpr int kBfmPlane    = kBfmChunk * kBfmPlaneRow;
+constexpr int kBfmListCap  = 4096;                                 // (column, row group) entries a workgroup parks in LDS between flushes (16 KB)
+constexpr int kBfmHitCap   = 2048;                                 // candidates of one flush round (16 KB): 128 entries x 16 pairs
+
+// where a candidate of one cloud pair goes: the pair's list, bitmaps and counters (what MODE kBfDense of the popcount kernel
+// updates per candidate).  Passed BY VALUE to the out-of-line overflow path: a reference to the kernel's argument block would
+// force a copy of it onto the stack, and every later read of it through scratch memory.
+struct BfSink {
+  uint2* cand;
+  uint32_t *bm_f, *bm_m, *g_cnt_f, *g_cnt_m, *g_hist, *g_total;
+  int nw, cap;
+};
+__device__ __forceinline__ void bf_publish(const BfSink k, const uint2 e, const uint32_t slot, const bool with_histogram = true) {
+  const int f = (int) (e.x & 0xffffu), m = (int) (e.x >> 16), d = (int) e.y;
+  if (slot < (uint32_t) k.cap) {
+    k.cand[slot] = e;
+  }
+  const uint32_t bit = 1u << (d & 31);
+  atomicOr(&k.bm_f[f * k.nw + (d >> 5)], bit);
+  atomicOr(&k.bm_m[m * k.nw + (d >> 5)], bit);
+  atomicAdd(&k.g_cnt_f[f], 1u);
+  atomicAdd(&k.g_cnt_m[m], 1u);
+  if (with_histogram) {
+    atomicAdd(&k.g_hist[d], 1u);
+  }
+}
+// pair `sub` (0..15: tile t = sub >> 2, accumulator r = sub & 3) of a parked entry: the exact distance from the packed rows, and
+// the candidate test of the reference (bruteforce_impl.cpp:52) -- the matrix-core distances only SELECTED the entry.
+// -> (fixed | moving << 16, distance), distance ~0: no candidate
+__device__ __forceinline__ uint2 bf_examine(const uint32_t* __restrict__ gdf, const uint32_t* __restrict__ gdm, const uint32_t entry, const int sub,
+                                            const int nf, const int lim) {
+  const int m = (int) (entry & 0xffffu);
+  const int f = (int) (((entry >> 16) & 0x7ffu) << 2) + 16 * (sub >> 2) + (sub & 3);
+  if (f >= nf) {
+    return make_uint2(0u, 0xffffffffu);
+  }
+  const uint4* pf = reinterpret_cast<const uint4*>(gdf + 8 * f);
+  const uint4* pm = reinterpret_cast<const uint4*>(gdm + 8 * m);
+  const uint4 f0 = pf[0], f1 = pf[1], m0 = pm[0], m1 = pm[1];
+  const int d = __popc(f0.x ^ m0.x) + __popc(f0.y ^ m0.y) + __popc(f0.z ^ m0.z) + __popc(f0.w ^ m0.w) + __popc(f1.x ^ m1.x) + __popc(f1.y ^ m1.y) +
+                __popc(f1.z ^ m1.z) + __popc(f1.w ^ m1.w);
+  return make_uint2((uint32_t) f | ((uint32_t) m << 16), d < lim ? (uint32_t) d : 0xffffffffu);
+}
+__device__ __attribute__((noinline)) void bf_examine_overflow(const BfSink k, const uint32_t* gdf, const uint32_t* gdm, const uint32_t entry, const int nf,
+                                                              const int lim) {
+  for (int sub = 0; sub < 16; ++sub) {
+    if ((entry >> (28 + (sub >> 2))) & 1u) {
+      const uint2 h = bf_examine(gdf, gdm, entry, sub, nf, lim);
+      if (h.y != 0xffffffffu) {
+        bf_publish(k, h, atomicAdd(k.g_total, 1u));
+      }
+    }
+  }
+}
+
+// The workgroup's parked entries -> the pair's candidate list (all threads, behind a barrier that ends the appends).  Out of line:
+// inlined, its registers pushed the scoring loop of the kernel into spills.  Rounds of 512 entries: their pairs are scored exactly
+// from the packed rows, the candidates among them collected in LDS, ONE slot range taken from the pair's global counter and one add per
+// distance level (a returning atomic per candidate on the one counter of a cloud pair serialises in the L2: 0.4 of 1.3 ms).
+__device__ __attribute__((noinline)) void bf_flush(const BfSink sink, const uint32_t* gdf, const uint32_t* gdm, const int nf, const int lim, const uint32_t* clist,
+                                                   uint2* hits, uint32_t* lhist, uint32_t* ccount, uint32_t* nhits, uint32_t* hbase) {
+  const int tid    = threadIdx.x;
+  const uint32_t n = *ccount < (uint32_t) kBfmListCap ? *ccount : (uint32_t) kBfmListCap;
+  for (uint32_t e0 = 0; e0 < n; e0 += kBfmHitCap / 16) {
+    const uint32_t ne = n - e0 < (uint32_t) kBfmHitCap / 16 ? n - e0 : (uint32_t) kBfmHitCap / 16;
+    if (tid == 0) {
+      *nhits = 0;
+    }
+    if (tid < kBfLevels) {
+      lhist[tid] = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < 16u * ne; i += kBfmThreads) {
+      const uint32_t entry = clist[e0 + (i >> 4)];
+      if ((entry >> (28 + ((i >> 2) & 3u))) & 1u) {  // (only the tiles whose accumulators met the threshold)
+        const uint2 h = bf_examine(gdf, gdm, entry, (int) (i & 15u), nf, lim);
+        if (h.y != 0xffffffffu) {
+          hits[atomicAdd(nhits, 1u)] = h;
+          atomicAdd(&lhist[h.y], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t nh = *nhits;
+    if (tid == 0 && nh > 0) {
+      *hbase = atomicAdd(sink.g_total, nh);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < nh; i += kBfmThreads) {
+      bf_publish(sink, hits[i], *hbase + i, false);
+    }
+    if (tid < kBfLevels && lhist[tid] != 0) {
+      atomicAdd(&sink.g_hist[tid], lhist[tid]);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    *ccount = 0;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(const BfArgs a) {
+  __shared__ __attribute__((aligned(256))) unsigned char bbuf[2][4 * kBfmPlane];
+  static_assert(kBfmPlane % 256 == 0, "planes must not shift the banks");
+  __shared__ int popm[2][kBfmChunk];
+  __shared__ uint32_t lut_a[16], lut_b[16];  // 4 bits -> 4 bytes: 0 / 1 (fixed side), +1 / -1 (moving side)
+  // candidates wait here for a bulk flush: half of a wave's tile rows meet one (a candidate per fixed row and cloud pair is one
+  // per 1024 pairs), and a slot from the GLOBAL counter costs the wave a trip to memory the matrix pipe idles through
+  __shared__ uint32_t clist[kBfmListCap];  // moving row | (first fixed row of the lane's 16) / 4 << 16 | tiles that met the threshold << 28
+  __shared__ uint32_t ccount, nhits, hbase;
+  __shared__ uint2 hits[kBfmHitCap];   // candidates of a flush round: fixed | moving << 16, distance
+  __shared__ uint32_t lhist[kBfLevels];  // ... and their histogram by distance (one global add per level and round)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int frame = (int) blockIdx.y;
+  int nf = a.b.n_fixed[frame];
+  int nm = a.b.n_moving[frame];
+  nf     = nf < 0 ? 0 : (nf > a.b.fixed_stride ? a.b.fixed_stride : nf);
+  nm     = nm < 0 ? 0 : (nm > a.b.moving_stride ? a.b.moving_stride : nm);
+  const int row0_wg = (int) blockIdx.x * kBfmRowsWg;
+  if (row0_wg >= nf || nm == 0) {
+    return;  // (block-uniform)
+  }
+  const uint32_t* __restrict__ gdf = reinterpret_cast<const uint32_t*>(a.b.fixed_desc + (size_t) frame * a.b.fixed_stride * PRS_DESC_BYTES);
+  const uint32_t* __restrict__ gdm = reinterpret_cast<const uint32_t*>(a.b.moving_desc + (size_t) frame * a.b.moving_stride * PRS_DESC_BYTES);
+  BfSink sink;
+  sink.cand    = a.cand + (size_t) frame * a.cap;
+  sink.bm_f    = a.bitmaps + (size_t) frame * (size_t) (a.b.fixed_stride + a.b.moving_stride) * a.nw;
+  sink.bm_m    = sink.bm_f + (size_t) a.b.fixed_stride * a.nw;
+  sink.g_cnt_f = a.g_acc + (size_t) frame * (size_t) (a.b.fixed_stride + a.b.moving_stride + kBfLevels + 8);
+  sink.g_cnt_m = sink.g_cnt_f + a.b.fixed_stride;
+  sink.g_hist  = sink.g_cnt_m + a.b.moving_stride;
+  sink.g_total = sink.g_hist + kBfLevels;
+  sink.nw      = a.nw;
+  sink.cap     = a.cap;
+
+  if (tid == 0) {
+    ccount = 0;
+  }
+  if (tid < 16) {
+    uint32_t v01 = 0, vpm = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      v01 |= ((tid >> b) & 1 ? 0x01u : 0x00u) << (8 * b);
+      vpm |= ((tid >> b) & 1 ? 0xffu : 0x01u) << (8 * b);
+    }
+    lut_a[tid] = v01;
+    lut_b[tid] = vpm;
+  }
+  __syncthreads();
+  auto expand16 = [](const uint32_t* lut, const uint32_t bits16) -> bf_v4i {
+    bf_v4i v;
+    v.x = (int) lut[bits16 & 15u];
+    v.y = (int) lut[(bits16 >> 4) & 15u];
+    v.z = (int) lut[(bits16 >> 8) & 15u];
+    v.w = (int) lut[(bits16 >> 12) & 15u];
+    return v;
+  };
+  // ---- this wave's fixed rows: A[t][kb] = bits [64 kb + 16 lg, +16) of row row0 + 16 t + li (rows past the end: zeros) ----
+  const int row0       = row0_wg + wave * kBfmRowsWave;
+  const bool wave_live = row0 < nf;
+  bf_v4i A[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int f = row0 + 16 * t + li;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const uint32_t w = f < nf ? gdf[8 * f + 2 * kb + (lg >> 1)] : 0u;
+      A[t][kb]         = expand16(lut_a, (w >> (16 * (lg & 1))) & 0xffffu);
+    }
+  }
+  // ---- the moving cloud, chunk by chunk ----
+  const int n_chunks = (nm + kBfmChunk - 1) / kBfmChunk;
+  // thread (row = tid >> 4, piece q = tid & 15) owns bits [16 q, +16) of moving row 64 c + row.  The word is REQUESTED before a chunk
+  // is scored and EXPANDED behind it (fetch / stage): requested and consumed back to back, every wave of the workgroup sits out a
+  // trip to memory per chunk with the matrix pipe idle
+  const int st_r = tid >> 4, st_q = tid & 15;
+  constexpr int kRowsPass = kBfmThreads / 16;          // rows the workgroup stages per pass (16 pieces per row)
+  constexpr int kHalves   = kBfmChunk / kRowsPass;     // passes: a thread stages one piece of `kHalves` rows, kRowsPass rows apart
+  struct Words {
+    uint32_t w[kHalves];
+  };
+  auto fetch = [&](const int c) -> Words {
+    Words r;
+#pragma unroll
+    for (int h = 0; h < kHalves; ++h) {
+      const int m = c * kBfmChunk + kRowsPass * h + st_r;
+      r.w[h]      = m < nm ? gdm[8 * m + (st_q >> 1)] : 0u;
+    }
+    return r;
+  };
+  auto stage = [&](const int c, const int buf, const Words ws) {
+#pragma unroll
+    for (int h = 0; h < kHalves; ++h) {
+      const int row         = kRowsPass * h + st_r;
+      const uint32_t bits16 = (ws.w[h] >> (16 * (st_q & 1))) & 0xffffu;
+      *reinterpret_cast<bf_v4i*>(&bbuf[buf][(st_q & 3) * kBfmPlane + row * kBfmPlaneRow + 16 * (st_q >> 2)]) = expand16(lut_b, bits16);  // piece q = 4 kb + g
+      // pop(b) of the row: the 16 pieces sit on the 16 lanes of a DPP row
+      int pop = __popc(bits16);
+      pop += __builtin_amdgcn_update_dpp(0, pop, 0x128, 0xf, 0xf, true);  // row_ror:8
+      pop += __builtin_amdgcn_update_dpp(0, pop, 0x124, 0xf, 0xf, true);  // row_ror:4
+      pop += __builtin_amdgcn_update_dpp(0, pop, 0x122, 0xf, 0xf, true);  // row_ror:2
+      pop += __builtin_amdgcn_update_dpp(0, pop, 0x121, 0xf, 0xf, true);  // row_ror:1
+      if (st_q == 0) {
+        popm[buf][row] = c * kBfmChunk + row < nm ? pop : (1 << 20);  // a row past the end never meets the threshold
+      }
+    }
+  };
+  auto flush = [&]() { bf_flush(sink, gdf, gdm, nf, a.lim, clist, hits, lhist, &ccount, &nhits, &hbase); };
+  stage(0, 0, fetch(0));
+  __syncthreads();
+  const bf_v4i zero = {0, 0, 0, 0};
+  for (int c = 0; c < n_chunks; ++c) {
+    const int buf = c & 1;
+    Words w_next;
+#pragma unroll
+    for (int h = 0; h < kHalves; ++h) {
+      w_next.w[h] = 0u;
+    }
+    if (c + 1 < n_chunks) {
+      w_next = fetch(c + 1);  // in flight while this chunk is scored
+    }
+    if (wave_live) {
+#pragma unroll 1
+      for (int bt = 0; bt < kBfmChunk / 16; ++bt) {
+        if (c * kBfmChunk + 16 * bt >= nm) {
+          break;  // (uniform) tiles past the end of the moving cloud
+        }
+        const unsigned char* brow = &bbuf[buf][lg * kBfmPlane + (16 * bt + li) * kBfmPlaneRow];
+        const int pop_b           = popm[buf][16 * bt + li];
+        const int thr             = a.lim - pop_b;  // candidate  <=>  acc < thr
+        bf_v4i B[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          B[kb] = *reinterpret_cast<const bf_v4i*>(brow + 16 * kb);
+        }
+        bf_v4i acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t][0], B[0], zero, 0, 0, 0);
+        }
+#pragma unroll
+        for (int kb = 1; kb < 4; ++kb) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t][kb], B[kb], acc[t], 0, 0, 0);
+          }
+        }
+        bool any_t[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          any_t[t] = (acc[t].x < thr) | (acc[t].y < thr) | (acc[t].z < thr) | (acc[t].w < thr);
+        }
+        const bool any = any_t[0] | any_t[1] | any_t[2] | any_t[3];
+        // A lane whose column met the threshold in ANY of its 16 rows parks (column, row group): the 16 pairs are scored again,
+        // exactly, from the packed rows when the list is flushed.  One LDS slot range per wave and tile row, no per-pair branch:
+        // half of a wave's tile rows hold a candidate (one per fixed row and cloud pair = one per 1024 pairs), and telling the
+        // 16 accumulators of a lane apart here cost the matrix pipe a third of its time.
+        const unsigned long long anymask = __ballot(any);
+        if (anymask != 0ull) {  // (wave-uniform)
+          uint32_t base = 0;
+          if (lane == 0) {
+            base = atomicAdd(&ccount, (uint32_t) __popcll(anymask));
+          }
+          base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+          if (any) {
+            const uint32_t lslot = base + (uint32_t) __popcll(anymask & ((1ull << lane) - 1ull));
+            const uint32_t tmask = (any_t[0] ? 1u : 0u) | (any_t[1] ? 2u : 0u) | (any_t[2] ? 4u : 0u) | (any_t[3] ? 8u : 0u);
+            const uint32_t entry = (uint32_t) (c * kBfmChunk + 16 * bt + li) | ((uint32_t) ((row0 + 4 * lg) >> 2) << 16) | (tmask << 28);
+            if (lslot < (uint32_t) kBfmListCap) {
+              clist[lslot] = entry;
+            } else {  // (list full: examined on the spot, out of line)
+              bf_examine_overflow(sink, gdf, gdm, entry, nf, a.lim);
+            }
+          }
+        }
+      }
+    }
+    if (c + 1 < n_chunks) {
+      stage(c + 1, buf ^ 1, w_next);
+    }
+    __syncthreads();  // chunk c + 1 is staged, chunk c is consumed
+    // a dense threshold fills the list: a chunk adds at most 8 waves x 4 tile rows x 64 lanes = 2048 entries, so a list that is below
+    // half its capacity before a chunk cannot overflow in it
+    const bool crowded = ccount >= (uint32_t) kBfmListCap / 2;
+    __syncthreads();  // (nobody appends again before everybody has read the count: the decision is uniform)
+    if (crowded) {
+      flush();
+    }
+  }
+  flush();
+}
+
 static inline uint32_t bf_align16(uint32_t v) {
   return (v + 15u) & ~15u;
 }
@@ -410,10 +728,17 @@ int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* param
       cus = prop.multiProcessorCount;
     }
   }
-  const int grid = batch->batch < cus ? batch->batch : cus;
+  // The dense phase on the matrix cores (bruteforce_dense_mfma_kernel) + the registration launch when the batch fills the chip with
+  // its 512-row workgroups (1024 pairs of 2000-point clouds: 2.77 -> 1.30 ms); a handful of pairs keeps the popcount kernels, whose
+  // split shape spreads a pair over more workgroups (8 pairs: 0.08 against 0.14 ms).  PRS_BF_MFMA=1 / 0 forces either (tests, A-B).
+  const int mfma_wgs = batch->batch * ((batch->fixed_stride + kBfmRowsWg - 1) / kBfmRowsWg);
+  const bool mfma    = ctx->bf_mfma > 0 || (ctx->bf_mfma < 0 && batch->fixed_stride >= 256 && batch->moving_stride >= 64 && mfma_wgs >= cus);
+  const int grid = mfma ? batch->batch : (batch->batch < cus ? batch->batch : cus);
   // few pairs: spread the dense phase of each pair over several workgroups (slices of >= 64 moving rows)
   a.chunks = 1;
-  if (batch->batch * 2 <= cus && batch->moving_stride >= 256) {
+  if (mfma) {
+    a.chunks = 2;  // (any value > 1: per-pair scratch rows + global accumulators, as in the split popcount shape)
+  } else if (batch->batch * 2 <= cus && batch->moving_stride >= 256) {
     int c = cus / batch->batch;
     const int most = batch->moving_stride / 64;
     a.chunks = c < most ? c : most;
@@ -468,7 +793,10 @@ int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* param
     if (e == hipSuccess) {
       e = hipMemsetAsync(a.bitmaps, 0, b_bm, stream);
     }
-    if (e == hipSuccess) {
+    if (e == hipSuccess && mfma) {
+      hipLaunchKernelGGL(bruteforce_dense_mfma_kernel, dim3((batch->fixed_stride + kBfmRowsWg - 1) / kBfmRowsWg, batch->batch), dim3(kBfmThreads), 0, stream, a);
+      e = hipGetLastError();
+    } else if (e == hipSuccess) {
       launch_mode(std::integral_constant<int, kBfDense>{}, dim3(a.chunks, batch->batch));
     }
     if (e == hipSuccess) {

@@ -1404,6 +1404,25 @@ int merge_batch_launch(prs_context* ctx, const prs_merger_params* params, const 
       e.type > PRS_EST_SMOOTHER || e.measurement_dim < 2 || e.measurement_dim > 4 || b.capacity <= 0 || b.max_frames <= 0 || b.measurement_stride <= 0) {
     return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_merge_batch_run: unknown merger / estimator or empty strides");
   }
+  // Which estimator a merger may own (mapping/instances.cpp:29-40 registers more types than any merger of mapping/mergers drives):
+  //   weighted mean / pose-based smoother: the landmark's position in the sensor comes from the MERGER, and only
+  //     MergerRigidStereoTriangulation computes one (merger_projective_rigid_stereo_triangulation_impl.cpp:15-35): the 4D3D forms.
+  //     The 2D3D / 3D3D forms have no caller in the reference that sets it: refused, not guessed;
+  //   stereo / depth filter: measurement layout and merger must agree;
+  //   mono filter (ProjectivePointEKF3D, 2-D measurements): no merger of the reference adds points from (u, v) alone: updates only.
+  if ((e.type == PRS_EST_WEIGHTED_MEAN || e.type == PRS_EST_SMOOTHER) && (params->variant != PRS_MERGER_STEREO_TRIANGULATION || e.measurement_dim != 4)) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED,
+                    "prs_merge_batch_run: the weighted-mean / smoother estimators are served in their 4D3D form under PRS_MERGER_STEREO_TRIANGULATION only "
+                    "(no merger of the reference provides landmark_in_sensor for 2-D / 3-D measurements)");
+  }
+  if (e.type == PRS_EST_EKF && ((e.measurement_dim == 4 && params->variant == PRS_MERGER_DEPTH_EKF) ||
+                                (e.measurement_dim == 3 && params->variant != PRS_MERGER_DEPTH_EKF))) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_merge_batch_run: 4-D measurements need a stereo merger, 3-D measurements PRS_MERGER_DEPTH_EKF");
+  }
+  if (e.type == PRS_EST_EKF && e.measurement_dim == 2 && params->target_number_of_merges != 0) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED,
+                    "prs_merge_batch_run: the mono filter updates landmarks only (target_number_of_merges must be 0: a point cannot be added from (u, v))");
+  }
   if (e.type == PRS_EST_SMOOTHER && (!b.meas || b.max_measurements <= 0 || e.measurement_dim < 3)) {
     return ctx_fail(ctx, PRS_ERR_NULL, "prs_merge_batch_run: the pose-based smoother needs the measurement history");
   }

@@ -9,6 +9,22 @@ from tests import helpers as hp
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module", params=["popcount", "mfma"])
+def hip_ctx(request):
+    """every test of this module on both dense phases: the popcount kernels (PRS_BF_MFMA=0) and the matrix-core kernel
+    (PRS_BF_MFMA=1: v_mfma_i32_16x16x64_i8 + exact re-scoring of the selected entries), whatever the batch size would pick"""
+    import os
+    old = os.environ.get("PRS_BF_MFMA")
+    os.environ["PRS_BF_MFMA"] = "1" if request.param == "mfma" else "0"
+    ctx = ops.Context(0)  # (the switch is read when the context is created)
+    if old is None:
+        del os.environ["PRS_BF_MFMA"]
+    else:
+        os.environ["PRS_BF_MFMA"] = old
+    yield ctx
+    ctx.close()
+
+
 def _tie_heavy(rng, n_base, n, flips):
     """descriptors drawn from few prototypes with a handful of flipped bits: many equal distances,
     shared best partners, pools with conflicts (bruteforce_impl.cpp:247-266)"""
