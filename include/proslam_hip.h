@@ -90,9 +90,9 @@ PRS_API int prs_version(void);
 /* The parameter structs below carry no size field and grow at their END between versions (round 5 added three int32 fields to
  * prs_aligner_params).  PRS_ABI_VERSION is what this header describes, prs_version() what the loaded library was built from; a
  * client checks that they agree once (prs_abi_check: also the sizes of the structs it will pass, as the client's compiler laid
- * them out) instead of finding out through a library that reads past a shorter struct.  Callers memset() parameter structs before
+ * them out) instead of finding out through a library that reads past a shorter struct (101 -> 102: step_norm_exit).  Callers memset() parameter structs before
  * filling them, so that fields they do not know select the shipped defaults (all zero). */
-#define PRS_ABI_VERSION 101
+#define PRS_ABI_VERSION 102
 PRS_API int prs_abi_check(int32_t header_version, uint64_t sizeof_stereo_params, uint64_t sizeof_pcf_params, uint64_t sizeof_aligner_params,
                           uint64_t sizeof_align_batch);
 #define PRS_ABI_CHECK() prs_abi_check(PRS_ABI_VERSION, sizeof(prs_stereo_params), sizeof(prs_pcf_params), sizeof(prs_aligner_params), sizeof(prs_align_batch))
@@ -305,6 +305,12 @@ typedef struct {
                                       PRS_TRANSLATION_WEIGHT_OFFSET min(0.01 + dn, 1) (shipped, the literal "(0.01+d,1)*I");
                                       PRS_TRANSLATION_WEIGHT_CLAMP clamp(dn, 0.01, 1).  Non-finite results count as 1 (0.01 for a NaN
                                       under CLAMP). */
+  /* OPT-IN, does LESS work than the reference (MultiAligner3DQR has no termination criterion in kitti.conf:1006-1009 / euroc.conf:
+   * every frame runs max_iterations): > 0 = leave the loop once the finder has latched (has_converged: the correspondences are
+   * frozen) and a Gauss-Newton step's 6-vector dx = (translation, normalised quaternion part) has |dx| below this bound.  The
+   * correspondence vector is the full run's (it froze before the exit); the pose differs from the max_iterations pose by about the
+   * last step (with lambda = 1 on diag(H) the steps halve: |dx| < 1e-5 leaves ~1e-5).  0 (what memset gives) = off. */
+  float step_norm_exit;
 } prs_aligner_params;
 enum { PRS_KERNEL_WEIGHT_INV_CHI = 0, PRS_KERNEL_WEIGHT_TAU_OVER_CHI = 1 };
 enum { PRS_DAMPING_DIAG = 0, PRS_DAMPING_IDENTITY = 1 };

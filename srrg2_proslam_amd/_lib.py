@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libproslam_hip.so")
-ABI_VERSION = 101  # PRS_ABI_VERSION of include/proslam_hip.h
+ABI_VERSION = 102  # PRS_ABI_VERSION of include/proslam_hip.h
 
 # status codes (include/proslam_hip.h)
 OK = 0
@@ -143,6 +143,7 @@ class AlignerParams(C.Structure):
         ("kernel_weight_form", C.c_int32),       # 0 Omega / chi (shipped), 1 Omega * tau / chi
         ("damping_form", C.c_int32),             # 0 H + lambda diag(H) (shipped), 1 H + lambda I
         ("translation_weight_form", C.c_int32),  # 0 min(0.01 + dn, 1) (shipped), 1 clamp(dn, 0.01, 1)
+        ("step_norm_exit", C.c_float),           # opt-in early exit (less work than the reference); 0 = off
     ]
 
 

@@ -1702,7 +1702,11 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
       if (g.a.enable_motion_prior) {
         add_motion_prior(g.a, g.prior_mean ? g.prior_mean + (size_t) frame * 16 : nullptr, X, H, b);
       }
-      gn_step(H, b, g.a.damping, X, g.a.damping_form == PRS_DAMPING_IDENTITY);
+      float dx6[6];
+      const bool step_ok = gn_step(H, b, g.a.damping, X, g.a.damping_form == PRS_DAMPING_IDENTITY, dx6);
+      // opt-in early exit (prs_aligner_params.step_norm_exit: less work than the reference)
+      const float dn2 = ((((dx6[0] * dx6[0] + dx6[1] * dx6[1]) + dx6[2] * dx6[2]) + dx6[3] * dx6[3]) + dx6[4] * dx6[4]) + dx6[5] * dx6[5];
+      const bool small_step = g.a.step_norm_exit > 0.0f && step_ok && dn2 < g.a.step_norm_exit * g.a.step_norm_exit;
       uint32_t changed_bits = 0;  // (bitwise, no short-circuit: sixteen compares would be sixteen branches)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -1717,7 +1721,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
       }
       // fixed point: finder latched (or out of the loop: inlier-only run) + pose reproduced bit-for-bit
       // => every later iteration of this phase repeats this one
-      sh.decision = (g.a.stop_at_fixed_point && changed_bits == 0u && (sh.converged || inlier_run)) ? 1 : 0;
+      sh.decision = ((g.a.stop_at_fixed_point && changed_bits == 0u && (sh.converged || inlier_run)) || (small_step && (sh.converged || inlier_run))) ? 1 : 0;
     }
     __syncthreads();
     ALIGN_ACC(acc_solve);
@@ -1950,6 +1954,12 @@ __device__ __forceinline__ void gn_solve_wave(const AlignArgs& g, GnShared& sh, 
     auto bcast = [](const float v, const int l) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
     float dx[6];
     const bool ok = ldlt_solve6(H, b, g.a.damping, dx, !SHIPPED_FORMS && g.a.damping_form == PRS_DAMPING_IDENTITY);
+    // opt-in early exit (prs_aligner_params.step_norm_exit: less work than the reference): the step is small and the finder has latched
+    bool small_step = false;
+    if (g.a.step_norm_exit > 0.0f) {  // (uniform)
+      const float n2 = ((((dx[0] * dx[0] + dx[1] * dx[1]) + dx[2] * dx[2]) + dx[3] * dx[3]) + dx[4] * dx[4]) + dx[5] * dx[5];
+      small_step     = ok && n2 < g.a.step_norm_exit * g.a.step_norm_exit;
+    }
     float D[16];
     tnq2t(dx, D);
     float4 xn;
@@ -1983,7 +1993,7 @@ __device__ __forceinline__ void gn_solve_wave(const AlignArgs& g, GnShared& sh, 
       *reinterpret_cast<float4*>(&sh.A[4 * lane]) = an;
     }
     if (stid == 0) {
-      sh.stop    = (g.a.stop_at_fixed_point && !any_changed && (sh.converged || inlier_run)) ? 1 : 0;
+      sh.stop    = ((g.a.stop_at_fixed_point && !any_changed && (sh.converged || inlier_run)) || (small_step && (sh.converged || inlier_run))) ? 1 : 0;
       sh.pose_ok = (fs - fs) == 0.0f ? 1 : 0;
     }
   }

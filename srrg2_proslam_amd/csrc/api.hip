@@ -148,7 +148,7 @@ using namespace prs;
 extern "C" {
 
 int prs_version(void) {
-  return PRS_ABI_VERSION;  // 0.1.1: prs_aligner_params grew by three fields in round 5 (kernel_weight_form, damping_form, translation_weight_form)
+  return PRS_ABI_VERSION;  // prs_aligner_params grew at its end: round 5 kernel_weight_form, damping_form, translation_weight_form; round 6 step_norm_exit
 }
 
 int prs_abi_check(int32_t header_version, uint64_t sizeof_stereo_params, uint64_t sizeof_pcf_params, uint64_t sizeof_aligner_params,

@@ -246,9 +246,15 @@ __device__ __forceinline__ bool ldlt_solve6(const float* H, const float* b, cons
 }
 
 // one damped Gauss-Newton step: X <- X * exp(dx); returns false (X untouched) when the system is not positive definite
-__device__ __forceinline__ bool gn_step(const float* H, const float* b, float damping, float* X, const bool identity_damping = false) {
+__device__ __forceinline__ bool gn_step(const float* H, const float* b, float damping, float* X, const bool identity_damping = false, float* dx_out = nullptr) {
   float dx[6];
   const bool ok = ldlt_solve6(H, b, damping, dx, identity_damping);
+  if (dx_out) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      dx_out[i] = dx[i];
+    }
+  }
   float D[16], Xn[16];
   tnq2t(dx, D);
   se3_mul(X, D, Xn);

@@ -252,6 +252,7 @@ def aligner_params(cfg, mean_disparity=-1.0, stop_at_fixed_point=1, **overrides)
     p.kernel_weight_form = int(al.get("kernel_weight_form", 0))
     p.damping_form = int(al.get("damping_form", 0))
     p.translation_weight_form = int(al.get("translation_weight_form", 0))
+    p.step_norm_exit = float(al.get("step_norm_exit", 0.0))  # opt-in: does less work than the reference
     if al.get("sensor_in_robot") is not None:
         set_sensor_in_robot(p, al["sensor_in_robot"])
     if al.get("motion_prior_info") is not None:

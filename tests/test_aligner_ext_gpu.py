@@ -243,3 +243,39 @@ def test_aligner_with_bruteforce_finder_on_the_reference_images(oracle, hip_ctx)
         err = rp.t2tnq(Xg.astype(np.float64) @ case["truth"])
         assert np.all(np.abs(err) < case["bound"]), (case["name"], err)
         gf.close()
+
+
+def test_step_norm_exit_is_opt_in_and_keeps_correspondences(oracle):
+    """prs_aligner_params.step_norm_exit (include/proslam_hip.h): 0 = the reference's loop (every iteration).  > 0 leaves the loop once
+    the finder has latched and |dx| is below the bound: fewer iterations, the SAME correspondence vector, and a pose within the
+    1e-4 relative Frobenius of BASELINE.json of the full run's (which is the checker's bit for bit)."""
+    import copy
+    import torch
+    import bench
+    from srrg2_proslam_amd import configs, synthetic as syn
+    cfg = configs.get("kitti")
+    frames = bench.make_unique_frames(cfg, 13, 1000, 1000, syn.seed_for(1, 0) + 5)
+    out = {}
+    for name, tol in (("full", 0.0), ("exit", 1e-5)):
+        vcfg = copy.deepcopy(cfg)
+        vcfg["aligner"]["step_norm_exit"] = tol
+        w = bench.FrameWorkload(vcfg, 0, 256, 1000, 1000, 512, len(frames), 0, frames=frames)
+        w.step()
+        torch.cuda.synchronize()
+        snap = w.snapshot()
+        ok, it_exec = w.check(snap)
+        out[name] = (snap, ok, it_exec)
+        w.close()
+        del w
+    (sf, okf, itf), (se, oke, ite) = out["full"], out["exit"]
+    assert okf == 1.0 and oke == 1.0
+    assert itf > 90 and ite < 0.6 * itf, (itf, ite)  # the early exit really skips most of the frozen tail
+    _, _, poses = bench.cpu_baseline(cfg, frames, len(frames))
+    for u, (Xr, c) in enumerate(poses):
+        for snap in (sf, se):
+            gc = snap["corr"][u]
+            assert len(gc) == len(c) and np.array_equal(gc["fixed_idx"], c["fixed_idx"]) and np.array_equal(gc["moving_idx"], c["moving_idx"]), u
+        Xr = np.asarray(Xr, np.float32).reshape(4, 4)
+        assert np.array_equal(sf["X"][u].reshape(4, 4).view(np.uint32), Xr.view(np.uint32)), u  # the full run is the checker's
+        rel = np.linalg.norm(se["X"][u].reshape(4, 4).astype(np.float64) - Xr) / np.linalg.norm(Xr)
+        assert rel <= 1e-4, (u, rel)
