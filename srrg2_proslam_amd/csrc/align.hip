@@ -1142,6 +1142,9 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
               make_uint2(((uint32_t) row & 0xffffu) | ((uint32_t) col << 16), (uint32_t) i | ((uint32_t) canon[i] << 16));
             inv[canon[i]] = (uint16_t) i;
           }
+          if (tid == 0) {
+            db[nF] = make_uint2(0x7fff7fffu, 0xffffffffu);  // sentinel behind the last entry: row / column no search pattern accepts
+          }
           __syncthreads();
           db_built = true;
           if (split_search && g.dbcache) {
@@ -1373,16 +1376,20 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                         asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
                                      : "=&v"(la), "=&v"(lb)
                                      : "v"(fd_lds + 16u * (uint32_t) pos));
+                        // (no "pos + 1 < seg1" test on the second slot: the entry behind a segment is another cell's.  If it survives the
+                        // bound and lies in the pattern it is in a scanned cell too -- the cells cover the pattern's bounding box -- and is
+                        // met again there: survivors are de-duplicated before they are scored.  Behind the last entry sits a sentinel no
+                        // pattern accepts.)
                         const bool hit_a = hamming_96(la, q0) < prune_at;
-                        const bool hit_b = (pos + 1 < seg1) & (hamming_96(lb, q0) < prune_at);
+                        const bool hit_b = hamming_96(lb, q0) < prune_at;
                         if (hit_a) {
                           surv[n_surv < kSurvivors ? n_surv : kSurvivors - 1] = (uint16_t) pos;
+                          ++n_surv;
                         }
-                        n_surv += hit_a ? 1 : 0;
                         if (hit_b) {
                           surv[n_surv < kSurvivors ? n_surv : kSurvivors - 1] = (uint16_t) (pos + 1);
+                          ++n_surv;
                         }
-                        n_surv += hit_b ? 1 : 0;
                       } else {
                         const unsigned long long wa = reinterpret_cast<const unsigned long long*>(db)[pos];
                         const unsigned long long wb = reinterpret_cast<const unsigned long long*>(db)[pos + 1];
@@ -1411,7 +1418,11 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                   } else {
                     for (int i = 0; i < n_surv; ++i) {
                       const int p = (int) surv[i];
-                      if (lean_circle ? accepts_circle(db[p]) : accepts_any(db[p])) {
+                      bool seen   = false;  // (an entry read as "one past a segment" and again in its own)
+                      for (int j = 0; j < i; ++j) {
+                        seen = seen | ((int) surv[j] == p);
+                      }
+                      if (!seen && (lean_circle ? accepts_circle(db[p]) : accepts_any(db[p]))) {
                         score_at(p);
                       }
                     }
@@ -2539,7 +2550,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   const uint32_t cs_entries = kdtree && nf + 4u > (uint32_t) g.ncells + 2u ? nf + 4u : (uint32_t) g.ncells + 2u;
   auto carve = [&](AlignArgs& g, bool with_operands) -> size_t {
     uint32_t off = 0;
-    g.off_db       = off; off = align_up16(off + nf * 8);
+    g.off_db       = off; off = align_up16(off + (nf + 1) * 8);  // (+ the sentinel entry behind the last one: the scan reads one entry past a segment)
     g.off_inv      = off; off = align_up16(off + nf * 2);
     g.off_cellstart = off; off = align_up16(off + cs_entries * 2);
     g.off_cfix     = off; off = align_up16(off + (with_operands ? nf * 16 : 0));
