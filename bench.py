@@ -1186,10 +1186,12 @@ def main():
         "algorithmic_bytes_per_frame_and_launch": bytes_search, "frames_per_launch": B,
         "traffic_over_algorithmic": (evidence["search"] / (B * bytes_search * searches)) if evidence and searches > 0 else None,
         "counter_gbps": (evidence["search"] / (ms_search * 1e-3) / 1e9) if evidence and ms_search > 0 else None,
-        "note": "not bandwidth-bound: at three 512-thread workgroups per CU the waves are parked 62 % of their cycles on dependent LDS chains "
-                "(SQ_WAIT_ANY / SQ_WAVE_CYCLES), 27 k vector + 19 k scalar instructions per frame and launch, 77 % of a launch is the candidate scan "
-                "(profiles/r04/align_pmc.txt; round-5 phase stamps and the two scan experiments that did not pay: profiles/r05/search_experiments.txt); "
-                "frac prices the algorithmic bytes, counter_gbps the bytes the PMC passes saw",
+        "note": "not bandwidth-bound: the kernel retires 0.84 vector instructions per cycle and CU (34 k per frame-search, profiles/r04/align_pmc.txt) "
+                "and 77 % of a launch is the candidate scan, so only the instruction count of a scan trip counts.  Round 6 (17.1 -> 14.0 ms same-box, "
+                "profiles/r06/search_scan_r06.txt): fixed descriptor rows in LDS in lattice order, a trip compares two 96-bit half rows with the irrelevance "
+                "bound (one LDS round trip), entry + pattern test + full distance for the survivors only, which wait in four LDS slots per thread; no operand "
+                "rows written (the Gauss-Newton kernel gathers through the correspondence vector).  frac prices the algorithmic bytes, counter_gbps the "
+                "bytes the PMC passes saw",
     }
     roof_gn = {
         "kernel": "gn_kernel<SLOTS, stereo> (reprojection-error Gauss-Newton rounds: factor linearisation, fixed-shape H / b reduction, "
@@ -1203,7 +1205,8 @@ def main():
         "note": "fp32 vector arithmetic, no MFMA: 6x6 normal equations are not a dense contraction; the kernel is bound by vector issue "
                 "(SQ_INSTS_VALU per launch / (launch cycles x CUs) = 1.07 vector instructions per cycle and CU, profiles/r05/rocprof_summary.json "
                 "pmc_sq2; round 5 took the IEEE reciprocals of the iteration to v_rcp_f32 + one Newton step where all 2^32 operands show it equal, "
-                "tests/test_reciprocal_gpu.py), frac prices only the algorithmic flops",
+                "tests/test_reciprocal_gpu.py; round 6: operand rows gathered through the correspondence vector, no spills in the headline "
+                "instantiation), frac prices only the algorithmic flops",
     }
     roof_match = {
         "kernel": "stereo_match5_kernel<%d> (the kernel BASELINE.json north_star prices; matcher + fused adaptor / triangulator epilogue)" % (1 if N <= 1024 else 2),
