@@ -91,6 +91,8 @@ struct AlignArgs {
   prs_align_batch b;
   int mode;
   int no_prefilter;  // diagnostic (PRS_NO_PREFILTER=1)
+  int surv_slots;  // LDS slots per thread for survivors of the irrelevance bound (align_batch_launch: 8 where that costs no resident workgroup, else 4)
+  int narrow_prefilter_limit;  // largest irrelevance bound tested on 96 instead of 128 bits (32; PRS_PREFILTER_96_LIMIT overrides: diagnostic)
   int rows_table;  // R = projector canvas rows (lattice row table extent)
   int lut_cap;     // entries of the circle width table
   int cell_sy, cell_sx, cell_ncx, cell_ncy, ncells;  // 2-D cell grid over the canvas (cells of 2^sy rows x 2^sx cols)
@@ -525,7 +527,10 @@ __host__ __device__ __forceinline__ int kd_open_capacity(const int max_fixed) {
 // Gauss-Newton code (and its registers) is not part of that instantiation
 // STYPE: the search pattern as a compile-time constant (-1 = read it from the parameters), so that the search
 // half only carries the code and registers of its own pattern
-template <int T, bool SPLIT, int STYPE>
+// SLOTS: LDS slots per thread for survivors of the irrelevance bound (4, or 8 where they cost no resident workgroup): a compile-time
+// constant like the pattern -- as run-time values the slot count and its mask pushed the kernel (at its 106 scalar registers)
+// into scalar spills inside the scan: 13.99 -> 14.43 ms on the headline
+template <int T, bool SPLIT, int STYPE, int SLOTS = 4>
 __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs g) {  // search half: <= 128 VGPRs = two workgroups per CU
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid   = threadIdx.x;
@@ -561,7 +566,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
   uint32_t* bestkey   = reinterpret_cast<uint32_t*>(smem + g.off_best);
   uint32_t* second    = reinterpret_cast<uint32_t*>(smem + g.off_second);
   uint16_t* lut       = reinterpret_cast<uint16_t*>(smem + g.off_lut);
-  constexpr int kSurvivors = 4;                                            // survivors of the irrelevance bound a query may park (lattice scan)
+  constexpr int kSurvivors = SLOTS;                                        // survivors of the irrelevance bound a query may park (lattice scan): 4, or 8 where the LDS is free
   uint16_t* surv      = reinterpret_cast<uint16_t*>(smem + g.off_surv) + kSurvivors * tid;
   float* terms        = reinterpret_cast<float*>(smem + g.off_terms);     // aliases the search-phase arrays
   uint8_t* clsbuf     = smem + g.off_cls;                                  // factor class per correspondence (last linearisation)
@@ -1352,8 +1357,14 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                 // score of an evicted one inside the loop -- made the compiler copy best / second best / survivors around every trip.
                 // Pattern test + full score after the scan; a fifth survivor (never on random rows) sends the query through the
                 // unpruned scan instead.
+                // pruned_tag: 0 = unpruned (every accepted entry is scored in full), 3 / 4 = the bound is tested on the first 96 / 128 bits
+                // (two copies of the loop, chosen per query by the frame's bound: a uniform branch INSIDE one loop cost the headline 2 %).
+                // 96 bits of unrelated rows differ in 48 +- 5, so a bound of up to 32 (kitti.conf / euroc.conf's first searches: 31) still
+                // rejects all but ~1e-4 of them at three quarters of the instructions; a larger bound (tum.conf's 49) needs all 128 bits
+                // (64 +- 6) or nearly every entry survives and the query falls through to the unpruned scan
                 auto scan = [&](auto accepts, auto pruned_tag) {
-                  constexpr bool PRUNED = decltype(pruned_tag)::value;
+                  constexpr int WORDS = decltype(pruned_tag)::value;
+                  constexpr bool PRUNED = WORDS != 0;
                   const uint16_t* cs = cellstart + (r0 >> g.cell_sy) * g.cell_ncx + cx0;  // bounds of the next cell row's segment
                   const int width    = cx1 + 1 - cx0;
                   int rows_left      = (r1 >> g.cell_sy) - (r0 >> g.cell_sy) + 1;
@@ -1380,14 +1391,14 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                         // bound and lies in the pattern it is in a scanned cell too -- the cells cover the pattern's bounding box -- and is
                         // met again there: survivors are de-duplicated before they are scored.  Behind the last entry sits a sentinel no
                         // pattern accepts.)
-                        const bool hit_a = hamming_96(la, q0) < prune_at;
-                        const bool hit_b = hamming_96(lb, q0) < prune_at;
+                        const bool hit_a = (WORDS == 3 ? hamming_96(la, q0) : hamming_half(la, q0)) < prune_at;
+                        const bool hit_b = (WORDS == 3 ? hamming_96(lb, q0) : hamming_half(lb, q0)) < prune_at;
                         if (hit_a) {
-                          surv[n_surv < kSurvivors ? n_surv : kSurvivors - 1] = (uint16_t) pos;
+                          surv[n_surv & (kSurvivors - 1)] = (uint16_t) pos;  // (slots are a power of two; a wrapped write belongs to a query that is rescanned anyway)
                           ++n_surv;
                         }
                         if (hit_b) {
-                          surv[n_surv < kSurvivors ? n_surv : kSurvivors - 1] = (uint16_t) (pos + 1);
+                          surv[n_surv & (kSurvivors - 1)] = (uint16_t) (pos + 1);
                           ++n_surv;
                         }
                       } else {
@@ -1412,9 +1423,9 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                   return lean_circle ? scan(accepts_circle, pruned_tag) : scan(accepts_any, pruned_tag);
                 };
                 if (prune_at > 0) {
-                  const int n_surv = scan_pattern(std::true_type{});
+                  const int n_surv = (prune_at <= g.narrow_prefilter_limit) ? scan_pattern(std::integral_constant<int, 3>{}) : scan_pattern(std::integral_constant<int, 4>{});
                   if (n_surv > kSurvivors) {
-                    scan_pattern(std::false_type{});  // (nothing has been scored yet)
+                    scan_pattern(std::integral_constant<int, 0>{});  // (nothing has been scored yet)
                   } else {
                     for (int i = 0; i < n_surv; ++i) {
                       const int p = (int) surv[i];
@@ -1428,7 +1439,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
                     }
                   }
                 } else {
-                  scan_pattern(std::false_type{});
+                  scan_pattern(std::integral_constant<int, 0>{});
                 }
               }
               if (bestk != kNoneU32) {  // circle_impl.cpp:78-92 / kdtree_impl.cpp:72-78 (best only)
@@ -2511,6 +2522,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   g.b          = *batch;
   g.mode       = mode;
   g.no_prefilter = ctx->no_prefilter ? 1 : 0;
+  g.narrow_prefilter_limit = ctx->prefilter_96_limit;
   g.prior_mean = batch->prior_mean;
   g.rows_table = finder->projector.canvas_rows;
   const int max_fixed = batch->max_fixed > 0 && batch->max_fixed < batch->fixed_stride ? batch->max_fixed : batch->fixed_stride;
@@ -2565,7 +2577,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
     g.off_best   = u; u = align_up16(u + nf * 4);
     g.off_second = u; u = align_up16(u + nf * 4);
     g.off_lut    = u; u = align_up16(u + lut_cap * 2);
-    g.off_surv   = u; u = align_up16(u + (uint32_t) (with_operands ? kAlignThreads : kSearchThreads) * 4 * 2);  // kSurvivors x u16 per thread
+    g.off_surv   = u; u = align_up16(u + (uint32_t) (with_operands ? kAlignThreads : kSearchThreads) * (uint32_t) g.surv_slots * 2);  // slots x u16 per thread
     // GN-phase terms; the region also serves the database build (hist + slot + bucket) and the disparity column
     g.off_terms = off;
     uint32_t terms_bytes       = kTerms * kAlignThreads * 4;
@@ -2584,6 +2596,7 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
     const uint32_t t_end = align_up16(off + terms_bytes);
     return u > t_end ? u : t_end;
   };
+  g.surv_slots     = 4;
   const size_t lds = carve(g, true);
   if (lds > 160 * 1024) {
     return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_align_batch_run: fixed cloud does not fit the 160 KiB LDS (lower max_fixed)");
@@ -2639,19 +2652,34 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   g.ctl     = reinterpret_cast<FrameCtl*>(small + 256);
   AlignArgs gs = g;
   gs.mode      = kModeSplitSearch;
-  const size_t lds_search = carve(gs, false);
+  // eight survivor slots per thread where they cost no resident workgroup (a wide search radius or correlated rows overflow four:
+  // tum.conf's shape 1.02 -> 0.93 ms per 6144 frames), four otherwise (the headline's 49.6 + 4 KB keep three workgroups per CU)
+  gs.surv_slots = 8;  // (the KD-tree finder parks nothing)
+  size_t lds_search = carve(gs, false);
+  gs.surv_slots     = 4;
+  {
+    const size_t lds4 = carve(gs, false);
+    if ((160u * 1024u) / lds_search == (160u * 1024u) / lds4 && finder->search_type != PRS_SEARCH_KDTREE) {
+      gs.surv_slots = 8;
+      lds_search    = carve(gs, false);
+    } else {
+      lds_search = lds4;
+    }
+  }
   // image of the lattice arrays (contiguous in LDS: db | inv | cellstart), kept per frame between search launches
   gs.db_blob = align_up16(gs.off_cellstart + cs_entries * 2) - gs.off_db;
   gs.dbcache = static_cast<unsigned char*>(job->buffer(stream, 2, (size_t) batch->batch * gs.db_blob));
   if (!gs.dbcache) {
     return ctx_fail(ctx, PRS_ERR_HIP, "prs_align_batch_run: lattice cache allocation failed");
   }
+  const bool wide_slots = gs.surv_slots == 8;
   auto skernel = finder->search_type == PRS_SEARCH_CIRCLE
-                   ? align_kernel<kSearchThreads, true, PRS_SEARCH_CIRCLE>
+                   ? (wide_slots ? align_kernel<kSearchThreads, true, PRS_SEARCH_CIRCLE, 8> : align_kernel<kSearchThreads, true, PRS_SEARCH_CIRCLE, 4>)
                    : (finder->search_type == PRS_SEARCH_SQUARE
-                        ? align_kernel<kSearchThreads, true, PRS_SEARCH_SQUARE>
-                        : (finder->search_type == PRS_SEARCH_RHOMBUS ? align_kernel<kSearchThreads, true, PRS_SEARCH_RHOMBUS>
-                                                                     : align_kernel<kSearchThreads, true, PRS_SEARCH_KDTREE>));
+                        ? (wide_slots ? align_kernel<kSearchThreads, true, PRS_SEARCH_SQUARE, 8> : align_kernel<kSearchThreads, true, PRS_SEARCH_SQUARE, 4>)
+                        : (finder->search_type == PRS_SEARCH_RHOMBUS
+                             ? (wide_slots ? align_kernel<kSearchThreads, true, PRS_SEARCH_RHOMBUS, 8> : align_kernel<kSearchThreads, true, PRS_SEARCH_RHOMBUS, 4>)
+                             : align_kernel<kSearchThreads, true, PRS_SEARCH_KDTREE, 4>));
   // two waves per frame (eight frames resident per CU: the kernel is bound by its single-wave phases and by
   // instruction issue, more independent frames fill the idle slots)
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(skernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_search);

@@ -213,6 +213,8 @@ int prs_context_create(int device_id, prs_context** out) {
   ctx->no_prefilter    = nopre && nopre[0] == '1';
   const char* nolone   = getenv("PRS_NO_LONE_GN");
   ctx->no_lone_gn      = nolone && nolone[0] == '1';
+  const char* p96      = getenv("PRS_PREFILTER_96_LIMIT");
+  ctx->prefilter_96_limit = p96 ? atoi(p96) : 32;
   const char* bfm      = getenv("PRS_BF_MFMA");
   ctx->bf_mfma         = bfm ? (bfm[0] == '1' ? 1 : 0) : -1;
   const char* mfused   = getenv("PRS_MERGE_FUSED");
