@@ -3,8 +3,9 @@
 // The per-frame loop the external MultiAligner3DQR drives in the reference, up to max_iterations of
 //     finder.setLocalMapInSensor(X); finder.compute(); slice.setupFactor(); linearize; GN step
 // for `batch` independent frames (sequences) per launch.  Two forms, bit-identical:
-//   * the split pipeline (default for PRS_MODE_ALIGN): align_kernel<512, true, pattern> performs ONE projective
-//     search for every frame that waits for it (three workgroups per CU), gn_kernel runs Gauss-Newton iterations
+//   * the split pipeline (default for PRS_MODE_ALIGN): align_kernel<512, true, pattern, slots> performs ONE projective
+//     search for every frame that waits for it (three workgroups per CU) and commits the correspondence vector, gn_kernel gathers its
+//     operand rows through that vector and runs Gauss-Newton iterations
 //     until the finder needs the next search (two waves per frame, eight frames per CU); the host enqueues five
 //     rounds (align_batch_launch) and confirms completion with one 4-byte readback (align_batch_finish);
 //   * the fused kernel align_kernel<256, false, -1>: one 256-thread workgroup owns a frame for the whole loop
@@ -96,7 +97,8 @@ struct AlignArgs {
   int rows_table;  // R = projector canvas rows (lattice row table extent)
   int lut_cap;     // entries of the circle width table
   int cell_sy, cell_sx, cell_ncx, cell_ncy, ncells;  // 2-D cell grid over the canvas (cells of 2^sy rows x 2^sx cols)
-  float4* ops;     // split pipeline: [batch][max_fixed][2] per-correspondence operands (fixed measurement, moving point)
+  float4* ops;     // split pipeline: [batch][max_fixed][2] operand rows (fixed measurement, moving point) of the correspondences BEYOND the ones
+                   // the Gauss-Newton kernel parks in LDS: gathered by that kernel once per launch, read back at every iteration
   FrameCtl* ctl;   // split pipeline: [batch]
   int* pending;    // split pipeline: number of frames the last GN launch left unfinished
   unsigned char* dbcache;  // split pipeline: [batch][db_blob] image of the LDS lattice (db | inv | cellstart)
@@ -1561,7 +1563,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
           continue;
         }
         SUB_ACC(acc_filter);
-        // -- commit: correspondences->swap(filtered) (:268) + per-correspondence operands for the factor
+        // -- commit: correspondences->swap(filtered) (:268) (+ the operands of the factor, fused kernel only)
         for (int f = cold_copy(tid_hot); f < nF; f += T) {
           const uint32_t slot = second[f];
           if (slot != kNoneU32) {
@@ -1843,7 +1845,7 @@ __global__ __launch_bounds__(T, SPLIT ? 6 : 1) void align_kernel(const AlignArgs
 // ---- split pipeline, GN half -------------------------------------------------------------------------
 // One workgroup per frame runs aligner iterations (linearize + damped GN step, with the
 // finder's "nothing new" bookkeeping in between) until the finder needs a projective search again or
-// max_iterations is reached.  The per-correspondence operands written by the search kernel sit in
+// max_iterations is reached.  The per-correspondence operands (gathered through the committed correspondence vector) sit in
 // registers (<= 8 per thread), so a workgroup needs only the 29 x THREADS term matrix in LDS and many
 // frames share a CU.  Arithmetic and summation order are those of the fused kernel.
 // Instantiated for 128 threads x {4, 6, 7, 8} correspondences per thread (the default) and 256 x {2, 3, 4}.
@@ -2554,8 +2556,8 @@ int align_batch_launch(prs_context* ctx, const prs_pcf_params* finder, const prs
   g.cell_ncy = ncy;
   g.cell_ncx = ncx;
   g.ncells   = ncy * ncx;
-  // LDS carve.  with_operands = false: the search half of the split pipeline, which hands the
-  // per-correspondence operand rows to the GN kernel through global memory instead of LDS
+  // LDS carve.  with_operands = false: the search half of the split pipeline, which keeps no operand rows (the GN kernel gathers
+  // them through the committed correspondence vector)
   // the KD-tree finder keeps its tree where the lattice finders keep theirs: nodes in `db`, leaf members in `inv`, root + leaf
   // offsets in `cellstart` (2 + n_leaves + 1 <= max_fixed + 3 entries)
   const bool kdtree         = finder->search_type == PRS_SEARCH_KDTREE;
