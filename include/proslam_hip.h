@@ -246,7 +246,8 @@ typedef struct {
   float local_map_in_sensor[16];
   float local_map_in_sensor_previous[16];
   float database_leaf_range; /* KD-tree finder: _search_radius_pixels when _initializeDatabase last ran (the tree's leaf range) */
-  int32_t reserved;
+  int32_t reserved; /* internal hint, no result depends on it: bit 0 = the search has stopped pruning candidates by partial descriptor
+                       distances for this finder (its rows are correlated: more than an eighth of a search's queries overflowed) */
 } prs_pcf_state;
 
 typedef struct {
