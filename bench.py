@@ -916,10 +916,16 @@ def latency_b1(cfg, frames, n_frames=64):
             return {"error": "latency_b1 exit %d: %s" % (run.returncode, run.stderr[-400:])}
         out = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
         poses = np.fromfile(path + ".poses", np.float32).reshape(2, n_frames, 4, 4)
+        # the same frames with the opt-in early exit (prs_aligner_params.step_norm_exit = 1e-5): LESS work than the reference, reported beside
+        run_x = subprocess.run([exe, path, str(warm), "1e-5"], capture_output=True, text=True, timeout=600)
+        out_x, poses_x = None, None
+        if run_x.returncode == 0:
+            out_x = json.loads([l for l in run_x.stdout.splitlines() if l.startswith("{")][-1])
+            poses_x = np.fromfile(path + ".poses", np.float32).reshape(2, n_frames, 4, 4)
     # the CPU checker, same frames, same order, ONE finder object across them (incl. the warm-up frames: its state carries over)
     sp, tp, pp, ap = oracle_params(cfg)
     finder = ob.ProjectiveFinder(pp)
-    worst, times = [0.0, 0.0], []
+    worst, worst_x, times = [0.0, 0.0], [0.0, 0.0], []
     for k in range(-warm, n_frames):
         d = seq[(k + warm) % n_frames] if k < 0 else seq[k]
         fr, mp = d["fr"], d["mp"]
@@ -937,9 +943,16 @@ def latency_b1(cfg, frames, n_frames=64):
             X = np.array(res.X, np.float32).reshape(4, 4)
             for flavour in range(2):
                 worst[flavour] = max(worst[flavour], float(np.linalg.norm(poses[flavour, k] - X) / np.linalg.norm(X)))
+                if poses_x is not None:
+                    worst_x[flavour] = max(worst_x[flavour], float(np.linalg.norm(poses_x[flavour, k] - X) / np.linalg.norm(X)))
     finder.close()
     out["cpu_checker"] = {"ms_per_frame_mean": float(np.mean(times)), "fps": 1e3 / float(np.mean(times)), "cores": 1, "kind": "port"}
     out["pose_rel_frobenius_max_vs_cpu_checker"] = {"adapters": worst[0], "c_abi": worst[1]}
+    if out_x is not None:
+        out["with_step_norm_exit"] = {"does_less_work_than_the_reference": True, "step_norm_exit": 1e-5,
+                                      "adapters_ms_per_frame_median": out_x["adapters"]["ms_per_frame_median"], "c_abi_ms_per_frame_median": out_x["c_abi"]["ms_per_frame_median"],
+                                      "pose_rel_frobenius_max_vs_100_iteration_checker": {"adapters": worst_x[0], "c_abi": worst_x[1]},
+                                      "note": "opt-in early exit of the Gauss-Newton loop (off by default): what one frame at a time costs when the frozen tail is cut"}
     out["note"] = ("one sequence, one frame at a time, host pointers, PCIe + launch + synchronisation inside every call; finder object carried across "
                    "frames; `adapters` = plugin/proslam_hip_plugin.hpp on array-of-structs clouds (gather / scatter timed), `c_abi` = flat arrays; the "
                    "reference times frames the same way (apps/app_benchmark.cpp:345-353)")

@@ -533,6 +533,7 @@ public:
   // readings of the un-vendored srrg2_solver arithmetic (include/proslam_hip.h, prs_aligner_params): 0 = the family
   // this library ships; a maintainer whose srrg2_solver does otherwise selects the other reading here (or in the .conf)
   PropertyInt param_robustifier_kernel_weight_form{PRS_KERNEL_WEIGHT_INV_CHI};     // RobustifierSaturated: Omega / chi | Omega * tau / chi
+  PropertyFloat param_step_norm_exit{0.f};  // OPT-IN, not a parameter of the reference: leave the loop once the finder has latched and |dx| is below this (0 = off)
   PropertyInt param_damping_form{PRS_DAMPING_DIAG};                                // IterationAlgorithmGN: H + lambda diag(H) | H + lambda I
   PropertyInt param_translation_weight_form{PRS_TRANSLATION_WEIGHT_OFFSET};        // min(0.01 + d / mean, 1) | clamp(d / mean, 0.01, 1)
   // AlignerSliceMotionModel3D (kitti.conf:747-772): prior on movingInFixed around setMotionPriorMean() (identity by default)
@@ -581,6 +582,7 @@ public:
     std::memcpy(a.sensor_in_robot, _sensor_in_robot, sizeof(_sensor_in_robot));
     a.kernel_weight_form      = (int32_t) param_robustifier_kernel_weight_form.value();
     a.damping_form            = (int32_t) param_damping_form.value();
+    a.step_norm_exit          = param_step_norm_exit.value();
     a.translation_weight_form = (int32_t) param_translation_weight_form.value();
     a.enable_motion_prior = param_enable_motion_model_slice.value() ? 1 : 0;
     for (int i = 0; i < 6; ++i) a.motion_prior_info[i] = param_motion_model_information[i];

@@ -41,10 +41,11 @@ static void rd(std::ifstream& f, std::vector<T>& v, size_t n) {
 
 int main(int argc, char** argv) {
   if (argc < 2) {
-    std::fprintf(stderr, "usage: latency_b1 <frames file> [warmup frames]\n");
+    std::fprintf(stderr, "usage: latency_b1 <frames file> [warmup frames] [step_norm_exit]\n");
     return 2;
   }
   const int warm = argc > 2 ? std::atoi(argv[2]) : 4;
+  const float step_norm_exit = argc > 3 ? (float) std::atof(argv[3]) : 0.0f;  // opt-in early exit (less work than the reference); 0 = off
   std::ifstream f(argv[1], std::ios::binary);
   if (!f) {
     std::fprintf(stderr, "cannot open %s\n", argv[1]);
@@ -124,6 +125,7 @@ int main(int argc, char** argv) {
     fd.param_maximum_estimate_change_norm_for_convergence.setValue(f_eps);
     fd.param_number_of_solver_iterations_per_projection.setValue((size_t) f_every);
     aligner.param_max_iterations.setValue((size_t) a_maxit);
+    aligner.param_step_norm_exit.setValue(step_norm_exit);
     aligner.param_min_num_inliers.setValue((size_t) a_mininl);
     aligner.param_min_num_correspondences.setValue((size_t) a_mincorr);
     aligner.param_damping.setValue(a_damp);
@@ -220,6 +222,7 @@ int main(int argc, char** argv) {
     ap.chi_threshold = a_chi, ap.enable_inverse_depth_weighting = a_idw != 0.f, ap.mean_disparity = -1.0f, ap.damping = a_damp;
     ap.max_iterations = (int32_t) a_maxit, ap.min_num_inliers = (int32_t) a_mininl, ap.min_num_correspondences = (int32_t) a_mincorr;
     ap.stop_at_fixed_point = 1;
+    ap.step_norm_exit      = step_norm_exit;
     prs_pcf* h = nullptr;
     if (prs_pcf_create(c, &pp, &h) != PRS_OK) {
       std::fprintf(stderr, "prs_pcf_create failed\n");
