@@ -505,8 +505,7 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
   __shared__ uint32_t ccount, nhits, hbase;
   __shared__ uint2 hits[kBfmHitCap];   // candidates of a flush round: fixed | moving << 16, distance
   __shared__ uint32_t lhist[kBfLevels];  // ... and their histogram by distance (one global add per level and round)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lg = lane >> 4;
+  const int tid = threadIdx.x, wave = tid >> 6;
   const int frame = (int) blockIdx.y;
   int nf = a.b.n_fixed[frame];
   int nm = a.b.n_moving[frame];
@@ -552,24 +551,45 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
     return v;
   };
   // ---- this wave's fixed rows: A[t][kb] = bits [64 kb + 16 lg, +16) of row row0 + 16 t + li (rows past the end: zeros) ----
-  const int row0       = row0_wg + wave * kBfmRowsWave;
+  // Thread-index values are RE-DERIVED where the chunk loop uses them (the lane from v_mbcnt behind a volatile asm the compiler cannot
+  // hoist, the wave in a scalar register): kept live beside the 64 registers of A they were spilled, and a reload from scratch ahead of
+  // the scoring loop waits for the vector-memory counter -- i.e. for the NEXT chunk's words, requested to be in flight across it.
+  auto lane_now = []() -> int {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+  };
+  const int wave_s     = __builtin_amdgcn_readfirstlane(wave);
+  const int row0       = row0_wg + wave_s * kBfmRowsWave;
   const bool wave_live = row0 < nf;
   bf_v4i A[4][4];
+  auto build_a = [&]() {
+    const int l = lane_now();
+    uint32_t w[4][4];  // (all sixteen words requested before the first is expanded: rows past the end read row nf - 1 and are zeroed)
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int f = row0 + 16 * t + li;
+    for (int t = 0; t < 4; ++t) {
+      const int f  = row0 + 16 * t + (l & 15);
+      const int fr = f < nf ? f : nf - 1;
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const uint32_t w = f < nf ? gdf[8 * f + 2 * kb + (lg >> 1)] : 0u;
-      A[t][kb]         = expand16(lut_a, (w >> (16 * (lg & 1))) & 0xffffu);
+      for (int kb = 0; kb < 4; ++kb) {
+        w[t][kb] = gdf[8 * fr + 2 * kb + (l >> 5)];
+      }
     }
-  }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bool live = row0 + 16 * t + (l & 15) < nf;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        A[t][kb] = expand16(lut_a, live ? (w[t][kb] >> (16 * ((l >> 4) & 1))) & 0xffffu : 0u);
+      }
+    }
+  };
+  build_a();
   // ---- the moving cloud, chunk by chunk ----
   const int n_chunks = (nm + kBfmChunk - 1) / kBfmChunk;
   // thread (row = tid >> 4, piece q = tid & 15) owns bits [16 q, +16) of moving row 64 c + row.  The word is REQUESTED before a chunk
   // is scored and EXPANDED behind it (fetch / stage): requested and consumed back to back, every wave of the workgroup sits out a
   // trip to memory per chunk with the matrix pipe idle
-  const int st_r = tid >> 4, st_q = tid & 15;
   constexpr int kRowsPass = kBfmThreads / 16;          // rows the workgroup stages per pass (16 pieces per row)
   constexpr int kHalves   = kBfmChunk / kRowsPass;     // passes: a thread stages one piece of `kHalves` rows, kRowsPass rows apart
   struct Words {
@@ -577,6 +597,7 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
   };
   auto fetch = [&](const int c) -> Words {
     Words r;
+    const int l = lane_now(), st_r = 4 * wave_s + (l >> 4), st_q = l & 15;
 #pragma unroll
     for (int h = 0; h < kHalves; ++h) {
       const int m = c * kBfmChunk + kRowsPass * h + st_r;
@@ -585,6 +606,7 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
     return r;
   };
   auto stage = [&](const int c, const int buf, const Words ws) {
+    const int l = lane_now(), st_r = 4 * wave_s + (l >> 4), st_q = l & 15;
 #pragma unroll
     for (int h = 0; h < kHalves; ++h) {
       const int row         = kRowsPass * h + st_r;
@@ -616,6 +638,7 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
       w_next = fetch(c + 1);  // in flight while this chunk is scored
     }
     if (wave_live) {
+      const int l = lane_now(), li = l & 15, lg = l >> 4;
 #pragma unroll 1
       for (int bt = 0; bt < kBfmChunk / 16; ++bt) {
         if (c * kBfmChunk + 16 * bt >= nm) {
@@ -654,11 +677,12 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
         const unsigned long long anymask = __ballot(any);
         if (anymask != 0ull) {  // (wave-uniform)
           uint32_t base = 0;
-          if (lane == 0) {
+          if (lane_now() == 0) {
             base = atomicAdd(&ccount, (uint32_t) __popcll(anymask));
           }
           base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
           if (any) {
+            const int lane       = lane_now();
             const uint32_t lslot = base + (uint32_t) __popcll(anymask & ((1ull << lane) - 1ull));
             const uint32_t tmask = (any_t[0] ? 1u : 0u) | (any_t[1] ? 2u : 0u) | (any_t[2] ? 4u : 0u) | (any_t[3] ? 8u : 0u);
             const uint32_t entry = (uint32_t) (c * kBfmChunk + 16 * bt + li) | ((uint32_t) ((row0 + 4 * lg) >> 2) << 16) | (tmask << 28);
@@ -681,6 +705,7 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
     __syncthreads();  // (nobody appends again before everybody has read the count: the decision is uniform)
     if (crowded) {
       flush();
+      build_a();  // (A is not kept across the call: 64 registers the calling convention would spill and reload around it)
     }
   }
   flush();
