@@ -587,40 +587,31 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
   build_a();
   // ---- the moving cloud, chunk by chunk ----
   const int n_chunks = (nm + kBfmChunk - 1) / kBfmChunk;
-  // thread (row = tid >> 4, piece q = tid & 15) owns bits [16 q, +16) of moving row 64 c + row.  The word is REQUESTED before a chunk
-  // is scored and EXPANDED behind it (fetch / stage): requested and consumed back to back, every wave of the workgroup sits out a
-  // trip to memory per chunk with the matrix pipe idle
-  constexpr int kRowsPass = kBfmThreads / 16;          // rows the workgroup stages per pass (16 pieces per row)
-  constexpr int kHalves   = kBfmChunk / kRowsPass;     // passes: a thread stages one piece of `kHalves` rows, kRowsPass rows apart
-  struct Words {
-    uint32_t w[kHalves];
+  // A chunk = 64 rows x 8 words = one 32-bit word per thread: thread (row = tid >> 3, word j = tid & 7) owns bits [32 j, +32) of moving
+  // row 64 c + row = the two 16-bit pieces (K block j >> 1, slices 2 (j & 1) and 2 (j & 1) + 1: the same spot of two neighbouring planes).
+  // One coalesced load at (chunk base + 4 tid), one population count reduced over the 8 lanes of a row.  The word is REQUESTED before a
+  // chunk is scored and EXPANDED behind it (fetch / stage): requested and consumed back to back, every wave of the workgroup sits out a
+  // trip to memory per chunk with the matrix pipe idle.  (Two 16-bit pieces per thread from two rows, the first shape of this kernel,
+  // spent ~110 of a wave's ~235 vector instructions per chunk on staging -- and the kernel is bound by vector issue, not by the matrix
+  // pipe: tools/probes/mfma_valu_overlap_probe.hip.)
+  static_assert(kBfmThreads == kBfmChunk * 8, "one word of the chunk per thread");
+  const uint32_t last_word = 32u * (uint32_t) nm - 4u;  // (byte offset of the cloud's last word: rows past the end read it and are masked)
+  auto fetch = [&](const int c) -> uint32_t {
+    const uint32_t off = (uint32_t) c * (kBfmChunk * 32u) + 256u * (uint32_t) wave_s + 4u * (uint32_t) lane_now();
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(gdm) + (off < last_word ? off : last_word));
   };
-  auto fetch = [&](const int c) -> Words {
-    Words r;
-    const int l = lane_now(), st_r = 4 * wave_s + (l >> 4), st_q = l & 15;
-#pragma unroll
-    for (int h = 0; h < kHalves; ++h) {
-      const int m = c * kBfmChunk + kRowsPass * h + st_r;
-      r.w[h]      = m < nm ? gdm[8 * m + (st_q >> 1)] : 0u;
-    }
-    return r;
-  };
-  auto stage = [&](const int c, const int buf, const Words ws) {
-    const int l = lane_now(), st_r = 4 * wave_s + (l >> 4), st_q = l & 15;
-#pragma unroll
-    for (int h = 0; h < kHalves; ++h) {
-      const int row         = kRowsPass * h + st_r;
-      const uint32_t bits16 = (ws.w[h] >> (16 * (st_q & 1))) & 0xffffu;
-      *reinterpret_cast<bf_v4i*>(&bbuf[buf][(st_q & 3) * kBfmPlane + row * kBfmPlaneRow + 16 * (st_q >> 2)]) = expand16(lut_b, bits16);  // piece q = 4 kb + g
-      // pop(b) of the row: the 16 pieces sit on the 16 lanes of a DPP row
-      int pop = __popc(bits16);
-      pop += __builtin_amdgcn_update_dpp(0, pop, 0x128, 0xf, 0xf, true);  // row_ror:8
-      pop += __builtin_amdgcn_update_dpp(0, pop, 0x124, 0xf, 0xf, true);  // row_ror:4
-      pop += __builtin_amdgcn_update_dpp(0, pop, 0x122, 0xf, 0xf, true);  // row_ror:2
-      pop += __builtin_amdgcn_update_dpp(0, pop, 0x121, 0xf, 0xf, true);  // row_ror:1
-      if (st_q == 0) {
-        popm[buf][row] = c * kBfmChunk + row < nm ? pop : (1 << 20);  // a row past the end never meets the threshold
-      }
+  auto stage = [&](const int c, const int buf, const uint32_t w) {
+    const int l = lane_now(), row = 8 * wave_s + (l >> 3), j = l & 7;
+    unsigned char* dst = &bbuf[buf][(2 * (j & 1)) * kBfmPlane + __mul24(row, kBfmPlaneRow) + 16 * (j >> 1)];
+    *reinterpret_cast<bf_v4i*>(dst)             = expand16(lut_b, w & 0xffffu);
+    *reinterpret_cast<bf_v4i*>(dst + kBfmPlane) = expand16(lut_b, w >> 16);
+    // pop(b) of the row: its 8 words sit on 8 neighbouring lanes
+    int pop = __popc(w);
+    pop += __builtin_amdgcn_update_dpp(0, pop, 0xb1, 0xf, 0xf, true);   // quad_perm [1, 0, 3, 2]
+    pop += __builtin_amdgcn_update_dpp(0, pop, 0x4e, 0xf, 0xf, true);   // quad_perm [2, 3, 0, 1]
+    pop += __builtin_amdgcn_update_dpp(0, pop, 0x141, 0xf, 0xf, true);  // row_half_mirror
+    if (j == 0) {
+      popm[buf][row] = c * kBfmChunk + row < nm ? pop : (1 << 20);  // a row past the end never meets the threshold
     }
   };
   auto flush = [&]() { bf_flush(sink, gdf, gdm, nf, a.lim, clist, hits, lhist, &ccount, &nhits, &hbase); };
@@ -629,11 +620,7 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
   const bf_v4i zero = {0, 0, 0, 0};
   for (int c = 0; c < n_chunks; ++c) {
     const int buf = c & 1;
-    Words w_next;
-#pragma unroll
-    for (int h = 0; h < kHalves; ++h) {
-      w_next.w[h] = 0u;
-    }
+    uint32_t w_next = 0u;
     if (c + 1 < n_chunks) {
       w_next = fetch(c + 1);  // in flight while this chunk is scored
     }
@@ -644,7 +631,7 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
         if (c * kBfmChunk + 16 * bt >= nm) {
           break;  // (uniform) tiles past the end of the moving cloud
         }
-        const unsigned char* brow = &bbuf[buf][lg * kBfmPlane + (16 * bt + li) * kBfmPlaneRow];
+        const unsigned char* brow = &bbuf[buf][__mul24(lg, kBfmPlane) + __mul24(16 * bt + li, kBfmPlaneRow)];
         const int pop_b           = popm[buf][16 * bt + li];
         const int thr             = a.lim - pop_b;  // candidate  <=>  acc < thr
         bf_v4i B[4];
