@@ -393,7 +393,7 @@ constexpr int kBfmChunk    = 64;                                   // moving row
 // (rows of 272 B with the slices side by side: a two-way conflict in every group, SQ_LDS_BANK_CONFLICT = a third of the LDS cycles)
 constexpr int kBfmPlaneRow = 64 + 16;
 constexpr int kBfmPlane    = kBfmChunk * kBfmPlaneRow;
-constexpr int kBfmListCap  = 4096;                                 // (column, row group) entries a workgroup parks in LDS between flushes (16 KB)
+constexpr int kBfmWaveList = 512;                                  // (column, row group) entries a WAVE parks in its own LDS segment between flushes (8 x 2 KB)
 constexpr int kBfmHitCap   = 2048;                                 // candidates of one flush round (16 KB): 128 entries x 16 pairs
 
 // where a candidate of one cloud pair goes: the pair's list, bitmaps and counters (what MODE kBfDense of the popcount kernel
@@ -435,26 +435,21 @@ __device__ __forceinline__ uint2 bf_examine(const uint32_t* __restrict__ gdf, co
                 __popc(f1.z ^ m1.z) + __popc(f1.w ^ m1.w);
   return make_uint2((uint32_t) f | ((uint32_t) m << 16), d < lim ? (uint32_t) d : 0xffffffffu);
 }
-__device__ __attribute__((noinline)) void bf_examine_overflow(const BfSink k, const uint32_t* gdf, const uint32_t* gdm, const uint32_t entry, const int nf,
-                                                              const int lim) {
-  for (int sub = 0; sub < 16; ++sub) {
-    if ((entry >> (28 + (sub >> 2))) & 1u) {
-      const uint2 h = bf_examine(gdf, gdm, entry, sub, nf, lim);
-      if (h.y != 0xffffffffu) {
-        bf_publish(k, h, atomicAdd(k.g_total, 1u));
-      }
-    }
-  }
-}
-
-// The workgroup's parked entries -> the pair's candidate list (all threads, behind a barrier that ends the appends).  Out of line:
-// inlined, its registers pushed the scoring loop of the kernel into spills.  Rounds of 512 entries: their pairs are scored exactly
+// The waves' parked entries -> the pair's candidate list (all threads, behind the barrier that published the waves' counts `wcnt`).
+// Out of line: inlined, its registers pushed the scoring loop of the kernel into spills.  The eight segments are walked as one list
+// (entry v of the concatenation -> segment by the running sums of the counts).  Rounds of 128 entries: their pairs are scored exactly
 // from the packed rows, the candidates among them collected in LDS, ONE slot range taken from the pair's global counter and one add per
 // distance level (a returning atomic per candidate on the one counter of a cloud pair serialises in the L2: 0.4 of 1.3 ms).
 __device__ __attribute__((noinline)) void bf_flush(const BfSink sink, const uint32_t* gdf, const uint32_t* gdm, const int nf, const int lim, const uint32_t* clist,
-                                                   uint2* hits, uint32_t* lhist, uint32_t* ccount, uint32_t* nhits, uint32_t* hbase) {
-  const int tid    = threadIdx.x;
-  const uint32_t n = *ccount < (uint32_t) kBfmListCap ? *ccount : (uint32_t) kBfmListCap;
+                                                   uint2* hits, uint32_t* lhist, const uint32_t* wcnt, uint32_t* nhits, uint32_t* hbase) {
+  const int tid = threadIdx.x;
+  uint32_t end[kBfmThreads / 64];  // running sums of the waves' counts
+  uint32_t n = 0;
+#pragma unroll
+  for (int w = 0; w < kBfmThreads / 64; ++w) {
+    n += wcnt[w];
+    end[w] = n;
+  }
   for (uint32_t e0 = 0; e0 < n; e0 += kBfmHitCap / 16) {
     const uint32_t ne = n - e0 < (uint32_t) kBfmHitCap / 16 ? n - e0 : (uint32_t) kBfmHitCap / 16;
     if (tid == 0) {
@@ -465,7 +460,16 @@ __device__ __attribute__((noinline)) void bf_flush(const BfSink sink, const uint
     }
     __syncthreads();
     for (uint32_t i = tid; i < 16u * ne; i += kBfmThreads) {
-      const uint32_t entry = clist[e0 + (i >> 4)];
+      const uint32_t v = e0 + (i >> 4);
+      uint32_t seg = 0, first = 0;
+#pragma unroll
+      for (int w = 0; w + 1 < kBfmThreads / 64; ++w) {
+        if (v >= end[w]) {
+          seg   = (uint32_t) w + 1u;
+          first = end[w];
+        }
+      }
+      const uint32_t entry = clist[seg * kBfmWaveList + (v - first)];
       if ((entry >> (28 + ((i >> 2) & 3u))) & 1u) {  // (only the tiles whose accumulators met the threshold)
         const uint2 h = bf_examine(gdf, gdm, entry, (int) (i & 15u), nf, lim);
         if (h.y != 0xffffffffu) {
@@ -488,10 +492,6 @@ __device__ __attribute__((noinline)) void bf_flush(const BfSink sink, const uint
     }
     __syncthreads();
   }
-  if (tid == 0) {
-    *ccount = 0;
-  }
-  __syncthreads();
 }
 
 __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(const BfArgs a) {
@@ -500,9 +500,13 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
   __shared__ int popm[2][kBfmChunk];
   __shared__ uint32_t lut_a[16], lut_b[16];  // 4 bits -> 4 bytes: 0 / 1 (fixed side), +1 / -1 (moving side)
   // candidates wait here for a bulk flush: half of a wave's tile rows meet one (a candidate per fixed row and cloud pair is one
-  // per 1024 pairs), and a slot from the GLOBAL counter costs the wave a trip to memory the matrix pipe idles through
-  __shared__ uint32_t clist[kBfmListCap];  // moving row | (first fixed row of the lane's 16) / 4 << 16 | tiles that met the threshold << 28
-  __shared__ uint32_t ccount, nhits, hbase;
+  // per 1024 pairs), and a slot from the GLOBAL counter costs the wave a trip to memory the matrix pipe idles through.  Every wave
+  // appends to its OWN segment and keeps its count in a scalar register: no atomic, no wait in the scoring loop (a shared list paid a
+  // returning LDS atomic per tile row that met the threshold).  The counts meet in `wcnt` once per chunk, double-buffered by chunk
+  // parity so that ONE barrier per chunk serves both the staged rows and the uniform "flush now" decision.
+  __shared__ uint32_t clist[(kBfmThreads / 64) * kBfmWaveList];  // moving row | (first fixed row of the lane's 16) / 4 << 16 | tiles that met the threshold << 28
+  __shared__ uint32_t wcnt[2][kBfmThreads / 64];
+  __shared__ uint32_t nhits, hbase;
   __shared__ uint2 hits[kBfmHitCap];   // candidates of a flush round: fixed | moving << 16, distance
   __shared__ uint32_t lhist[kBfLevels];  // ... and their histogram by distance (one global add per level and round)
   const int tid = threadIdx.x, wave = tid >> 6;
@@ -528,9 +532,6 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
   sink.nw      = a.nw;
   sink.cap     = a.cap;
 
-  if (tid == 0) {
-    ccount = 0;
-  }
   if (tid < 16) {
     uint32_t v01 = 0, vpm = 0;
 #pragma unroll
@@ -614,7 +615,11 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
       popm[buf][row] = c * kBfmChunk + row < nm ? pop : (1 << 20);  // a row past the end never meets the threshold
     }
   };
-  auto flush = [&]() { bf_flush(sink, gdf, gdm, nf, a.lim, clist, hits, lhist, &ccount, &nhits, &hbase); };
+  uint32_t my_count = 0;  // entries in this wave's segment (wave-uniform: a scalar register)
+  auto flush = [&](const int parity) {
+    bf_flush(sink, gdf, gdm, nf, a.lim, clist, hits, lhist, wcnt[parity], &nhits, &hbase);
+    my_count = 0;
+  };
   stage(0, 0, fetch(0));
   __syncthreads();
   const bf_v4i zero = {0, 0, 0, 0};
@@ -663,39 +668,42 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
         // 16 accumulators of a lane apart here cost the matrix pipe a third of its time.
         const unsigned long long anymask = __ballot(any);
         if (anymask != 0ull) {  // (wave-uniform)
-          uint32_t base = 0;
-          if (lane_now() == 0) {
-            base = atomicAdd(&ccount, (uint32_t) __popcll(anymask));
-          }
-          base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
           if (any) {
             const int lane       = lane_now();
-            const uint32_t lslot = base + (uint32_t) __popcll(anymask & ((1ull << lane) - 1ull));
+            const uint32_t lslot = my_count + (uint32_t) __popcll(anymask & ((1ull << lane) - 1ull));
             const uint32_t tmask = (any_t[0] ? 1u : 0u) | (any_t[1] ? 2u : 0u) | (any_t[2] ? 4u : 0u) | (any_t[3] ? 8u : 0u);
-            const uint32_t entry = (uint32_t) (c * kBfmChunk + 16 * bt + li) | ((uint32_t) ((row0 + 4 * lg) >> 2) << 16) | (tmask << 28);
-            if (lslot < (uint32_t) kBfmListCap) {
-              clist[lslot] = entry;
-            } else {  // (list full: examined on the spot, out of line)
-              bf_examine_overflow(sink, gdf, gdm, entry, nf, a.lim);
-            }
+            // (a chunk adds at most 4 tile rows x 64 lanes = 256 entries and a flush is due at 256: the segment cannot overflow)
+            clist[wave_s * kBfmWaveList + (int) lslot] =
+              (uint32_t) (c * kBfmChunk + 16 * bt + (lane & 15)) | ((uint32_t) ((row0 + 4 * (lane >> 4)) >> 2) << 16) | (tmask << 28);
           }
+          my_count += (uint32_t) __popcll(anymask);
         }
       }
     }
     if (c + 1 < n_chunks) {
       stage(c + 1, buf ^ 1, w_next);
     }
-    __syncthreads();  // chunk c + 1 is staged, chunk c is consumed
-    // a dense threshold fills the list: a chunk adds at most 8 waves x 4 tile rows x 64 lanes = 2048 entries, so a list that is below
-    // half its capacity before a chunk cannot overflow in it
-    const bool crowded = ccount >= (uint32_t) kBfmListCap / 2;
-    __syncthreads();  // (nobody appends again before everybody has read the count: the decision is uniform)
+    if (lane_now() == 0) {
+      wcnt[buf][wave_s] = my_count;
+    }
+    __syncthreads();  // chunk c + 1 is staged, chunk c is consumed, the counts of this chunk's parity are published
+    // (the next write to wcnt[buf] is two chunks away, behind the next barrier: every wave reads the same eight counts)
+    bool crowded = false;
+#pragma unroll
+    for (int w = 0; w < kBfmThreads / 64; ++w) {
+      crowded |= wcnt[buf][w] >= (uint32_t) kBfmWaveList / 2;
+    }
     if (crowded) {
-      flush();
+      flush(buf);
       build_a();  // (A is not kept across the call: 64 registers the calling convention would spill and reload around it)
     }
   }
-  flush();
+  // (after the loop the last barrier has published the final counts in wcnt[(n_chunks - 1) & 1], zeros after a flush)
+  if (lane_now() == 0) {
+    wcnt[n_chunks & 1][wave_s] = my_count;
+  }
+  __syncthreads();
+  flush(n_chunks & 1);
 }
 
 static inline uint32_t bf_align16(uint32_t v) {
