@@ -393,8 +393,8 @@ constexpr int kBfmChunk    = 64;                                   // moving row
 // (rows of 272 B with the slices side by side: a two-way conflict in every group, SQ_LDS_BANK_CONFLICT = a third of the LDS cycles)
 constexpr int kBfmPlaneRow = 64 + 16;
 constexpr int kBfmPlane    = kBfmChunk * kBfmPlaneRow;
-constexpr int kBfmWaveList = 512;                                  // (column, row group) entries a WAVE parks in its own LDS segment between flushes (8 x 2 KB)
-constexpr int kBfmHitCap   = 2048;                                 // candidates of one flush round (16 KB): 128 entries x 16 pairs
+constexpr int kBfmWaveList = 1024;                                 // (column, row group, tiles) entries a WAVE parks in its own LDS segment between flushes (8 x 4 KB)
+constexpr int kBfmFlushAt  = 256;                                  // a flush is due when a segment holds this many at the end of a chunk
 
 // where a candidate of one cloud pair goes: the pair's list, bitmaps and counters (what MODE kBfDense of the popcount kernel
 // updates per candidate).  Passed BY VALUE to the out-of-line overflow path: a reference to the kernel's argument block would
@@ -418,31 +418,18 @@ __device__ __forceinline__ void bf_publish(const BfSink k, const uint2 e, const 
     atomicAdd(&k.g_hist[d], 1u);
   }
 }
-// pair `sub` (0..15: tile t = sub >> 2, accumulator r = sub & 3) of a parked entry: the exact distance from the packed rows, and
-// the candidate test of the reference (bruteforce_impl.cpp:52) -- the matrix-core distances only SELECTED the entry.
-// -> (fixed | moving << 16, distance), distance ~0: no candidate
-__device__ __forceinline__ uint2 bf_examine(const uint32_t* __restrict__ gdf, const uint32_t* __restrict__ gdm, const uint32_t entry, const int sub,
-                                            const int nf, const int lim) {
-  const int m = (int) (entry & 0xffffu);
-  const int f = (int) (((entry >> 16) & 0x7ffu) << 2) + 16 * (sub >> 2) + (sub & 3);
-  if (f >= nf) {
-    return make_uint2(0u, 0xffffffffu);
-  }
-  const uint4* pf = reinterpret_cast<const uint4*>(gdf + 8 * f);
-  const uint4* pm = reinterpret_cast<const uint4*>(gdm + 8 * m);
-  const uint4 f0 = pf[0], f1 = pf[1], m0 = pm[0], m1 = pm[1];
-  const int d = __popc(f0.x ^ m0.x) + __popc(f0.y ^ m0.y) + __popc(f0.z ^ m0.z) + __popc(f0.w ^ m0.w) + __popc(f1.x ^ m1.x) + __popc(f1.y ^ m1.y) +
-                __popc(f1.z ^ m1.z) + __popc(f1.w ^ m1.w);
-  return make_uint2((uint32_t) f | ((uint32_t) m << 16), d < lim ? (uint32_t) d : 0xffffffffu);
-}
 // The waves' parked entries -> the pair's candidate list (all threads, behind the barrier that published the waves' counts `wcnt`).
 // Out of line: inlined, its registers pushed the scoring loop of the kernel into spills.  The eight segments are walked as one list
-// (entry v of the concatenation -> segment by the running sums of the counts).  Rounds of 128 entries: their pairs are scored exactly
-// from the packed rows, the candidates among them collected in LDS, ONE slot range taken from the pair's global counter and one add per
-// distance level (a returning atomic per candidate on the one counter of a cloud pair serialises in the L2: 0.4 of 1.3 ms).
+// (entry v of the concatenation -> segment by the running sums of the counts), ONE ENTRY PER THREAD: the 4 pairs (lane's 4 rows of a
+// tile x the entry's column) of the entry's lowest marked tile are scored exactly from the packed rows -- the candidate test of the
+// reference (bruteforce_impl.cpp:52); the matrix-core distances only SELECTED the entry -- then the next marked tile while any lane of
+// the wave has one.  The scoring loop parks one entry per (lane, tile), so the first pass has every lane busy; sixteen threads per
+// entry, one pair each behind the tile mask, ran the scoring code once per 4 entries with 3 lanes in 4 idle (a sixth of the kernel's
+// vector instructions).  Candidates of a pass take ONE slot range per wave from the pair's global counter and one add per distance
+// level and flush (a returning atomic per candidate on the one counter of a cloud pair serialises in the L2: 0.4 of 1.3 ms).
 __device__ __attribute__((noinline)) void bf_flush(const BfSink sink, const uint32_t* gdf, const uint32_t* gdm, const int nf, const int lim, const uint32_t* clist,
-                                                   uint2* hits, uint32_t* lhist, const uint32_t* wcnt, uint32_t* nhits, uint32_t* hbase) {
-  const int tid = threadIdx.x;
+                                                   uint32_t* lhist, const uint32_t* wcnt) {
+  const int tid = threadIdx.x, lane = tid & 63;
   uint32_t end[kBfmThreads / 64];  // running sums of the waves' counts
   uint32_t n = 0;
 #pragma unroll
@@ -450,17 +437,18 @@ __device__ __attribute__((noinline)) void bf_flush(const BfSink sink, const uint
     n += wcnt[w];
     end[w] = n;
   }
-  for (uint32_t e0 = 0; e0 < n; e0 += kBfmHitCap / 16) {
-    const uint32_t ne = n - e0 < (uint32_t) kBfmHitCap / 16 ? n - e0 : (uint32_t) kBfmHitCap / 16;
-    if (tid == 0) {
-      *nhits = 0;
-    }
-    if (tid < kBfLevels) {
-      lhist[tid] = 0;
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < 16u * ne; i += kBfmThreads) {
-      const uint32_t v = e0 + (i >> 4);
+  if (n == 0) {
+    return;  // (block-uniform)
+  }
+  static_assert(kBfLevels <= kBfmThreads, "one thread per distance level");
+  if (tid < kBfLevels) {
+    lhist[tid] = 0;
+  }
+  __syncthreads();
+  for (uint32_t v0 = 0; v0 < n; v0 += kBfmThreads) {
+    const uint32_t v = v0 + (uint32_t) tid;
+    uint32_t entry   = 0;
+    if (v < n) {
       uint32_t seg = 0, first = 0;
 #pragma unroll
       for (int w = 0; w + 1 < kBfmThreads / 64; ++w) {
@@ -469,29 +457,65 @@ __device__ __attribute__((noinline)) void bf_flush(const BfSink sink, const uint
           first = end[w];
         }
       }
-      const uint32_t entry = clist[seg * kBfmWaveList + (v - first)];
-      if ((entry >> (28 + ((i >> 2) & 3u))) & 1u) {  // (only the tiles whose accumulators met the threshold)
-        const uint2 h = bf_examine(gdf, gdm, entry, (int) (i & 15u), nf, lim);
-        if (h.y != 0xffffffffu) {
-          hits[atomicAdd(nhits, 1u)] = h;
-          atomicAdd(&lhist[h.y], 1u);
+      entry = clist[seg * kBfmWaveList + (v - first)];
+    }
+    uint32_t tiles = entry >> 28;
+    const int m    = (int) (entry & 0xffffu);
+    const int f00  = (int) (((entry >> 16) & 0x7ffu) << 2);
+    uint4 m0 = make_uint4(0u, 0u, 0u, 0u), m1 = m0;
+    if (tiles != 0u) {
+      const uint4* pm = reinterpret_cast<const uint4*>(gdm + 8 * m);
+      m0 = pm[0];
+      m1 = pm[1];
+    }
+    while (__any(tiles != 0u)) {  // (wave-uniform)
+      int d[4]    = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+      int f_first = 0;
+      if (tiles != 0u) {
+        const int t = __ffs((int) tiles) - 1;
+        tiles &= tiles - 1u;
+        f_first = f00 + 16 * t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (f_first + r < nf) {
+            const uint4* pf = reinterpret_cast<const uint4*>(gdf + 8 * (f_first + r));
+            const uint4 a0 = pf[0], a1 = pf[1];
+            d[r] = __popc(a0.x ^ m0.x) + __popc(a0.y ^ m0.y) + __popc(a0.z ^ m0.z) + __popc(a0.w ^ m0.w) + __popc(a1.x ^ m1.x) + __popc(a1.y ^ m1.y) +
+                   __popc(a1.z ^ m1.z) + __popc(a1.w ^ m1.w);
+          }
+        }
+      }
+      const uint32_t mine = (d[0] < lim ? 1u : 0u) + (d[1] < lim ? 1u : 0u) + (d[2] < lim ? 1u : 0u) + (d[3] < lim ? 1u : 0u);
+      uint32_t incl       = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, 64);
+        if (lane >= o) {
+          incl += up;
+        }
+      }
+      const uint32_t total = __shfl(incl, 63, 64);
+      if (total != 0u) {  // (wave-uniform)
+        uint32_t base = 0;
+        if (lane == 0) {
+          base = atomicAdd(sink.g_total, total);
+        }
+        uint32_t slot = (uint32_t) __shfl((int) base, 0, 64) + incl - mine;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (d[r] < lim) {
+            bf_publish(sink, make_uint2((uint32_t) (f_first + r) | ((uint32_t) m << 16), (uint32_t) d[r]), slot++, false);
+            atomicAdd(&lhist[d[r]], 1u);
+          }
         }
       }
     }
-    __syncthreads();
-    const uint32_t nh = *nhits;
-    if (tid == 0 && nh > 0) {
-      *hbase = atomicAdd(sink.g_total, nh);
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < nh; i += kBfmThreads) {
-      bf_publish(sink, hits[i], *hbase + i, false);
-    }
-    if (tid < kBfLevels && lhist[tid] != 0) {
-      atomicAdd(&sink.g_hist[tid], lhist[tid]);
-    }
-    __syncthreads();
   }
+  __syncthreads();
+  if (tid < kBfLevels && lhist[tid] != 0) {
+    atomicAdd(&sink.g_hist[tid], lhist[tid]);
+  }
+  __syncthreads();  // (the histogram and the segments are free again)
 }
 
 __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(const BfArgs a) {
@@ -506,9 +530,7 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
   // parity so that ONE barrier per chunk serves both the staged rows and the uniform "flush now" decision.
   __shared__ uint32_t clist[(kBfmThreads / 64) * kBfmWaveList];  // moving row | (first fixed row of the lane's 16) / 4 << 16 | tiles that met the threshold << 28
   __shared__ uint32_t wcnt[2][kBfmThreads / 64];
-  __shared__ uint32_t nhits, hbase;
-  __shared__ uint2 hits[kBfmHitCap];   // candidates of a flush round: fixed | moving << 16, distance
-  __shared__ uint32_t lhist[kBfLevels];  // ... and their histogram by distance (one global add per level and round)
+  __shared__ uint32_t lhist[kBfLevels];  // candidates of a flush by distance (one global add per level and flush)
   const int tid = threadIdx.x, wave = tid >> 6;
   const int frame = (int) blockIdx.y;
   int nf = a.b.n_fixed[frame];
@@ -617,7 +639,7 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
   };
   uint32_t my_count = 0;  // entries in this wave's segment (wave-uniform: a scalar register)
   auto flush = [&](const int parity) {
-    bf_flush(sink, gdf, gdm, nf, a.lim, clist, hits, lhist, wcnt[parity], &nhits, &hbase);
+    bf_flush(sink, gdf, gdm, nf, a.lim, clist, lhist, wcnt[parity]);
     my_count = 0;
   };
   stage(0, 0, fetch(0));
@@ -661,22 +683,38 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
         for (int t = 0; t < 4; ++t) {
           any_t[t] = (acc[t].x < thr) | (acc[t].y < thr) | (acc[t].z < thr) | (acc[t].w < thr);
         }
-        const bool any = any_t[0] | any_t[1] | any_t[2] | any_t[3];
-        // A lane whose column met the threshold in ANY of its 16 rows parks (column, row group): the 16 pairs are scored again,
-        // exactly, from the packed rows when the list is flushed.  One LDS slot range per wave and tile row, no per-pair branch:
-        // half of a wave's tile rows hold a candidate (one per fixed row and cloud pair = one per 1024 pairs), and telling the
-        // 16 accumulators of a lane apart here cost the matrix pipe a third of its time.
-        const unsigned long long anymask = __ballot(any);
+        // A lane whose column met the threshold in one of its 4 rows of a tile parks (column, row group, tile): the 4 pairs are scored
+        // again, exactly, from the packed rows when the list is flushed.  No per-pair branch here: half of a wave's tile rows hold a
+        // candidate (one per fixed row and cloud pair = one per 1024 pairs), and telling the accumulators of a lane apart in this
+        // loop cost the matrix pipe a third of its time.  One entry per (lane, tile) while the segment has room for a worst-case tile
+        // row (4 x 64), else one per lane with all its tiles marked: a chunk then adds at most 256 + 256 + 64 + 64 to a count below
+        // kBfmFlushAt, so a segment never overflows.
+        const unsigned long long mask_t[4] = {__ballot(any_t[0]), __ballot(any_t[1]), __ballot(any_t[2]), __ballot(any_t[3])};
+        const unsigned long long anymask   = mask_t[0] | mask_t[1] | mask_t[2] | mask_t[3];
         if (anymask != 0ull) {  // (wave-uniform)
-          if (any) {
-            const int lane       = lane_now();
-            const uint32_t lslot = my_count + (uint32_t) __popcll(anymask & ((1ull << lane) - 1ull));
-            const uint32_t tmask = (any_t[0] ? 1u : 0u) | (any_t[1] ? 2u : 0u) | (any_t[2] ? 4u : 0u) | (any_t[3] ? 8u : 0u);
-            // (a chunk adds at most 4 tile rows x 64 lanes = 256 entries and a flush is due at 256: the segment cannot overflow)
-            clist[wave_s * kBfmWaveList + (int) lslot] =
-              (uint32_t) (c * kBfmChunk + 16 * bt + (lane & 15)) | ((uint32_t) ((row0 + 4 * (lane >> 4)) >> 2) << 16) | (tmask << 28);
+          const int lane            = lane_now();
+          const uint32_t base_entry = (uint32_t) (c * kBfmChunk + 16 * bt + (lane & 15)) | ((uint32_t) ((row0 + 4 * (lane >> 4)) >> 2) << 16);
+          uint32_t* segment         = &clist[wave_s * kBfmWaveList];
+          auto rank = [](const unsigned long long mk) -> uint32_t {  // set bits below this lane
+            return __builtin_amdgcn_mbcnt_hi((uint32_t) (mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mk, 0u));
+          };
+          if (my_count <= (uint32_t) kBfmWaveList / 2) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              if (mask_t[t] != 0ull) {  // (wave-uniform)
+                if (any_t[t]) {
+                  segment[my_count + rank(mask_t[t])] = base_entry | (1u << (28 + t));
+                }
+                my_count += (uint32_t) __popcll(mask_t[t]);
+              }
+            }
+          } else {
+            if (any_t[0] | any_t[1] | any_t[2] | any_t[3]) {
+              const uint32_t tmask = (any_t[0] ? 1u : 0u) | (any_t[1] ? 2u : 0u) | (any_t[2] ? 4u : 0u) | (any_t[3] ? 8u : 0u);
+              segment[my_count + rank(anymask)] = base_entry | (tmask << 28);
+            }
+            my_count += (uint32_t) __popcll(anymask);
           }
-          my_count += (uint32_t) __popcll(anymask);
         }
       }
     }
@@ -691,7 +729,7 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
     bool crowded = false;
 #pragma unroll
     for (int w = 0; w < kBfmThreads / 64; ++w) {
-      crowded |= wcnt[buf][w] >= (uint32_t) kBfmWaveList / 2;
+      crowded |= wcnt[buf][w] >= (uint32_t) kBfmFlushAt;
     }
     if (crowded) {
       flush(buf);
