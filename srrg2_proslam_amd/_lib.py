@@ -278,6 +278,7 @@ SYMBOLS = {
     "prs_context_use_own_stream": (C.c_int, [_vp]),
     "prs_context_synchronize": (C.c_int, [_vp]),
     "prs_context_enable_timing": (C.c_int, [_vp, C.c_int32]),
+    "prs_context_set_bruteforce_dense_phase": (C.c_int, [_vp, C.c_int32]),
     "prs_context_get_align_timing": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "prs_context_get_align_round_timing": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "prs_last_error": (C.c_char_p, [_vp]),

@@ -216,7 +216,7 @@ int prs_context_create(int device_id, prs_context** out) {
   const char* p96      = getenv("PRS_PREFILTER_96_LIMIT");
   ctx->prefilter_96_limit = p96 ? atoi(p96) : 32;
   const char* bfm      = getenv("PRS_BF_MFMA");
-  ctx->bf_mfma         = bfm ? (bfm[0] == '1' ? 1 : 0) : -1;
+  ctx->bf_mfma         = !bfm ? PRS_BF_DENSE_POPCOUNT : (bfm[0] == '1' ? PRS_BF_DENSE_MATRIX : (bfm[0] == 'a' ? PRS_BF_DENSE_MATRIX_WHEN_FULL : PRS_BF_DENSE_POPCOUNT));
   const char* mfused   = getenv("PRS_MERGE_FUSED");
   ctx->merge_fused     = mfused && mfused[0] == '1';
   *out                 = ctx;
@@ -258,6 +258,17 @@ int prs_context_destroy(prs_context* ctx) {
     }
   }
   delete ctx;
+  return PRS_OK;
+}
+
+int prs_context_set_bruteforce_dense_phase(prs_context* ctx, int32_t mode) {
+  if (!ctx) {
+    return PRS_ERR_NULL;
+  }
+  if (mode != PRS_BF_DENSE_POPCOUNT && mode != PRS_BF_DENSE_MATRIX_WHEN_FULL && mode != PRS_BF_DENSE_MATRIX) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_context_set_bruteforce_dense_phase: mode must be one of PRS_BF_DENSE_*");
+  }
+  ctx->bf_mfma = mode;
   return PRS_OK;
 }
 

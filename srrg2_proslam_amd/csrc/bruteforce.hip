@@ -786,11 +786,14 @@ int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* param
       cus = prop.multiProcessorCount;
     }
   }
-  // The dense phase on the matrix cores (bruteforce_dense_mfma_kernel) + the registration launch when the batch fills the chip with
-  // its 512-row workgroups (1024 pairs of 2000-point clouds: 2.77 -> 1.30 ms); a handful of pairs keeps the popcount kernels, whose
-  // split shape spreads a pair over more workgroups (8 pairs: 0.08 against 0.14 ms).  PRS_BF_MFMA=1 / 0 forces either (tests, A-B).
+  // The dense phase on the matrix cores (bruteforce_dense_mfma_kernel) + the registration launch: OPT-IN
+  // (prs_context_set_bruteforce_dense_phase).  It pays when candidates are rare (uniform random rows, 1024 pairs of 2000-point clouds:
+  // 2.77 -> 1.02 ms) and costs when they are not (real descriptors, 1.6 % of the pairs within 50 bits: 1.20 -> 1.86 ms), and the
+  // library cannot tell which input it has.  PRS_BF_DENSE_MATRIX_WHEN_FULL: when the batch fills the chip with its 512-row workgroups;
+  // a handful of pairs keeps the popcount kernels, whose split shape spreads a pair over more workgroups (8 pairs: 0.08 against 0.12 ms).
   const int mfma_wgs = batch->batch * ((batch->fixed_stride + kBfmRowsWg - 1) / kBfmRowsWg);
-  const bool mfma    = ctx->bf_mfma > 0 || (ctx->bf_mfma < 0 && batch->fixed_stride >= 256 && batch->moving_stride >= 64 && mfma_wgs >= cus);
+  const bool mfma    = ctx->bf_mfma == PRS_BF_DENSE_MATRIX ||
+                    (ctx->bf_mfma == PRS_BF_DENSE_MATRIX_WHEN_FULL && batch->fixed_stride >= 256 && batch->moving_stride >= 64 && mfma_wgs >= cus);
   const int grid = mfma ? batch->batch : (batch->batch < cus ? batch->batch : cus);
   // few pairs: spread the dense phase of each pair over several workgroups (slices of >= 64 moving rows)
   a.chunks = 1;

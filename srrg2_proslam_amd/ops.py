@@ -68,6 +68,11 @@ class Context:
     def synchronize(self):
         _check(self, _lib.load().prs_context_synchronize(self._h), "prs_context_synchronize")
 
+    def set_bruteforce_dense_phase(self, mode):
+        """BF_DENSE_POPCOUNT (default) / BF_DENSE_MATRIX_WHEN_FULL / BF_DENSE_MATRIX: which kernels score the brute-force matcher's
+        N_f x N_m pairs (prs_context_set_bruteforce_dense_phase; same results, the matrix cores pay only when candidates are rare)"""
+        _check(self, _lib.load().prs_context_set_bruteforce_dense_phase(self._h, int(mode)), "prs_context_set_bruteforce_dense_phase")
+
     def enable_timing(self, on=True):
         """HIP-event timing of the aligner's two kernels inside align_batch (measurement only)"""
         _check(self, _lib.load().prs_context_enable_timing(self._h, 1 if on else 0), "prs_context_enable_timing")
@@ -835,6 +840,7 @@ def motion_predict_batch(ctx, pose_prev2, pose_prev1, pose_pred):
 
 # ---- intensity feature extraction (sensor_processing/feature_extractors) ----
 SELECT_CANONICAL, SELECT_LIBSTDCXX = 0, 1
+BF_DENSE_POPCOUNT, BF_DENSE_MATRIX_WHEN_FULL, BF_DENSE_MATRIX = 0, 1, 2  # include/proslam_hip.h PRS_BF_DENSE_*
 
 
 def extractor_params(threshold=15, nms=1, target=1000, vertical=3, horizontal=3, selection_order=SELECT_CANONICAL, max_raw_detections=0):

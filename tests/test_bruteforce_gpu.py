@@ -11,16 +11,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module", params=["popcount", "mfma"])
 def hip_ctx(request):
-    """every test of this module on both dense phases: the popcount kernels (PRS_BF_MFMA=0) and the matrix-core kernel
-    (PRS_BF_MFMA=1: v_mfma_i32_16x16x64_i8 + exact re-scoring of the selected entries), whatever the batch size would pick"""
-    import os
-    old = os.environ.get("PRS_BF_MFMA")
-    os.environ["PRS_BF_MFMA"] = "1" if request.param == "mfma" else "0"
-    ctx = ops.Context(0)  # (the switch is read when the context is created)
-    if old is None:
-        del os.environ["PRS_BF_MFMA"]
-    else:
-        os.environ["PRS_BF_MFMA"] = old
+    """every test of this module on both dense phases: the popcount kernels (the default) and the matrix-core kernel
+    (PRS_BF_DENSE_MATRIX: v_mfma_i32_16x16x64_i8 + exact re-scoring of the selected entries), whatever the batch size"""
+    ctx = ops.Context(0)
+    ctx.set_bruteforce_dense_phase(ops.BF_DENSE_MATRIX if request.param == "mfma" else ops.BF_DENSE_POPCOUNT)
     yield ctx
     ctx.close()
 
@@ -150,3 +144,15 @@ def test_error_and_warning_contract(hip_ctx):
     ref, ref_flags = ob.bruteforce_match(big, big, p.maximum_descriptor_distance, p.maximum_distance_ratio_to_second_best)
     assert L.prs_bruteforce_match(hip_ctx._h, C.byref(p), vp(big), 300, vp(big), 300, vp(o2), 300, C.byref(n)) == ref_flags
     assert n.value == len(ref)
+
+
+def test_dense_phase_setter(hip_ctx):
+    # prs_context_set_bruteforce_dense_phase: the three PRS_BF_DENSE_* modes are accepted, anything else is refused loudly
+    probe = ops.Context(0)
+    try:
+        for mode in (ops.BF_DENSE_POPCOUNT, ops.BF_DENSE_MATRIX_WHEN_FULL, ops.BF_DENSE_MATRIX):
+            probe.set_bruteforce_dense_phase(mode)
+        with pytest.raises(RuntimeError, match="PRS_BF_DENSE"):
+            probe.set_bruteforce_dense_phase(7)
+    finally:
+        probe.close()
