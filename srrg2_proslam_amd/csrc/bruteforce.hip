@@ -168,48 +168,131 @@ __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) 
     if (MODE == kBfRegister) {
       m_begin = m_end = 0;
     }
+    // Candidates are NOT handled where they are found: a lane shifts the outcome of every comparison into a 32-bit record (one
+    // v_cmp + one v_addc per pair, no branch), and after 32 moving rows the wave drains its records: every lane with a marked row
+    // re-scores it (the row through a per-lane load: the block's rows are hot in the cache) and publishes it, one slot range per wave
+    // and round from the candidate counter.  On real descriptors 1.6 % of the pairs are candidates (two thirds of a wave's rows
+    // hold one): handling them inside the row loop ran the publish path -- a returning atomic on the pair's one counter, five more
+    // atomics, a store -- twenty times per 32 rows with one or two lanes busy; the drain runs it three or four times with a third
+    // of the lanes busy.  (Uniform random rows: one candidate per fixed point, nothing to gain or lose.)
+    if (MODE == kBfDense) {
+      for (int i = tid; i < kBfLevels; i += kBfThreads) {
+        hist[i] = 0u;  // (this workgroup's candidates by level: added to the pair's histogram once, behind the loop)
+      }
+      __syncthreads();
+    }
+    uint32_t hit[KPT], cnt_mine[KPT];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+      hit[k]      = 0u;
+      cnt_mine[k] = 0u;  // candidates of this thread's fixed row(s): a register, stored / added once
+    }
+    const uint32_t* __restrict__ gdm_lane =
+      reinterpret_cast<const uint32_t*>(a.b.moving_desc + (size_t) frame * a.b.moving_stride * PRS_DESC_BYTES);  // (per-lane rows of the drain)
+    auto drain = [&](const int block_first, const int block_rows) {
+#pragma unroll
+      for (int k = 0; k < KPT; ++k) {
+        const int f = k * kBfThreads + tid;
+        uint32_t h  = f < nf ? hit[k] : 0u;
+        hit[k]      = 0u;
+        // one slot range per wave and block: the lanes' counts summed along the wave (six DPP adds), ONE returning add on the candidate
+        // counter, then every lane walks its own marks with no further exchange (non-returning atomics and stores only)
+        const uint32_t mine = (uint32_t) __popc(h);
+        uint32_t incl       = mine;
+        incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x111, 0xf, 0xf, false);  // row_shr:1
+        incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x112, 0xf, 0xf, false);  // row_shr:2
+        incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x114, 0xf, 0xf, false);  // row_shr:4
+        incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x118, 0xf, 0xf, false);  // row_shr:8
+        incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+        incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+        const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+        if (total == 0u) {
+          continue;  // (wave-uniform)
+        }
+        uint32_t base = 0;
+        if (lane == 0) {
+          base = MODE == kBfDense ? atomicAdd(g_total, total) : atomicAdd(&misc[0], total);
+        }
+        uint32_t slot = (uint32_t) __builtin_amdgcn_readfirstlane((int) base) + incl - mine;
+        while (h != 0u) {  // :52
+          const int b = 31 - __clz((int) h);  // the record's bit j holds row block_first + block_rows - 1 - j
+          h &= ~(1u << b);
+          const int m     = block_first + block_rows - 1 - b;
+          const uint4* pm = reinterpret_cast<const uint4*>(gdm_lane + 8 * m);
+          const uint4 m0 = pm[0], m1 = pm[1];
+          const int d = __popc(fd[k][0] ^ m0.x) + __popc(fd[k][1] ^ m0.y) + __popc(fd[k][2] ^ m0.z) + __popc(fd[k][3] ^ m0.w) + __popc(fd[k][4] ^ m1.x) +
+                        __popc(fd[k][5] ^ m1.y) + __popc(fd[k][6] ^ m1.z) + __popc(fd[k][7] ^ m1.w);
+          if (slot < (uint32_t) a.cap) {
+            cand[slot] = make_uint2((uint32_t) f | ((uint32_t) m << 16), (uint32_t) d);
+          }
+          ++slot;
+          const uint32_t bit = 1u << (d & 31);
+          atomicOr(&bm_f[f * a.nw + (d >> 5)], bit);
+          atomicOr(&bm_m[m * a.nw + (d >> 5)], bit);
+          if (MODE == kBfDense) {
+            atomicAdd(&g_cnt_m[m], 1u);
+          } else {
+            atomicAdd(&cnt_m[m], 1u);
+          }
+          atomicAdd(&hist[d], 1u);
+        }
+        cnt_mine[k] += mine;
+      }
+    };
     uint32_t md_next[8];
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
       md_next[w] = m_begin < m_end ? gdm[8 * m_begin + w] : 0u;
     }
-    for (int m = m_begin; m < m_end; ++m) {
-      // uniform address: the row travels through the scalar cache into SGPRs; the next row is
-      // requested before this one is scored
-      uint32_t md[8];
-      const int mn = m + 1 < m_end ? m + 1 : m;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) {
-        md[w]      = md_next[w];
-        md_next[w] = gdm[8 * mn + w];
-      }
-#pragma unroll
-      for (int k = 0; k < KPT; ++k) {
-        int d = 0;
+    for (int block_first = m_begin; block_first < m_end; block_first += 32) {
+      const int block_rows = m_end - block_first < 32 ? m_end - block_first : 32;
+      // the block's 32 rows (1 KB) touched once by the wave's 64 lanes: they reach the SCALAR cache through the row loop, the drain's
+      // per-lane loads go through the vector L1 and would each wait for the L2 otherwise
+      const int touch_row = block_first + (lane >> 1) < m_end ? block_first + (lane >> 1) : m_end - 1;
+      const uint4 touched = *reinterpret_cast<const uint4*>(gdm_lane + 8 * touch_row + 4 * (lane & 1));
+      for (int j = 0; j < block_rows; ++j) {
+        const int m = block_first + j;
+        // uniform address: the row travels through the scalar cache into SGPRs; the next row is
+        // requested before this one is scored
+        uint32_t md[8];
+        const int mn = m + 1 < m_end ? m + 1 : m;
 #pragma unroll
         for (int w = 0; w < 8; ++w) {
-          d += __popc(fd[k][w] ^ md[w]);
+          md[w]      = md_next[w];
+          md_next[w] = gdm[8 * mn + w];
         }
-        const int f = k * kBfThreads + tid;
-        if (d < a.lim && f < nf) {  // :52
-          const uint32_t slot = MODE == kBfDense ? atomicAdd(g_total, 1u) : atomicAdd(&misc[0], 1u);
-          if (slot < (uint32_t) a.cap) {
-            cand[slot] = make_uint2((uint32_t) f | ((uint32_t) m << 16), (uint32_t) d);
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+          int d = 0;
+#pragma unroll
+          for (int w = 0; w < 8; ++w) {
+            d += __popc(fd[k][w] ^ md[w]);
           }
-          const uint32_t bit = 1u << (d & 31);
-          atomicOr(&bm_f[f * a.nw + (d >> 5)], bit);
-          atomicOr(&bm_m[m * a.nw + (d >> 5)], bit);
-          if (MODE == kBfDense) {
-            atomicAdd(&g_cnt_f[f], 1u);
-            atomicAdd(&g_cnt_m[m], 1u);
-            atomicAdd(&g_hist[d], 1u);
-          } else {
-            atomicAdd(&cnt_f[f], 1u);
-            atomicAdd(&cnt_m[m], 1u);
-            atomicAdd(&hist[d], 1u);
-          }
+          // record = 2 * record + (d < lim)
+          asm("v_cmp_gt_i32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hit[k]) : "v"(d), "s"(a.lim) : "vcc");
         }
       }
+      asm volatile("" ::"v"(touched.x), "v"(touched.y), "v"(touched.z), "v"(touched.w));  // (the touch has landed)
+      drain(block_first, block_rows);
+    }
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+      const int f = k * kBfThreads + tid;
+      if (f < nf && MODE == kBfFused) {
+        cnt_f[f] = cnt_mine[k];
+      }
+      if (f < nf && MODE == kBfDense && cnt_mine[k] != 0u) {
+        atomicAdd(&g_cnt_f[f], cnt_mine[k]);
+      }
+    }
+    if (MODE == kBfDense) {
+      __syncthreads();
+      for (int i = tid; i < kBfLevels; i += kBfThreads) {
+        if (hist[i] != 0u) {
+          atomicAdd(&g_hist[i], hist[i]);
+        }
+      }
+      __syncthreads();
     }
     if (MODE == kBfDense) {
       continue;  // the registration launch takes over
