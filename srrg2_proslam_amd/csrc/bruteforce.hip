@@ -41,6 +41,11 @@ struct BfArgs {
   uint32_t* bitmaps;   // [grid][(fixed_stride + moving_stride) * nw]
   // LDS carve (bytes)
   uint32_t off_cnt_f, off_cnt_m, off_reg_f, off_reg_m, off_acc, off_hist;
+  // what of the registration state lives in LDS instead of the scratch rows in global memory (the registration phases are chains of
+  // dependent reads: one real cloud pair of 1350 x 1350 points spent 80 of its 135 us on them at L2 latency):
+  uint32_t off_bm;     // the distance bitmaps of the fixed / moving indices ((fixed_stride + moving_stride) * nw words), ~0: global
+  uint32_t off_lvl;    // the candidates grouped by level, 4 bytes each (fixed | moving << 13 | lowe ok << 29) ...
+  int lvl_cap;         // ... for cloud pairs with at most this many candidates (0: always global, 8 bytes each)
   // few cloud pairs: the dense phase is spread over `chunks` workgroups per pair (each takes a slice of the
   // moving cloud) that accumulate into global memory; one workgroup per pair then registers the candidates
   int chunks;
@@ -52,14 +57,15 @@ enum { kBfFused = 0, kBfDense = 1, kBfRegister = 2 };
 // Lowe's ratio against the sorted distance list of one index (bruteforce_impl.cpp:157-199):
 // a single-entry list passes (:181-184); otherwise the first strictly larger distance is the second
 // best, none = equal = reject (:163-165), else best / second < maximum ratio in float.
-__device__ __forceinline__ bool lowe_ok(uint32_t* bm, int nw, uint32_t count, int d, float max_ratio) {
+template <bool LDS>
+__device__ __forceinline__ bool lowe_ok(const uint32_t* bm, int nw, uint32_t count, int d, float max_ratio) {
   if (count == 1) {
     return true;
   }
   int second = -1;
   int w      = d >> 5;
   // the rows are updated with device-scope atomics: read them the same way (never from a stale L1 line)
-  uint32_t word = __hip_atomic_load(&bm[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~((2u << (d & 31)) - 1u);  // bits above d
+  uint32_t word = (LDS ? bm[w] : __hip_atomic_load(&bm[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & ~((2u << (d & 31)) - 1u);  // bits above d
   while (true) {
     if (word) {
       second = (w << 5) + __ffs(word) - 1;
@@ -68,7 +74,7 @@ __device__ __forceinline__ bool lowe_ok(uint32_t* bm, int nw, uint32_t count, in
     if (++w >= nw) {
       break;
     }
-    word = __hip_atomic_load(&bm[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    word = LDS ? bm[w] : __hip_atomic_load(&bm[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (second < 0) {
     return false;
@@ -89,6 +95,10 @@ __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) 
   uint32_t* lfill  = lstart + kBfLevels + 1;                             // [256]
   uint32_t* hist2  = lfill + kBfLevels;                                  // [256] registrations per level
   uint32_t* misc   = hist2 + kBfLevels;                                  // [0] candidates, [1] registrations
+  const bool bm_lds = MODE != kBfDense && a.off_bm != 0xffffffffu;       // (uniform)
+  uint32_t* lbm_f  = reinterpret_cast<uint32_t*>(smem + (bm_lds ? a.off_bm : 0u));
+  uint32_t* lbm_m  = lbm_f + (size_t) a.b.fixed_stride * a.nw;
+  uint32_t* lvl    = reinterpret_cast<uint32_t*>(smem + a.off_lvl);
   const int tid    = threadIdx.x;
   const int lane   = tid & 63;
   const int wave   = tid >> 6;
@@ -131,11 +141,15 @@ __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) 
         cnt_m[i] = MODE == kBfRegister ? g_cnt_m[i] : 0u;
         reg_m[i] = 0;
       }
-      if (MODE == kBfFused) {
+      if (MODE == kBfFused || bm_lds) {
         for (int i = tid; i < (nf + nm) * a.nw; i += kBfThreads) {
           // fixed rows first, moving rows behind them (bm_m = bm_f + fixed_stride * nw)
           const int idx = i < nf * a.nw ? i : (a.b.fixed_stride * a.nw + (i - nf * a.nw));
-          bm_f[idx]     = 0;
+          if (bm_lds) {
+            lbm_f[idx] = MODE == kBfRegister ? bm_f[idx] : 0u;  // (the dense launch's rows, complete at the kernel boundary)
+          } else {
+            bm_f[idx] = 0;
+          }
         }
       }
       for (int i = tid; i < 4 * kBfLevels + 8; i += kBfThreads) {
@@ -227,8 +241,13 @@ __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) 
           }
           ++slot;
           const uint32_t bit = 1u << (d & 31);
-          atomicOr(&bm_f[f * a.nw + (d >> 5)], bit);
-          atomicOr(&bm_m[m * a.nw + (d >> 5)], bit);
+          if (bm_lds) {
+            atomicOr(&lbm_f[f * a.nw + (d >> 5)], bit);
+            atomicOr(&lbm_m[m * a.nw + (d >> 5)], bit);
+          } else {
+            atomicOr(&bm_f[f * a.nw + (d >> 5)], bit);
+            atomicOr(&bm_m[m * a.nw + (d >> 5)], bit);
+          }
           if (MODE == kBfDense) {
             atomicAdd(&g_cnt_m[m], 1u);
           } else {
@@ -339,15 +358,22 @@ __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) 
       }
     }
     __syncthreads();
+    const bool lvl_lds = n_cand <= (uint32_t) a.lvl_cap;  // (uniform) this pair's level lists fit the LDS
     for (uint32_t i = tid; i < n_cand; i += kBfThreads) {
       const uint2 c  = cand[i];
       const int f    = (int) (c.x & 0xffffu);
       const int m    = (int) (c.x >> 16);
       const int d    = (int) c.y;
-      const bool ok  = lowe_ok(bm_f + (size_t) f * a.nw, a.nw, cnt_f[f], d, a.max_ratio) &&
-                      lowe_ok(bm_m + (size_t) m * a.nw, a.nw, cnt_m[m], d, a.max_ratio);  // :279-284
+      const bool ok  = bm_lds ? lowe_ok<true>(lbm_f + (size_t) f * a.nw, a.nw, cnt_f[f], d, a.max_ratio) &&
+                                 lowe_ok<true>(lbm_m + (size_t) m * a.nw, a.nw, cnt_m[m], d, a.max_ratio)
+                              : lowe_ok<false>(bm_f + (size_t) f * a.nw, a.nw, cnt_f[f], d, a.max_ratio) &&
+                                 lowe_ok<false>(bm_m + (size_t) m * a.nw, a.nw, cnt_m[m], d, a.max_ratio);  // :279-284
       const uint32_t pos = lstart[d] + atomicAdd(&lfill[d], 1u);
-      by_level[pos]      = make_uint2(c.x, ok ? 1u : 0u);
+      if (lvl_lds) {
+        lvl[pos] = (uint32_t) f | ((uint32_t) m << 13) | (ok ? 1u << 29 : 0u);
+      } else {
+        by_level[pos] = make_uint2(c.x, ok ? 1u : 0u);
+      }
     }
     __syncthreads();
     // the candidate counts are dead: the arrays now count pool members per index
@@ -361,6 +387,18 @@ __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) 
     __syncthreads();
 
     // ---- phase 3: one pool per distinct distance, ascending (:113-157, :247-293) ----------------
+    auto level_entry = [&](const uint32_t i, int& f, int& m) -> bool {  // -> Lowe's ratio holds on both sides
+      if (lvl_lds) {
+        const uint32_t x = lvl[i];
+        f = (int) (x & 0x1fffu);
+        m = (int) ((x >> 13) & 0xffffu);
+        return (x >> 29) != 0u;
+      }
+      const uint2 c = by_level[i];
+      f = (int) (c.x & 0xffffu);
+      m = (int) (c.x >> 16);
+      return c.y != 0u;
+    };
     for (int d = 0; d < a.lim && d < kBfLevels; ++d) {
       const uint32_t s0 = lstart[d], s1 = lstart[d + 1];
       if (s0 == s1) {
@@ -368,8 +406,8 @@ __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) 
       }
       // pool = candidates of this distance whose indices are both unregistered (:117-118)
       for (uint32_t i = s0 + tid; i < s1; i += kBfThreads) {
-        const uint32_t x = by_level[i].x;
-        const int f = (int) (x & 0xffffu), m = (int) (x >> 16);
+        int f, m;
+        (void) level_entry(i, f, m);
         if (!reg_f[f] && !reg_m[m]) {
           atomicAdd(&cnt_f[f], 1u);
           atomicAdd(&cnt_m[m], 1u);
@@ -379,17 +417,17 @@ __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) 
       // unique in the pool (:256-266) + Lowe on both sides -> registered (:285-289).  A candidate that
       // registers has pool counts 1/1, so no other pool member reads the flags it sets.
       for (uint32_t i = s0 + tid; i < s1; i += kBfThreads) {
-        const uint2 c = by_level[i];
-        const int f = (int) (c.x & 0xffffu), m = (int) (c.x >> 16);
-        if (!reg_f[f] && !reg_m[m] && cnt_f[f] == 1u && cnt_m[m] == 1u && c.y) {
+        int f, m;
+        const bool ok = level_entry(i, f, m);
+        if (!reg_f[f] && !reg_m[m] && cnt_f[f] == 1u && cnt_m[m] == 1u && ok) {
           acc[f] = (uint32_t) m | ((uint32_t) d << 16);
           atomicAdd(&hist2[d], 1u);
         }
       }
       __syncthreads();
       for (uint32_t i = s0 + tid; i < s1; i += kBfThreads) {
-        const uint32_t x = by_level[i].x;
-        const int f = (int) (x & 0xffffu), m = (int) (x >> 16);
+        int f, m;
+        (void) level_entry(i, f, m);
         cnt_f[f] = 0;
         cnt_m[m] = 0;
         const uint32_t r = acc[f];
@@ -906,6 +944,22 @@ int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* param
   a.off_hist  = off; off = bf_align16(off + (4 * kBfLevels + 8) * 4);
   if (off > 160u * 1024u) {
     return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_bruteforce_match: clouds do not fit the 160 KiB LDS");
+  }
+  // one workgroup per CU (the grid never exceeds the CUs): what the arrays above leave of the 160 KiB holds the distance bitmaps, then
+  // the level lists of as many candidates as fit (pairs with more keep the 8-byte lists in global memory)
+  a.off_bm  = 0xffffffffu;
+  a.off_lvl = 0;
+  a.lvl_cap = 0;
+  {
+    const uint64_t bm_bytes = (uint64_t) (batch->fixed_stride + batch->moving_stride) * (uint64_t) a.nw * 4u;
+    if (!getenv("PRS_BF_GLOBAL_STATE") && batch->fixed_stride <= 8192 && off + bm_bytes + 4096u <= 160u * 1024u) {
+      a.off_bm = off;
+      off      = bf_align16(off + (uint32_t) bm_bytes);
+      a.off_lvl = off;
+      const uint32_t room = (160u * 1024u - off) / 4u;
+      a.lvl_cap = (int) (room < (uint32_t) a.cap ? room : (uint32_t) a.cap);
+      off += 4u * (uint32_t) a.lvl_cap;
+    }
   }
   const int kpt = (batch->fixed_stride + kBfThreads - 1) / kBfThreads;
   hipStream_t stream = ctx_stream(ctx);
