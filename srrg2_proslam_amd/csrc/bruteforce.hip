@@ -399,44 +399,50 @@ __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) 
       m = (int) (c.x >> 16);
       return c.y != 0u;
     };
+    // Two barriers per level.  The pool counts of consecutive non-empty levels live in the two 16-bit halves of a count word (a count
+    // never exceeds the other cloud's size <= 65535): while level d is counted into its half, the entries of the previous non-empty
+    // level clear theirs (they were last read before the barrier that ended that level), so no third pass and barrier is needed to
+    // reset them; and a candidate that registers may raise its flags at once -- its pool counts are 1 / 1, no other member of the
+    // pool carries either index, and later levels only start behind the barrier.
+    int half = 0;
+    uint32_t p0 = 0, p1 = 0;  // the previous non-empty level's entries
     for (int d = 0; d < a.lim && d < kBfLevels; ++d) {
       const uint32_t s0 = lstart[d], s1 = lstart[d + 1];
       if (s0 == s1) {
         continue;  // uniform
+      }
+      const uint32_t one = 1u << (16 * half), keep_mine = 0xffffu << (16 * half);
+      for (uint32_t i = p0 + tid; i < p1; i += kBfThreads) {
+        int f, m;
+        (void) level_entry(i, f, m);
+        atomicAnd(&cnt_f[f], keep_mine);  // (the other half: this level's counts may already be growing in the same word)
+        atomicAnd(&cnt_m[m], keep_mine);
       }
       // pool = candidates of this distance whose indices are both unregistered (:117-118)
       for (uint32_t i = s0 + tid; i < s1; i += kBfThreads) {
         int f, m;
         (void) level_entry(i, f, m);
         if (!reg_f[f] && !reg_m[m]) {
-          atomicAdd(&cnt_f[f], 1u);
-          atomicAdd(&cnt_m[m], 1u);
+          atomicAdd(&cnt_f[f], one);
+          atomicAdd(&cnt_m[m], one);
         }
       }
       __syncthreads();
-      // unique in the pool (:256-266) + Lowe on both sides -> registered (:285-289).  A candidate that
-      // registers has pool counts 1/1, so no other pool member reads the flags it sets.
+      // unique in the pool (:256-266) + Lowe on both sides -> registered (:285-289)
       for (uint32_t i = s0 + tid; i < s1; i += kBfThreads) {
         int f, m;
         const bool ok = level_entry(i, f, m);
-        if (!reg_f[f] && !reg_m[m] && cnt_f[f] == 1u && cnt_m[m] == 1u && ok) {
-          acc[f] = (uint32_t) m | ((uint32_t) d << 16);
+        if (!reg_f[f] && !reg_m[m] && ((cnt_f[f] >> (16 * half)) & 0xffffu) == 1u && ((cnt_m[m] >> (16 * half)) & 0xffffu) == 1u && ok) {
+          acc[f]   = (uint32_t) m | ((uint32_t) d << 16);
+          reg_f[f] = 1;
+          reg_m[m] = 1;
           atomicAdd(&hist2[d], 1u);
         }
       }
       __syncthreads();
-      for (uint32_t i = s0 + tid; i < s1; i += kBfThreads) {
-        int f, m;
-        (void) level_entry(i, f, m);
-        cnt_f[f] = 0;
-        cnt_m[m] = 0;
-        const uint32_t r = acc[f];
-        if (r != 0xffffffffu && (int) (r & 0xffffu) == m && (int) (r >> 16) == d) {
-          reg_f[f] = 1;
-          reg_m[m] = 1;
-        }
-      }
-      __syncthreads();
+      p0   = s0;
+      p1   = s1;
+      half ^= 1;
     }
 
     // ---- phase 4: emit ordered by (distance, fixed index) ---------------------------------------
@@ -916,13 +922,13 @@ int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* param
   const bool mfma    = ctx->bf_mfma == PRS_BF_DENSE_MATRIX ||
                     (ctx->bf_mfma == PRS_BF_DENSE_MATRIX_WHEN_FULL && batch->fixed_stride >= 256 && batch->moving_stride >= 64 && mfma_wgs >= cus);
   const int grid = mfma ? batch->batch : (batch->batch < cus ? batch->batch : cus);
-  // few pairs: spread the dense phase of each pair over several workgroups (slices of >= 64 moving rows)
+  // few pairs: spread the dense phase of each pair over several workgroups (slices of >= 32 moving rows: one drain block)
   a.chunks = 1;
   if (mfma) {
     a.chunks = 2;  // (any value > 1: per-pair scratch rows + global accumulators, as in the split popcount shape)
   } else if (batch->batch * 2 <= cus && batch->moving_stride >= 256) {
     int c = cus / batch->batch;
-    const int most = batch->moving_stride / 64;
+    const int most = batch->moving_stride / 32;
     a.chunks = c < most ? c : most;
   }
   const size_t b_cand = (size_t) grid * a.cap * sizeof(uint2);
@@ -987,10 +993,7 @@ int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* param
   };
   if (a.chunks > 1) {
     const size_t acc_bytes = (size_t) batch->batch * (size_t) (batch->fixed_stride + batch->moving_stride + kBfLevels + 8) * sizeof(uint32_t);
-    e = hipMemsetAsync(a.g_acc, 0, acc_bytes, stream);
-    if (e == hipSuccess) {
-      e = hipMemsetAsync(a.bitmaps, 0, b_bm, stream);
-    }
+    e = hipMemsetAsync(a.bitmaps, 0, b_bm + acc_bytes, stream);  // (the bitmaps and the accumulators behind them: one launch)
     if (e == hipSuccess && mfma) {
       hipLaunchKernelGGL(bruteforce_dense_mfma_kernel, dim3((batch->fixed_stride + kBfmRowsWg - 1) / kBfmRowsWg, batch->batch), dim3(kBfmThreads), 0, stream, a);
       e = hipGetLastError();

@@ -156,3 +156,20 @@ def test_dense_phase_setter(hip_ctx):
             probe.set_bruteforce_dense_phase(7)
     finally:
         probe.close()
+
+
+def test_registration_state_in_global_memory(oracle, hip_ctx, monkeypatch):
+    # the distance bitmaps and the level lists live in LDS when they fit (the usual case); PRS_BF_GLOBAL_STATE keeps them in the
+    # scratch rows in global memory, the path large clouds x large thresholds take
+    monkeypatch.setenv("PRS_BF_GLOBAL_STATE", "1")
+    rng = np.random.default_rng(77)
+    df = _tie_heavy(rng, 40, 900, 6)
+    dm = _tie_heavy(rng, 40, 800, 6)
+    dm[:300] = df[rng.permutation(900)[:300]]
+    for max_dist, ratio in ((40.0, 0.9), (12.0, 1.0)):
+        ref, rflags = oracle.bruteforce_match(df, dm, max_dist, ratio)
+        clouds = ops.BruteforceClouds(0, 1, 900, 800, candidate_capacity=900 * 800)
+        clouds.upload(0, df, dm)
+        ops.bruteforce_match_batch(hip_ctx, ops.bruteforce_params(max_dist, ratio), clouds)
+        hip_ctx.synchronize()
+        assert hp.corr_equal(ref, clouds.matches_of(0)) and rflags == int(clouds.status[0].item()), (max_dist, ratio)

@@ -11,6 +11,7 @@ for name, call in (("real 1024 x ~750", lambda: bb.run_real(1024, 50.0, quiet=Tr
                    ("real 256 x ~1350", lambda: bb.run_real(256, 50.0, quiet=True, target=2000, capacity=262144, dense=mode)),
                    ("real 8 x ~1350", lambda: bb.run_real(8, 50.0, quiet=True, target=2000, capacity=262144, dense=mode)),
                    ("real 1 x ~1350", lambda: bb.run_real(1, 50.0, quiet=True, target=2000, capacity=262144, dense=mode)),
+                   ("real 1 x ~750", lambda: bb.run_real(1, 50.0, quiet=True, target=1000, capacity=65536, dense=mode)),
                    ("random 1024 x 2000", lambda: bb.run(1024, 2000, 50.0, quiet=True, dense=mode)),
                    ("random 1024 x 1000", lambda: bb.run(1024, 1000, 50.0, quiet=True, dense=mode)),
                    ("random 8 x 2000", lambda: bb.run(8, 2000, 50.0, quiet=True, dense=mode)),
