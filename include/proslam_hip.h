@@ -85,14 +85,14 @@ PRS_API int prs_context_get_align_timing(prs_context* ctx, double* search_ms, do
  * `batches` timed batches (round 15 collects every later round) */
 PRS_API int prs_context_get_align_round_timing(prs_context* ctx, double* search_ms16, double* gn_ms16, int64_t* batches);
 /* Dense phase of the brute-force matcher (prs_bruteforce_match_batch): which kernels score the N_f x N_m pairs.  Results are
- * identical; only the cost differs, and it depends on how many pairs fall below the threshold.
- *   PRS_BF_DENSE_POPCOUNT (the default): v_xor / v_bcnt on the vector units, candidates handled where they are found.  The right
- *     choice for real descriptors: ~1.6 % of the left x right pairs of a KITTI stereo pair are within 50 bits (distance mean 125,
- *     standard deviation 33), and the matcher's time is candidate handling, not scoring.
- *   PRS_BF_DENSE_MATRIX_WHEN_FULL: v_mfma_i32_16x16x64_i8 selects (column, row group) entries that are re-scored exactly, when the
- *     batch fills the chip with 512-row workgroups (else the popcount kernels).  2.7x the popcount kernels when candidates are rare
- *     (uniform random rows: one per fixed point), up to 1.8x SLOWER on real descriptors (profiles/r06/README.md).
- *   PRS_BF_DENSE_MATRIX: always the matrix-core kernel (tests, A-B runs).
+ * identical; only the cost differs.
+ *   PRS_BF_DENSE_MATRIX_WHEN_FULL (the default): a batch of more cloud pairs than half the CUs runs one workgroup per pair with the
+ *     distances from v_mfma_i32_16x16x64_i8 (exact: integer products) and the registration state in LDS; fewer pairs run the popcount
+ *     kernels, which spread a pair over several workgroups.  On 1024 real cloud pairs (KITTI stereo pairs, ~750 points a side, 1.6 % of
+ *     the pairs within 50 bits) 1.6x the popcount kernels, on uniform random rows 2.2x (profiles/r06/README.md).
+ *   PRS_BF_DENSE_POPCOUNT: v_xor / v_bcnt on the vector units for every batch size.
+ *   PRS_BF_DENSE_MATRIX: always the matrix cores (the fused shape where it applies, else a split matrix-core kernel + a registration
+ *     launch that re-scores what it selects: fast on uniform random rows, slow on real ones; tests, A-B runs).
  * The environment variable PRS_BF_MFMA (0 / auto / 1), read when the context is created, sets the initial mode. */
 #define PRS_BF_DENSE_POPCOUNT 0
 #define PRS_BF_DENSE_MATRIX_WHEN_FULL 1

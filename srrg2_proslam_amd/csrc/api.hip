@@ -216,7 +216,7 @@ int prs_context_create(int device_id, prs_context** out) {
   const char* p96      = getenv("PRS_PREFILTER_96_LIMIT");
   ctx->prefilter_96_limit = p96 ? atoi(p96) : 32;
   const char* bfm      = getenv("PRS_BF_MFMA");
-  ctx->bf_mfma         = !bfm ? PRS_BF_DENSE_POPCOUNT : (bfm[0] == '1' ? PRS_BF_DENSE_MATRIX : (bfm[0] == 'a' ? PRS_BF_DENSE_MATRIX_WHEN_FULL : PRS_BF_DENSE_POPCOUNT));
+  ctx->bf_mfma         = !bfm || bfm[0] == 'a' ? PRS_BF_DENSE_MATRIX_WHEN_FULL : (bfm[0] == '1' ? PRS_BF_DENSE_MATRIX : PRS_BF_DENSE_POPCOUNT);
   const char* mfused   = getenv("PRS_MERGE_FUSED");
   ctx->merge_fused     = mfused && mfused[0] == '1';
   *out                 = ctx;

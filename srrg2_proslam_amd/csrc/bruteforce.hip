@@ -46,6 +46,7 @@ struct BfArgs {
   uint32_t off_bm;     // the distance bitmaps of the fixed / moving indices ((fixed_stride + moving_stride) * nw words), ~0: global
   uint32_t off_lvl;    // the candidates grouped by level, 4 bytes each (fixed | moving << 13 | lowe ok << 29) ...
   int lvl_cap;         // ... for cloud pairs with at most this many candidates (0: always global, 8 bytes each)
+  uint32_t off_mx;     // scratch of the matrix-core dense phase (bf_matrix_phase1), dead behind it: the level lists lie over it
   // few cloud pairs: the dense phase is spread over `chunks` workgroups per pair (each takes a slice of the
   // moving cloud) that accumulate into global memory; one workgroup per pair then registers the candidates
   int chunks;
@@ -82,8 +83,13 @@ __device__ __forceinline__ bool lowe_ok(const uint32_t* bm, int nw, uint32_t cou
   return (float) d / (float) second < max_ratio;
 }
 
-template <int KPT, int MODE>
+// dense phase of the fused shape on the matrix cores (defined with the matrix-core kernels below)
+__device__ __forceinline__ void bf_matrix_phase1(const BfArgs& a, unsigned char* scratch, int nf, int nm, const uint32_t* gdf, const uint32_t* gdm, uint2* cand,
+                                                 uint32_t* cnt_f, uint32_t* cnt_m, uint32_t* hist, uint32_t* counter, uint32_t* lbm_f, uint32_t* lbm_m);
+
+template <int KPT, int MODE, bool MX = false>
 __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) {
+  static_assert(!MX || (MODE == kBfFused && KPT == 1), "the matrix-core dense phase belongs to the fused shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* cnt_f  = reinterpret_cast<uint32_t*>(smem + a.off_cnt_f);   // candidates per fixed; later pool counts
   uint32_t* cnt_m  = reinterpret_cast<uint32_t*>(smem + a.off_cnt_m);
@@ -162,6 +168,11 @@ __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) 
     }
 
     // ---- phase 1: all pairs (bruteforce_impl.cpp:32-79) ----------------------------------------
+    if constexpr (MX) {
+      bf_matrix_phase1(a, smem + a.off_mx, nf, nm, gdf,
+                       reinterpret_cast<const uint32_t*>(a.b.moving_desc + (size_t) frame * a.b.moving_stride * PRS_DESC_BYTES), cand, cnt_f, cnt_m, hist, &misc[0],
+                       lbm_f, lbm_m);
+    } else {
     uint32_t fd[KPT][8];
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
@@ -313,6 +324,7 @@ __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) 
       }
       __syncthreads();
     }
+    }  // (popcount dense phase)
     if (MODE == kBfDense) {
       continue;  // the registration launch takes over
     }
@@ -871,6 +883,245 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
   flush(n_chunks & 1);
 }
 
+// ---- the dense phase of the FUSED shape on the matrix cores ------------------------------------------------------------
+// bruteforce_kernel<1, kBfFused, true>: one 1024-thread workgroup per cloud pair, the registration state in LDS as in the popcount
+// shape, the N_f x N_m distances from v_mfma_i32_16x16x64_i8 as in bruteforce_dense_mfma_kernel (a wave owns 64 fixed rows, the
+// workgroup walks the moving cloud in 64-row chunks that waves 0-7 expand into LDS), fixed rows beyond 1024 in further passes.
+// What differs is what happens to a candidate.  Real descriptors put 1.6 % of the pairs below a threshold of 50 bits: every tile of
+// every tile row holds one, so nothing here is rare.  A lane that met the threshold in one of its 4 rows of a tile parks the tile's
+// four EXACT distances (acc + pop(b), packed to bytes by seven packed-math instructions) beside (column, row group, tile) in its
+// wave's LDS segment; a wave drains its own segment when a worst-case tile row (4 x 64 entries) might not fit: one slot range per 64
+// entries from the pair's LDS counter, the bitmaps / counts / histogram updated by LDS atomics.  No re-scoring from memory, no
+// barrier, no global atomic: the split kernel's flush spent 1.3 of its 1.7 ms per 1024 real cloud pairs on those.
+constexpr int kMxSeg        = 320;  // entries of a wave's segment (8 bytes each): drained when more than kMxSeg - 256 wait in it
+constexpr uint32_t kMxBytes = 2u * 4u * kBfmPlane + 2u * kBfmChunk * 4u + 2u * 16u * 4u + (uint32_t) (kBfThreads / 64) * kMxSeg * 8u;
+typedef unsigned short bf_us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void bf_matrix_phase1(const BfArgs& a, unsigned char* scratch, const int nf, const int nm, const uint32_t* __restrict__ gdf,
+                                                 const uint32_t* __restrict__ gdm, uint2* __restrict__ cand, uint32_t* cnt_f, uint32_t* cnt_m, uint32_t* hist,
+                                                 uint32_t* counter, uint32_t* lbm_f, uint32_t* lbm_m) {
+  unsigned char* bbuf = scratch;                                                      // [2][4 planes][64 rows x 80 B]
+  int* popm           = reinterpret_cast<int*>(scratch + 2 * 4 * kBfmPlane);          // [2][64]
+  uint32_t* lut_a     = reinterpret_cast<uint32_t*>(popm + 2 * kBfmChunk);            // [16]
+  uint32_t* lut_b     = lut_a + 16;                                                   // [16]
+  uint2* segments     = reinterpret_cast<uint2*>(lut_b + 16);                         // [16 waves][kMxSeg]
+  static_assert(kBfmPlane % 256 == 0, "planes must not shift the banks");
+  auto lane_now = []() -> int {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+  };
+  const int tid    = threadIdx.x;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < 16) {
+    uint32_t v01 = 0, vpm = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      v01 |= ((tid >> b) & 1 ? 0x01u : 0x00u) << (8 * b);
+      vpm |= ((tid >> b) & 1 ? 0xffu : 0x01u) << (8 * b);
+    }
+    lut_a[tid] = v01;
+    lut_b[tid] = vpm;
+  }
+  __syncthreads();
+  if (nf == 0 || nm == 0) {
+    return;  // (block-uniform)
+  }
+  auto expand16 = [](const uint32_t* lut, const uint32_t bits16) -> bf_v4i {
+    bf_v4i v;
+    v.x = (int) lut[bits16 & 15u];
+    v.y = (int) lut[(bits16 >> 4) & 15u];
+    v.z = (int) lut[(bits16 >> 8) & 15u];
+    v.w = (int) lut[(bits16 >> 12) & 15u];
+    return v;
+  };
+  uint2* segment    = segments + wave_s * kMxSeg;
+  uint32_t my_count = 0;  // entries in this wave's segment (wave-uniform: a scalar register)
+  // this wave's parked entries -> the pair's candidate list and registration state (:52-69)
+  auto drain = [&]() {
+    for (uint32_t i0 = 0; i0 < my_count; i0 += 64u) {
+      const int lane   = lane_now();
+      const uint32_t i = i0 + (uint32_t) lane;
+      const uint2 e    = i < my_count ? segment[i] : make_uint2(0u, 0xffffffffu);  // (distances of 255: never below a threshold <= 255)
+      const int m      = (int) (e.x & 0xffffu);
+      const int f0     = (int) (((e.x >> 16) & 0x7ffu) << 2) + 16 * (int) ((e.x >> 27) & 3u);
+      int d[4];
+      uint32_t mine = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d[r] = (int) ((e.y >> (8 * r)) & 0xffu);
+        if (d[r] >= a.lim || f0 + r >= nf) {
+          d[r] = -1;  // (a row past the end scores as an all-zero row)
+        } else {
+          ++mine;
+        }
+      }
+      uint32_t incl = mine;
+      incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x111, 0xf, 0xf, false);  // row_shr:1
+      incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x112, 0xf, 0xf, false);  // row_shr:2
+      incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x114, 0xf, 0xf, false);  // row_shr:4
+      incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x118, 0xf, 0xf, false);  // row_shr:8
+      incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+      incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+      const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+      if (total == 0u) {
+        continue;  // (wave-uniform)
+      }
+      uint32_t base = 0;
+      if (lane == 0) {
+        base = atomicAdd(counter, total);
+      }
+      uint32_t slot = (uint32_t) __builtin_amdgcn_readfirstlane((int) base) + incl - mine;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (d[r] >= 0) {
+          const int f = f0 + r;
+          if (slot < (uint32_t) a.cap) {
+            cand[slot] = make_uint2((uint32_t) f | ((uint32_t) m << 16), (uint32_t) d[r]);
+          }
+          ++slot;
+          const uint32_t bit = 1u << (d[r] & 31);
+          atomicOr(&lbm_f[f * a.nw + (d[r] >> 5)], bit);
+          atomicOr(&lbm_m[m * a.nw + (d[r] >> 5)], bit);
+          atomicAdd(&cnt_f[f], 1u);
+          atomicAdd(&cnt_m[m], 1u);
+          atomicAdd(&hist[d[r]], 1u);
+        }
+      }
+    }
+    my_count = 0;
+  };
+  const int n_chunks       = (nm + kBfmChunk - 1) / kBfmChunk;
+  const uint32_t last_word = 32u * (uint32_t) nm - 4u;  // (byte offset of the cloud's last word: rows past the end read it and are masked)
+  auto fetch = [&](const int c) -> uint32_t {           // waves 0-7: one 32-bit word of the chunk per thread
+    const uint32_t off = (uint32_t) c * (kBfmChunk * 32u) + 256u * (uint32_t) wave_s + 4u * (uint32_t) lane_now();
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(gdm) + (off < last_word ? off : last_word));
+  };
+  auto stage = [&](const int c, const int buf, const uint32_t w) {
+    const int l = lane_now(), row = 8 * wave_s + (l >> 3), j = l & 7;
+    unsigned char* dst = bbuf + buf * (4 * kBfmPlane) + (2 * (j & 1)) * kBfmPlane + __mul24(row, kBfmPlaneRow) + 16 * (j >> 1);
+    *reinterpret_cast<bf_v4i*>(dst)             = expand16(lut_b, w & 0xffffu);
+    *reinterpret_cast<bf_v4i*>(dst + kBfmPlane) = expand16(lut_b, w >> 16);
+    int pop = __popc(w);
+    pop += __builtin_amdgcn_update_dpp(0, pop, 0xb1, 0xf, 0xf, true);   // quad_perm [1, 0, 3, 2]
+    pop += __builtin_amdgcn_update_dpp(0, pop, 0x4e, 0xf, 0xf, true);   // quad_perm [2, 3, 0, 1]
+    pop += __builtin_amdgcn_update_dpp(0, pop, 0x141, 0xf, 0xf, true);  // row_half_mirror
+    if (j == 0) {
+      popm[buf * kBfmChunk + row] = c * kBfmChunk + row < nm ? pop : (1 << 20);  // a row past the end never meets the threshold
+    }
+  };
+  const bool stager = wave_s < kBfmChunk * 8 / 64;  // (512 words per chunk)
+  const bf_v4i zero = {0, 0, 0, 0};
+  for (int pass_first = 0; pass_first < nf; pass_first += kBfThreads) {
+    const int row0       = pass_first + wave_s * kBfmRowsWave;
+    const bool wave_live = row0 < nf;
+    bf_v4i A[4][4];
+    {
+      const int l = lane_now();
+      uint32_t w[4][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int f  = row0 + 16 * t + (l & 15);
+        const int fr = f < nf ? f : nf - 1;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          w[t][kb] = gdf[8 * fr + 2 * kb + (l >> 5)];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bool live = row0 + 16 * t + (l & 15) < nf;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          A[t][kb] = expand16(lut_a, live ? (w[t][kb] >> (16 * ((l >> 4) & 1))) & 0xffffu : 0u);
+        }
+      }
+    }
+    __syncthreads();  // (the previous pass has left the chunk buffers)
+    if (stager) {
+      stage(0, 0, fetch(0));
+    }
+    __syncthreads();
+    for (int c = 0; c < n_chunks; ++c) {
+      const int buf   = c & 1;
+      uint32_t w_next = 0u;
+      if (stager && c + 1 < n_chunks) {
+        w_next = fetch(c + 1);  // in flight while this chunk is scored
+      }
+      if (wave_live) {
+        const int l = lane_now(), li = l & 15, lg = l >> 4;
+#pragma unroll 1
+        for (int bt = 0; bt < kBfmChunk / 16; ++bt) {
+          if (c * kBfmChunk + 16 * bt >= nm) {
+            break;  // (uniform) tiles past the end of the moving cloud
+          }
+          if (my_count > (uint32_t) (kMxSeg - 256)) {
+            drain();  // (wave-uniform: room for a worst-case tile row)
+          }
+          const unsigned char* brow = bbuf + buf * (4 * kBfmPlane) + __mul24(lg, kBfmPlane) + __mul24(16 * bt + li, kBfmPlaneRow);
+          const int pop_b           = popm[buf * kBfmChunk + 16 * bt + li];
+          const int thr             = a.lim - pop_b;  // candidate  <=>  acc < thr
+          bf_v4i B[4];
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) {
+            B[kb] = *reinterpret_cast<const bf_v4i*>(brow + 16 * kb);
+          }
+          bf_v4i acc[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t][0], B[0], zero, 0, 0, 0);
+          }
+#pragma unroll
+          for (int kb = 1; kb < 4; ++kb) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t][kb], B[kb], acc[t], 0, 0, 0);
+            }
+          }
+          bool any_t[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            any_t[t] = (acc[t].x < thr) | (acc[t].y < thr) | (acc[t].z < thr) | (acc[t].w < thr);
+          }
+          const unsigned long long mask_t[4] = {__ballot(any_t[0]), __ballot(any_t[1]), __ballot(any_t[2]), __ballot(any_t[3])};
+          if ((mask_t[0] | mask_t[1] | mask_t[2] | mask_t[3]) != 0ull) {  // (wave-uniform)
+            const int lane            = lane_now();
+            const uint32_t base_entry = (uint32_t) (c * kBfmChunk + 16 * bt + (lane & 15)) | ((uint32_t) ((row0 + 4 * (lane >> 4)) >> 2) << 16);
+            bf_us2 pop2;
+            pop2.x = (unsigned short) pop_b;
+            pop2.y = (unsigned short) pop_b;
+            bf_us2 cap2;
+            cap2.x = 255;
+            cap2.y = 255;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              if (mask_t[t] != 0ull) {  // (wave-uniform)
+                if (any_t[t]) {
+                  // the tile's four distances acc + pop(b) as bytes (a distance of 256 parks as 255: above every threshold this shape takes)
+                  const uint32_t p01 = __builtin_amdgcn_perm((uint32_t) acc[t].y, (uint32_t) acc[t].x, 0x05040100u);
+                  const uint32_t p23 = __builtin_amdgcn_perm((uint32_t) acc[t].w, (uint32_t) acc[t].z, 0x05040100u);
+                  bf_us2 d01 = __builtin_bit_cast(bf_us2, p01) + pop2, d23 = __builtin_bit_cast(bf_us2, p23) + pop2;
+                  d01 = __builtin_elementwise_min(d01, cap2);
+                  d23 = __builtin_elementwise_min(d23, cap2);
+                  const uint32_t packed = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, d23), __builtin_bit_cast(uint32_t, d01), 0x06040200u);
+                  const uint32_t rank   = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask_t[t] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask_t[t], 0u));
+                  segment[my_count + rank] = make_uint2(base_entry | ((uint32_t) t << 27), packed);
+                }
+                my_count += (uint32_t) __popcll(mask_t[t]);
+              }
+            }
+          }
+        }
+      }
+      if (stager && c + 1 < n_chunks) {
+        stage(c + 1, buf ^ 1, w_next);
+      }
+      __syncthreads();  // chunk c + 1 is staged, chunk c is consumed
+    }
+    drain();
+  }
+}
+
 static inline uint32_t bf_align16(uint32_t v) {
   return (v + 15u) & ~15u;
 }
@@ -913,14 +1164,33 @@ int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* param
       cus = prop.multiProcessorCount;
     }
   }
-  // The dense phase on the matrix cores (bruteforce_dense_mfma_kernel) + the registration launch: OPT-IN
-  // (prs_context_set_bruteforce_dense_phase).  It pays when candidates are rare (uniform random rows, 1024 pairs of 2000-point clouds:
-  // 2.77 -> 1.02 ms) and costs when they are not (real descriptors, 1.6 % of the pairs within 50 bits: 1.20 -> 1.86 ms), and the
-  // library cannot tell which input it has.  PRS_BF_DENSE_MATRIX_WHEN_FULL: when the batch fills the chip with its 512-row workgroups;
-  // a handful of pairs keeps the popcount kernels, whose split shape spreads a pair over more workgroups (8 pairs: 0.08 against 0.12 ms).
-  const int mfma_wgs = batch->batch * ((batch->fixed_stride + kBfmRowsWg - 1) / kBfmRowsWg);
-  const bool mfma    = ctx->bf_mfma == PRS_BF_DENSE_MATRIX ||
-                    (ctx->bf_mfma == PRS_BF_DENSE_MATRIX_WHEN_FULL && batch->fixed_stride >= 256 && batch->moving_stride >= 64 && mfma_wgs >= cus);
+  // Which kernels score the pairs (prs_context_set_bruteforce_dense_phase).  PRS_BF_DENSE_MATRIX_WHEN_FULL, the default: a batch that
+  // fills the chip (more cloud pairs than half the CUs) takes the fused shape with its dense phase on the matrix cores
+  // (bruteforce_kernel<1, kBfFused, true>: 1024 real cloud pairs 0.99 -> 0.62 ms, 1024 pairs of 2000 uniform random rows 2.75 -> 1.23 ms);
+  // a handful of pairs keeps the popcount kernels, whose split shape spreads a pair over more workgroups (one real pair of 1350 points:
+  // 0.11 ms against 0.23 ms).
+  // LDS of the fused / registration workgroups: the registration state first
+  uint32_t off = 0;
+  a.off_cnt_f = off; off = bf_align16(off + (uint32_t) batch->fixed_stride * 4);
+  a.off_cnt_m = off; off = bf_align16(off + (uint32_t) batch->moving_stride * 4);
+  a.off_reg_f = off; off = bf_align16(off + (uint32_t) batch->fixed_stride);
+  a.off_reg_m = off; off = bf_align16(off + (uint32_t) batch->moving_stride);
+  a.off_acc   = off; off = bf_align16(off + (uint32_t) batch->fixed_stride * 4);
+  a.off_hist  = off; off = bf_align16(off + (4 * kBfLevels + 8) * 4);
+  if (off > 160u * 1024u) {
+    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_bruteforce_match: clouds do not fit the 160 KiB LDS");
+  }
+  const uint64_t bm_bytes  = (uint64_t) (batch->fixed_stride + batch->moving_stride) * (uint64_t) a.nw * 4u;
+  const bool bm_fits       = !getenv("PRS_BF_GLOBAL_STATE") && off + bm_bytes + 4096u <= 160u * 1024u;
+  const bool fused_regime  = !(batch->batch * 2 <= cus && batch->moving_stride >= 256);  // (else: few pairs, each spread over several workgroups)
+  const bool matrix_forced = ctx->bf_mfma == PRS_BF_DENSE_MATRIX, matrix_when_full = ctx->bf_mfma == PRS_BF_DENSE_MATRIX_WHEN_FULL;
+  // the fused shape with its dense phase on the matrix cores (bruteforce_kernel<1, kBfFused, true>): the registration state AND the
+  // phase's scratch must fit the LDS, and a parked distance is a byte
+  const bool fused_matrix = (matrix_forced || (matrix_when_full && batch->batch * 2 > cus && batch->fixed_stride >= 256 && batch->moving_stride >= 64)) &&
+                            fused_regime && lim <= 255 && bm_fits && ((off + bm_bytes + 255u) & ~(uint64_t) 255u) + kMxBytes <= 160u * 1024u;
+  // (the split matrix-core kernel, bruteforce_dense_mfma_kernel + the registration launch: only when forced and the fused shape is
+  //  not taken -- it is the fastest on uniform random rows and the slowest on real ones, see the header)
+  const bool mfma = !fused_matrix && matrix_forced;
   const int grid = mfma ? batch->batch : (batch->batch < cus ? batch->batch : cus);
   // few pairs: spread the dense phase of each pair over several workgroups (slices of >= 32 moving rows: one drain block)
   a.chunks = 1;
@@ -941,31 +1211,23 @@ int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* param
   if (!a.cand || !a.by_level || !a.bitmaps) {
     return ctx_fail(ctx, PRS_ERR_HIP, "prs_bruteforce_match: scratch allocation failed");
   }
-  uint32_t off = 0;
-  a.off_cnt_f = off; off = bf_align16(off + (uint32_t) batch->fixed_stride * 4);
-  a.off_cnt_m = off; off = bf_align16(off + (uint32_t) batch->moving_stride * 4);
-  a.off_reg_f = off; off = bf_align16(off + (uint32_t) batch->fixed_stride);
-  a.off_reg_m = off; off = bf_align16(off + (uint32_t) batch->moving_stride);
-  a.off_acc   = off; off = bf_align16(off + (uint32_t) batch->fixed_stride * 4);
-  a.off_hist  = off; off = bf_align16(off + (4 * kBfLevels + 8) * 4);
-  if (off > 160u * 1024u) {
-    return ctx_fail(ctx, PRS_ERR_UNSUPPORTED, "prs_bruteforce_match: clouds do not fit the 160 KiB LDS");
-  }
   // one workgroup per CU (the grid never exceeds the CUs): what the arrays above leave of the 160 KiB holds the distance bitmaps, then
-  // the level lists of as many candidates as fit (pairs with more keep the 8-byte lists in global memory)
+  // the level lists of as many candidates as fit (pairs with more keep the 8-byte lists in global memory); the scratch of the
+  // matrix-core dense phase is dead when the lists are written and lies under them
   a.off_bm  = 0xffffffffu;
   a.off_lvl = 0;
   a.lvl_cap = 0;
-  {
-    const uint64_t bm_bytes = (uint64_t) (batch->fixed_stride + batch->moving_stride) * (uint64_t) a.nw * 4u;
-    if (!getenv("PRS_BF_GLOBAL_STATE") && batch->fixed_stride <= 8192 && off + bm_bytes + 4096u <= 160u * 1024u) {
-      a.off_bm = off;
-      off      = bf_align16(off + (uint32_t) bm_bytes);
-      a.off_lvl = off;
-      const uint32_t room = (160u * 1024u - off) / 4u;
-      a.lvl_cap = (int) (room < (uint32_t) a.cap ? room : (uint32_t) a.cap);
-      off += 4u * (uint32_t) a.lvl_cap;
-    }
+  a.off_mx  = 0;
+  if (bm_fits) {
+    a.off_bm  = off;
+    off       = bf_align16(off + (uint32_t) bm_bytes);
+    off       = fused_matrix ? (off + 255u) & ~255u : off;
+    a.off_lvl = off;
+    a.off_mx  = off;
+    const uint32_t room = (160u * 1024u - off) / 4u;
+    a.lvl_cap = (int) (room < (uint32_t) a.cap ? room : (uint32_t) a.cap);
+    const uint32_t lists = 4u * (uint32_t) a.lvl_cap;
+    off += fused_matrix && kMxBytes > lists ? kMxBytes : lists;
   }
   const int kpt = (batch->fixed_stride + kBfThreads - 1) / kBfThreads;
   hipStream_t stream = ctx_stream(ctx);
@@ -1004,7 +1266,11 @@ int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* param
       launch_mode(std::integral_constant<int, kBfRegister>{}, dim3(batch->batch));
     }
   } else {
-    launch_mode(std::integral_constant<int, kBfFused>{}, dim3(grid));
+    if (fused_matrix) {
+      launch(bruteforce_kernel<1, kBfFused, true>, dim3(grid));
+    } else {
+      launch_mode(std::integral_constant<int, kBfFused>{}, dim3(grid));
+    }
   }
   if (e != hipSuccess) {
     return ctx_fail_hip(ctx, e, "prs_bruteforce_match launch");

@@ -19,7 +19,7 @@ struct prs_context {
   bool merge_fused      = false;    // PRS_MERGE_FUSED=1: pose-based smoother merger as one kernel instead of front | smoother | back
   bool no_prefilter     = false;    // PRS_NO_PREFILTER=1: the search scan scores every candidate in full (diagnostic: what the irrelevance bound buys)
   int prefilter_96_limit = 32;      // PRS_PREFILTER_96_LIMIT: largest irrelevance bound the search scan tests on 96 instead of 128 bits (diagnostic / A-B)
-  int bf_mfma           = 0;        // PRS_BF_DENSE_*: the brute-force matcher's dense phase (prs_context_set_bruteforce_dense_phase; PRS_BF_MFMA=0 / auto / 1)
+  int bf_mfma           = 1;        // PRS_BF_DENSE_*: the brute-force matcher's dense phase (prs_context_set_bruteforce_dense_phase; PRS_BF_MFMA=0 / auto / 1)
   bool no_lone_gn       = false;    // PRS_NO_LONE_GN=1: small batches use the throughput instantiation of the Gauss-Newton kernel too (diagnostic)
   bool stamps_split     = false;    // PRS_STAMPS_SPLIT=1 (with PRS_STAMPS=1): phase stamps of the split search kernel
   // reusable device scratch for the host-pointer entry points
