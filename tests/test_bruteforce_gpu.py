@@ -9,12 +9,14 @@ from tests import helpers as hp
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["popcount", "mfma"])
+@pytest.fixture(scope="module", params=["popcount", "matrix", "default"])
 def hip_ctx(request):
-    """every test of this module on both dense phases: the popcount kernels (the default) and the matrix-core kernel
-    (PRS_BF_DENSE_MATRIX: v_mfma_i32_16x16x64_i8 + exact re-scoring of the selected entries), whatever the batch size"""
+    """every test of this module on the three dense-phase modes (prs_context_set_bruteforce_dense_phase): the popcount kernels, the
+    matrix cores whatever the batch size (v_mfma_i32_16x16x64_i8: the fused shape where one workgroup takes a pair, else the split
+    kernel that re-scores the entries it selects), and the default (matrix cores for batches that fill the chip)"""
     ctx = ops.Context(0)
-    ctx.set_bruteforce_dense_phase(ops.BF_DENSE_MATRIX if request.param == "mfma" else ops.BF_DENSE_POPCOUNT)
+    if request.param != "default":
+        ctx.set_bruteforce_dense_phase(ops.BF_DENSE_MATRIX if request.param == "matrix" else ops.BF_DENSE_POPCOUNT)
     yield ctx
     ctx.close()
 
@@ -173,3 +175,27 @@ def test_registration_state_in_global_memory(oracle, hip_ctx, monkeypatch):
         ops.bruteforce_match_batch(hip_ctx, ops.bruteforce_params(max_dist, ratio), clouds)
         hip_ctx.synchronize()
         assert hp.corr_equal(ref, clouds.matches_of(0)) and rflags == int(clouds.status[0].item()), (max_dist, ratio)
+
+
+def test_full_batch_with_dense_candidates_and_two_row_passes(oracle, hip_ctx):
+    # more cloud pairs than half the CUs (the default takes the fused matrix-core shape), fixed clouds beyond 1024 rows (a second pass
+    # over the moving cloud), descriptors drawn from few prototypes: every tile of every tile row holds candidates, wave segments
+    # are drained many times per pair
+    rng = np.random.default_rng(23)
+    B, fs, ms = 140, 1300, 1100
+    clouds = ops.BruteforceClouds(0, B, fs, ms, candidate_capacity=200000)
+    inputs = []
+    for b in range(B):
+        nf = int(rng.integers(900, fs + 1)) if b % 3 else int(rng.integers(1, 200))
+        nm = int(rng.integers(700, ms + 1)) if b % 5 else int(rng.integers(1, 100))
+        df = _tie_heavy(rng, 60, nf, 40)
+        dm = _tie_heavy(np.random.default_rng(23), 60, nm, 40)  # (the same prototypes)
+        inputs.append((df, dm))
+        clouds.upload(b, df, dm)
+    for max_dist, ratio in ((50.0, 0.9), (31.0, 0.8)):
+        ops.bruteforce_match_batch(hip_ctx, ops.bruteforce_params(max_dist, ratio), clouds)
+        hip_ctx.synchronize()
+        for b in list(range(0, B, 13)) + [B - 1]:
+            ref, rflags = oracle.bruteforce_match(inputs[b][0], inputs[b][1], max_dist, ratio)
+            assert hp.corr_equal(ref, clouds.matches_of(b)), (b, max_dist)
+            assert int(clouds.status[b].item()) == rflags, (b, max_dist)
