@@ -495,29 +495,33 @@ def f_rows_leg():
         out["roofline_f3"] = {"error": str(exc)}
     try:
         from srrg2_proslam_amd import ops as _ops
-        b = bench_bruteforce.run(1024, 2000, 50.0, quiet=True, dense=_ops.BF_DENSE_MATRIX)
-        b1 = bench_bruteforce.run(1024, 1000, 50.0, quiet=True, dense=_ops.BF_DENSE_MATRIX)
+        # the default mode (PRS_BF_DENSE_MATRIX_WHEN_FULL): these batches fill the chip and take the fused matrix-core shape
+        b = bench_bruteforce.run(1024, 2000, 50.0, quiet=True)
+        b1 = bench_bruteforce.run(1024, 1000, 50.0, quiet=True)
         p = bench_bruteforce.run(1024, 2000, 50.0, quiet=True, dense=_ops.BF_DENSE_POPCOUNT)
         p1 = bench_bruteforce.run(1024, 1000, 50.0, quiet=True, dense=_ops.BF_DENSE_POPCOUNT)
         real = {}
-        for name, mode in (("popcount", _ops.BF_DENSE_POPCOUNT), ("matrix_cores", _ops.BF_DENSE_MATRIX)):
+        for name, mode in (("default", None), ("popcount", _ops.BF_DENSE_POPCOUNT)):
             real[name] = [bench_bruteforce.run_real(1024, 50.0, quiet=True, target=1000, capacity=65536, dense=mode),
                           bench_bruteforce.run_real(256, 50.0, quiet=True, target=2000, capacity=262144, dense=mode)]
+        real["speedup_over_popcount"] = [real["popcount"][i]["ms_per_launch"] / real["default"][i]["ms_per_launch"] for i in range(2)]
+        real["one_cloud_pair"] = [bench_bruteforce.run_real(1, 50.0, quiet=True, target=1000, capacity=65536),
+                                  bench_bruteforce.run_real(1, 50.0, quiet=True, target=2000, capacity=262144)]
         tops = b["pairs_per_s"] * 512.0 / 1e12
         out["roofline_f4"] = {
             "kernel": "bruteforce dense phase + registration (CorrespondenceFinderDescriptorBasedBruteforce::compute: all N_f x N_m Hamming distances, pools by "
                       "distance, uniqueness, Lowe's ratio on both sides)",
             "bound": "mfma", "achieved": tops, "peak": I8_MFMA_TOPS, "unit": "TOP/s", "frac": tops / I8_MFMA_TOPS, "traffic": None,
-            "mode": "PRS_BF_DENSE_MATRIX (opt-in: prs_context_set_bruteforce_dense_phase), uniform random rows with one true partner per point",
+            "mode": "the default dense phase (fused shape, distances from v_mfma_i32_16x16x64_i8) on uniform random rows with one true partner per point",
             "operations_per_descriptor_pair": 512, "descriptor_pairs_per_s": b["pairs_per_s"], "ms_per_launch": b["ms_per_launch"],
             "shapes": [b, b1],
-            "default_mode_popcount": {"shapes": [p, p1], "speedup_of_matrix_cores": [p["ms_per_launch"] / b["ms_per_launch"], p1["ms_per_launch"] / b1["ms_per_launch"]]},
+            "popcount_kernels": {"shapes": [p, p1], "speedup_of_default": [p["ms_per_launch"] / b["ms_per_launch"], p1["ms_per_launch"] / b1["ms_per_launch"]]},
             "real_descriptors": real,
             "note": "hamming(a, b) = pop(a) + pop(b) - 2 a.b: the binary dot product of 256-bit rows is 256 multiply-adds = 512 operations per pair, "
-                    "priced against the dense I8 MFMA rate (2 x BF16); includes the registration phases of every cloud pair.  The matrix-core dense phase "
-                    "is OPT-IN: it wins when candidates are rare (uniform random rows: 128 +- 8 bits apart, one candidate per fixed point) and loses on "
-                    "real descriptors (KITTI stereo pairs: 125 +- 33 bits, 1.6 % of the pairs within 50 bits: candidate handling, not scoring, is the "
-                    "matcher's time there) -- real_descriptors holds both modes on real rows, default_mode_popcount the default on the random rows"}
+                    "priced against the dense I8 MFMA rate (2 x BF16); includes the registration phases of every cloud pair.  Uniform random rows are "
+                    "128 +- 8 bits apart (one candidate per fixed point); real descriptors (KITTI stereo pairs, our extractor) 125 +- 33 bits, 1.6 % of "
+                    "the pairs within 50 bits -- there the matcher's time is candidate handling and registration, not scoring: real_descriptors holds "
+                    "the same modes on real rows, and one cloud pair at a time (the popcount kernels spread over several workgroups)"}
     except (SystemExit, RuntimeError, AssertionError) as exc:
         out["roofline_f4"] = {"error": str(exc)}
     return out
