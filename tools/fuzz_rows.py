@@ -61,6 +61,7 @@ def fuzz_bruteforce(cases, rng, ctx, oracle):
         ref, rflags = oracle.bruteforce_match(df, dm, max_dist, ratio)
         clouds = ops.BruteforceClouds(0, 1, nf, nm, candidate_capacity=nf * nm)
         clouds.upload(0, df, dm)
+        ctx.set_bruteforce_dense_phase((ops.BF_DENSE_MATRIX_WHEN_FULL, ops.BF_DENSE_POPCOUNT, ops.BF_DENSE_MATRIX)[c % 3])  # every kernel family
         ops.bruteforce_match_batch(ctx, ops.bruteforce_params(max_dist, ratio), clouds)
         ctx.synchronize()
         got, gflags = clouds.matches_of(0), int(clouds.status[0].item())
@@ -68,6 +69,30 @@ def fuzz_bruteforce(cases, rng, ctx, oracle):
         if not (hp.corr_equal(ref, got) and rflags == gflags):
             bad += 1
             print("BRUTEFORCE MISMATCH case %d nf %d nm %d protos %d dist %g ratio %g: %d vs %d" % (c, nf, nm, protos, max_dist, ratio, len(ref), len(got)))
+    ctx.set_bruteforce_dense_phase(ops.BF_DENSE_MATRIX_WHEN_FULL)
+    # full batches (more cloud pairs than half the CUs): the default takes the fused matrix-core shape
+    for c in range(max(1, cases // 20)):
+        B, fs, ms = 136, int(rng.choice([96, 700, 1200])), int(rng.choice([80, 640, 1100]))
+        protos, flips = int(rng.choice([3, 40, 5000])), int(rng.integers(0, 40))
+        max_dist, ratio = float(rng.choice([5.0, 20.0, 33.5, 50.0, 120.0])), float(rng.choice([0.5, 0.8, 0.95, 1.0, 1.5]))
+        clouds = ops.BruteforceClouds(0, B, fs, ms, candidate_capacity=min(fs * ms, 400000))
+        inputs, seed = [], int(rng.integers(1 << 30))
+        for b in range(B):
+            nf, nm = int(rng.integers(1, fs + 1)), int(rng.integers(1, ms + 1))
+            df = _tie_heavy(np.random.default_rng(seed + b), protos, nf, flips) if b % 17 < 3 else np.random.default_rng(seed + b).integers(0, 256, (nf, 32), dtype=np.uint8)
+            dm = _tie_heavy(np.random.default_rng(seed + b), protos, nm, flips) if b % 17 < 3 else df[np.random.default_rng(b).integers(0, nf, nm)].copy()
+            inputs.append((df, dm))
+            clouds.upload(b, df, dm)
+        ops.bruteforce_match_batch(ctx, ops.bruteforce_params(max_dist, ratio), clouds)
+        ctx.synchronize()
+        for b in [0, 1, 2, 17, 18, 19, 53, B - 1]:
+            ref, rflags = oracle.bruteforce_match(inputs[b][0], inputs[b][1], max_dist, ratio)
+            got, gflags = clouds.matches_of(b), int(clouds.status[b].item())
+            total += len(ref)
+            if not (hp.corr_equal(ref, got) and rflags == gflags):
+                bad += 1
+                print("BRUTEFORCE BATCH MISMATCH batch %d pair %d fs %d ms %d dist %g ratio %g: %d vs %d (flags %d %d)" % (
+                    c, b, fs, ms, max_dist, ratio, len(ref), len(got), rflags, gflags))
     return bad, total
 
 
