@@ -199,3 +199,44 @@ def test_full_batch_with_dense_candidates_and_two_row_passes(oracle, hip_ctx):
             ref, rflags = oracle.bruteforce_match(inputs[b][0], inputs[b][1], max_dist, ratio)
             assert hp.corr_equal(ref, clouds.matches_of(b)), (b, max_dist)
             assert int(clouds.status[b].item()) == rflags, (b, max_dist)
+
+
+def test_real_descriptors_of_kitti_stereo_pairs(oracle, hip_ctx):
+    # the descriptors our extractor finds in the reference's KITTI test images (left cloud = fixed, right cloud = moving): 1.6 % of the
+    # pairs are within 50 bits, 7 % within 75 -- nothing like uniform random rows.  140 cloud pairs (the seven stereo pairs replicated):
+    # the default takes the fused matrix-core shape; every distinct pair against the checker.
+    import os
+    import torch
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_kitti.npz"))
+    left = [im for im in z["city_left"]] + [im for im in z["highway_left"]]
+    right = [im for im in z["city_right"]] + [im for im in z["highway_right"]]
+    dev = torch.device("cuda", 0)
+    img = torch.from_numpy(np.stack(left + right)).to(dev)
+    n_img, stride = img.shape[0], 1024
+    kp = torch.zeros((n_img, stride, 2), dtype=torch.float32, device=dev)
+    desc = torch.zeros((n_img, stride, 32), dtype=torch.uint8, device=dev)
+    n = torch.zeros((n_img,), dtype=torch.int32, device=dev)
+    st = torch.zeros((n_img,), dtype=torch.int32, device=dev)
+    ectx = ops.Context(0)
+    ectx.use_torch_stream()
+    ops.extract_features_batch(ectx, ops.extractor_params(), img, kp, desc, n, st)
+    torch.cuda.synchronize()
+    ectx.close()
+    pairs, B = len(left), 140
+    sel = torch.arange(B, device=dev) % pairs
+    clouds = ops.BruteforceClouds(0, B, stride, stride, candidate_capacity=200000)
+    clouds.fixed_desc.copy_(desc[sel])
+    clouds.moving_desc.copy_(desc[sel + pairs])
+    clouds.n_fixed.copy_(n[sel])
+    clouds.n_moving.copy_(n[sel + pairs])
+    torch.cuda.synchronize()
+    hd, hn = desc.cpu().numpy(), n.cpu().numpy()
+    for max_dist, ratio in ((50.0, 0.9), (75.0, 0.8)):
+        ops.bruteforce_match_batch(hip_ctx, ops.bruteforce_params(max_dist, ratio), clouds)
+        hip_ctx.synchronize()
+        for b in list(range(pairs)) + [B - 1]:
+            k = b % pairs
+            ref, rflags = oracle.bruteforce_match(hd[k, : hn[k]], hd[k + pairs, : hn[k + pairs]], max_dist, ratio)
+            assert len(ref) > 50
+            assert hp.corr_equal(ref, clouds.matches_of(b)), (b, max_dist)
+            assert int(clouds.status[b].item()) == rflags, (b, max_dist)
