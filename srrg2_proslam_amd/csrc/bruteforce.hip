@@ -888,14 +888,14 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
 // shape, the N_f x N_m distances from v_mfma_i32_16x16x64_i8 as in bruteforce_dense_mfma_kernel (a wave owns 64 fixed rows, the
 // workgroup walks the moving cloud in 64-row chunks that waves 0-7 expand into LDS), fixed rows beyond 1024 in further passes.
 // What differs is what happens to a candidate.  Real descriptors put 1.6 % of the pairs below a threshold of 50 bits: every tile of
-// every tile row holds one, so nothing here is rare.  A lane that met the threshold in one of its 4 rows of a tile parks the tile's
-// four EXACT distances (acc + pop(b), packed to bytes by seven packed-math instructions) beside (column, row group, tile) in its
-// wave's LDS segment; a wave drains its own segment when a worst-case tile row (4 x 64 entries) might not fit: one slot range per 64
-// entries from the pair's LDS counter, the bitmaps / counts / histogram updated by LDS atomics.  No re-scoring from memory, no
-// barrier, no global atomic: the split kernel's flush spent 1.3 of its 1.7 ms per 1024 real cloud pairs on those.
-constexpr int kMxSeg        = 320;  // entries of a wave's segment (8 bytes each): drained when more than kMxSeg - 256 wait in it
-constexpr uint32_t kMxBytes = 2u * 4u * kBfmPlane + 2u * kBfmChunk * 4u + 2u * 16u * 4u + (uint32_t) (kBfThreads / 64) * kMxSeg * 8u;
-typedef unsigned short bf_us2 __attribute__((ext_vector_type(2)));
+// every tile row holds one, so nothing here is rare.  A lane that met the threshold in one of its 4 rows of a tile parks ONE 16-byte
+// entry in its wave's LDS segment: (column, row group, tile), pop(b) and the tile's four accumulators as 16-bit halves (two v_perm; the
+// distances acc + pop(b) are EXACT) -- six vector instructions per visited tile, where packing the distances to bytes took twelve.  A
+// wave drains its own segment when a worst-case pair of tiles (2 x 64 entries) might not fit: one slot range per 64 entries from the
+// pair's LDS counter, the bitmaps / counts / histogram updated by LDS atomics.  No re-scoring from memory, no barrier, no global
+// atomic: the split kernel's flush spent 1.3 of its 1.7 ms per 1024 real cloud pairs on those.
+constexpr int kMxSeg        = 192;  // entries of a wave's segment (16 bytes each): drained when more than kMxSeg - 128 wait in it
+constexpr uint32_t kMxBytes = 2u * 4u * kBfmPlane + 2u * kBfmChunk * 4u + 2u * 16u * 4u + (uint32_t) (kBfThreads / 64) * kMxSeg * 16u;
 
 __device__ __forceinline__ void bf_matrix_phase1(const BfArgs& a, unsigned char* scratch, const int nf, const int nm, const uint32_t* __restrict__ gdf,
                                                  const uint32_t* __restrict__ gdm, uint2* __restrict__ cand, uint32_t* cnt_f, uint32_t* cnt_m, uint32_t* hist,
@@ -904,7 +904,7 @@ __device__ __forceinline__ void bf_matrix_phase1(const BfArgs& a, unsigned char*
   int* popm           = reinterpret_cast<int*>(scratch + 2 * 4 * kBfmPlane);          // [2][64]
   uint32_t* lut_a     = reinterpret_cast<uint32_t*>(popm + 2 * kBfmChunk);            // [16]
   uint32_t* lut_b     = lut_a + 16;                                                   // [16]
-  uint2* segments     = reinterpret_cast<uint2*>(lut_b + 16);                         // [16 waves][kMxSeg]
+  uint4* segments     = reinterpret_cast<uint4*>(lut_b + 16);                         // [16 waves][kMxSeg]
   static_assert(kBfmPlane % 256 == 0, "planes must not shift the banks");
   auto lane_now = []() -> int {
     int l;
@@ -935,21 +935,24 @@ __device__ __forceinline__ void bf_matrix_phase1(const BfArgs& a, unsigned char*
     v.w = (int) lut[(bits16 >> 12) & 15u];
     return v;
   };
-  uint2* segment    = segments + wave_s * kMxSeg;
+  uint4* segment    = segments + wave_s * kMxSeg;
   uint32_t my_count = 0;  // entries in this wave's segment (wave-uniform: a scalar register)
   // this wave's parked entries -> the pair's candidate list and registration state (:52-69)
   auto drain = [&]() {
     for (uint32_t i0 = 0; i0 < my_count; i0 += 64u) {
       const int lane   = lane_now();
       const uint32_t i = i0 + (uint32_t) lane;
-      const uint2 e    = i < my_count ? segment[i] : make_uint2(0u, 0xffffffffu);  // (distances of 255: never below a threshold <= 255)
+      const uint4 e    = i < my_count ? segment[i] : make_uint4(0u, 1u << 20, 0u, 0u);  // (pop(b) of a row past the end: above every threshold)
       const int m      = (int) (e.x & 0xffffu);
       const int f0     = (int) (((e.x >> 16) & 0x7ffu) << 2) + 16 * (int) ((e.x >> 27) & 3u);
       int d[4];
+      d[0] = (int) (short) (e.z & 0xffffu) + (int) e.y;
+      d[1] = (int) (short) (e.z >> 16) + (int) e.y;
+      d[2] = (int) (short) (e.w & 0xffffu) + (int) e.y;
+      d[3] = (int) (short) (e.w >> 16) + (int) e.y;
       uint32_t mine = 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        d[r] = (int) ((e.y >> (8 * r)) & 0xffu);
         if (d[r] >= a.lim || f0 + r >= nf) {
           d[r] = -1;  // (a row past the end scores as an all-zero row)
         } else {
@@ -1055,9 +1058,6 @@ __device__ __forceinline__ void bf_matrix_phase1(const BfArgs& a, unsigned char*
           if (c * kBfmChunk + 16 * bt >= nm) {
             break;  // (uniform) tiles past the end of the moving cloud
           }
-          if (my_count > (uint32_t) (kMxSeg - 256)) {
-            drain();  // (wave-uniform: room for a worst-case tile row)
-          }
           const unsigned char* brow = bbuf + buf * (4 * kBfmPlane) + __mul24(lg, kBfmPlane) + __mul24(16 * bt + li, kBfmPlaneRow);
           const int pop_b           = popm[buf * kBfmChunk + 16 * bt + li];
           const int thr             = a.lim - pop_b;  // candidate  <=>  acc < thr
@@ -1087,25 +1087,17 @@ __device__ __forceinline__ void bf_matrix_phase1(const BfArgs& a, unsigned char*
           if ((mask_t[0] | mask_t[1] | mask_t[2] | mask_t[3]) != 0ull) {  // (wave-uniform)
             const int lane            = lane_now();
             const uint32_t base_entry = (uint32_t) (c * kBfmChunk + 16 * bt + (lane & 15)) | ((uint32_t) ((row0 + 4 * (lane >> 4)) >> 2) << 16);
-            bf_us2 pop2;
-            pop2.x = (unsigned short) pop_b;
-            pop2.y = (unsigned short) pop_b;
-            bf_us2 cap2;
-            cap2.x = 255;
-            cap2.y = 255;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+              if ((t & 1) == 0 && (mask_t[t] | mask_t[t + 1]) != 0ull && my_count > (uint32_t) (kMxSeg - 128)) {
+                drain();  // (wave-uniform: room for a worst-case pair of tiles)
+              }
               if (mask_t[t] != 0ull) {  // (wave-uniform)
                 if (any_t[t]) {
-                  // the tile's four distances acc + pop(b) as bytes (a distance of 256 parks as 255: above every threshold this shape takes)
-                  const uint32_t p01 = __builtin_amdgcn_perm((uint32_t) acc[t].y, (uint32_t) acc[t].x, 0x05040100u);
-                  const uint32_t p23 = __builtin_amdgcn_perm((uint32_t) acc[t].w, (uint32_t) acc[t].z, 0x05040100u);
-                  bf_us2 d01 = __builtin_bit_cast(bf_us2, p01) + pop2, d23 = __builtin_bit_cast(bf_us2, p23) + pop2;
-                  d01 = __builtin_elementwise_min(d01, cap2);
-                  d23 = __builtin_elementwise_min(d23, cap2);
-                  const uint32_t packed = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, d23), __builtin_bit_cast(uint32_t, d01), 0x06040200u);
-                  const uint32_t rank   = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask_t[t] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask_t[t], 0u));
-                  segment[my_count + rank] = make_uint2(base_entry | ((uint32_t) t << 27), packed);
+                  const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask_t[t] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask_t[t], 0u));
+                  segment[my_count + rank] = make_uint4(base_entry | ((uint32_t) t << 27), (uint32_t) pop_b,
+                                                        __builtin_amdgcn_perm((uint32_t) acc[t].y, (uint32_t) acc[t].x, 0x05040100u),
+                                                        __builtin_amdgcn_perm((uint32_t) acc[t].w, (uint32_t) acc[t].z, 0x05040100u));
                 }
                 my_count += (uint32_t) __popcll(mask_t[t]);
               }
@@ -1185,9 +1177,9 @@ int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* param
   const bool fused_regime  = !(batch->batch * 2 <= cus && batch->moving_stride >= 256);  // (else: few pairs, each spread over several workgroups)
   const bool matrix_forced = ctx->bf_mfma == PRS_BF_DENSE_MATRIX, matrix_when_full = ctx->bf_mfma == PRS_BF_DENSE_MATRIX_WHEN_FULL;
   // the fused shape with its dense phase on the matrix cores (bruteforce_kernel<1, kBfFused, true>): the registration state AND the
-  // phase's scratch must fit the LDS, and a parked distance is a byte
+  // phase's scratch must fit the LDS
   const bool fused_matrix = (matrix_forced || (matrix_when_full && batch->batch * 2 > cus && batch->fixed_stride >= 256 && batch->moving_stride >= 64)) &&
-                            fused_regime && lim <= 255 && bm_fits && ((off + bm_bytes + 255u) & ~(uint64_t) 255u) + kMxBytes <= 160u * 1024u;
+                            fused_regime && bm_fits && ((off + bm_bytes + 255u) & ~(uint64_t) 255u) + kMxBytes <= 160u * 1024u;
   // (the split matrix-core kernel, bruteforce_dense_mfma_kernel + the registration launch: only when forced and the fused shape is
   //  not taken -- it is the fastest on uniform random rows and the slowest on real ones, see the header)
   const bool mfma = !fused_matrix && matrix_forced;
