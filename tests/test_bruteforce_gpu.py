@@ -240,3 +240,30 @@ def test_real_descriptors_of_kitti_stereo_pairs(oracle, hip_ctx):
             assert len(ref) > 50
             assert hp.corr_equal(ref, clouds.matches_of(b)), (b, max_dist)
             assert int(clouds.status[b].item()) == rflags, (b, max_dist)
+
+
+def test_capacity_overflow_is_reported_per_cloud_pair(oracle, hip_ctx):
+    # a cloud pair with more candidates than candidate_capacity reports PRS_ERR_CAPACITY and no matches; its neighbours in the batch
+    # are unaffected (full batch: the default runs the fused matrix-core shape, whose drains stop storing at the capacity)
+    rng = np.random.default_rng(5)
+    B, n = 140, 200
+    clouds = ops.BruteforceClouds(0, B, n, n, candidate_capacity=1000)
+    inputs = []
+    for b in range(B):
+        if b % 10 == 3:
+            df = np.tile(rng.integers(0, 256, (1, 32), dtype=np.uint8), (n, 1))  # all rows equal: n^2 candidates at distance 0
+            dm = df.copy()
+        else:
+            df = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            dm = df[rng.permutation(n)].copy()
+        inputs.append((df, dm))
+        clouds.upload(b, df, dm)
+    ops.bruteforce_match_batch(hip_ctx, ops.bruteforce_params(50.0, 0.9), clouds)
+    hip_ctx.synchronize()
+    status = clouds.status.cpu().numpy()
+    for b in range(B):
+        if b % 10 == 3:
+            assert status[b] == -2 and int(clouds.n_matches[b].item()) == 0, (b, status[b])  # PRS_ERR_CAPACITY
+        elif b % 7 == 0:
+            ref, rflags = oracle.bruteforce_match(inputs[b][0], inputs[b][1], 50.0, 0.9)
+            assert hp.corr_equal(ref, clouds.matches_of(b)) and status[b] == rflags, b
