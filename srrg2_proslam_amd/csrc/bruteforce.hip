@@ -9,13 +9,15 @@
 // of its moving index.  Registrations only ever happen between pools, so the sequential loop is a
 // level-synchronous process over the distinct distances 0, 1, 2, ... -- which is how it runs here:
 //
-//   phase 1 (dense, VALU bound): one lane per fixed descriptor (rows in registers), the moving
-//            rows arrive through scalar loads (uniform address), 2 VALU per 32-bit word; the rare
-//            candidates are appended to a per-workgroup list, and the per-index distance bitmaps
-//            and candidate counts Lowe's check needs are updated;
+//   phase 1 (dense): all pairs scored, the candidates appended to the pair's list, the per-index distance bitmaps and candidate
+//            counts Lowe's check needs updated.  Popcount kernels: one lane per fixed descriptor (rows in registers), the moving
+//            rows through scalar loads (uniform address), 2 VALU per 32-bit word, candidates recorded branch-free and drained
+//            every 32 rows.  Matrix cores (bf_matrix_phase1, the default for batches that fill the chip; and the split
+//            bruteforce_dense_mfma_kernel): v_mfma_i32_16x16x64_i8 on 0 / 1 x +1 / -1 bytes, exact.  Real descriptors put 1.6 % of
+//            all pairs below a threshold of 50 bits (uniform random rows: one per point): candidates are NOT rare;
 //   phase 2: Lowe flags per candidate (next larger distance = first set bit above d in the
-//            bitmap), counting sort of the candidates by distance level;
-//   phase 3: the levels in ascending order: pool membership, uniqueness counts, registration;
+//            bitmap), counting sort of the candidates by distance level (bitmaps and level lists in LDS when they fit);
+//   phase 3: the levels in ascending order: pool membership, uniqueness counts, registration (two barriers per level);
 //   phase 4: emit ordered by (distance, fixed index) -- the canonical order this build defines for the
 //            reference's unstable std::sort by response only (:94-97).
 #include <stdlib.h>
@@ -508,19 +510,20 @@ __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) 
   }
 }
 
-// ---- round 6: the dense phase on the matrix cores --------------------------------------------------------------------
+// ---- round 6: the dense phase on the matrix cores, split shape (forced mode PRS_BF_DENSE_MATRIX below a full batch) ---------
 // hamming(a, b) = pop(a) + pop(b) - 2 a.b.  With the fixed rows as 0 / 1 bytes and the moving rows as +1 / -1 bytes (b' = 1 - 2 b),
 //     sum_k a_k b'_k = pop(a) - 2 a.b,     so     hamming(a, b) = (A B'^T)[a][b] + pop(b):
 // a 16 x 16 tile of distances is four v_mfma_i32_16x16x64_i8 (K = 256 bits) and "candidate" (d < lim, bruteforce_impl.cpp:52) is
 // acc < lim - pop(b), one compare per accumulator against a per-lane threshold (a lane's four accumulators share their column).
 // Integer products and sums: exact, the candidate set is the one the popcount kernel finds.
-// Shape: 1024 threads = 16 waves per workgroup, a wave owns 64 fixed rows (4 A tiles, expanded once into 64 registers), the workgroup
+// Shape: 512 threads = 8 waves per workgroup, a wave owns 64 fixed rows (4 A tiles, expanded once into 64 registers), the workgroup
 // walks the moving cloud in chunks of 64 rows that all waves expand into LDS (double-buffered, one barrier per chunk: 64 MFMAs per
 // wave).  The operand layout inside K is free as long as A and B agree (a dot product does not care about the order of its terms):
 // lane (i = l & 15, g = l >> 4) holds, for K block kb, the 16 bits [64 kb + 16 g, +16) of row i as 16 bytes; the result layout is the
 // one tools/probes/mfma_i8_probe.hip pins (register r of lane l = row 4 (l >> 4) + r, column l & 15).
-// Candidates (one per fixed point, give or take) go through the same global counters / bitmaps / list as the split popcount shape
-// (MODE kBfDense); bruteforce_kernel<.., kBfRegister> then registers them pair by pair.
+// Candidates go through the same global counters / bitmaps / list as the split popcount shape (MODE kBfDense);
+// bruteforce_kernel<.., kBfRegister> then registers them pair by pair.  Built for one candidate per fixed point (uniform random
+// rows): the entries it parks are re-scored from memory at a flush behind barriers, which real descriptors make the bulk of its time.
 typedef int bf_v4i __attribute__((ext_vector_type(4)));
 constexpr int kBfmThreads  = 512;                                  // 8 waves; two workgroups per CU: one scores while the other flushes / waits at its barrier
 constexpr int kBfmRowsWave = 64;                                   // fixed rows per wave (4 A tiles)
