@@ -86,10 +86,11 @@ PRS_API int prs_context_get_align_timing(prs_context* ctx, double* search_ms, do
 PRS_API int prs_context_get_align_round_timing(prs_context* ctx, double* search_ms16, double* gn_ms16, int64_t* batches);
 /* Dense phase of the brute-force matcher (prs_bruteforce_match_batch): which kernels score the N_f x N_m pairs.  Results are
  * identical; only the cost differs.
- *   PRS_BF_DENSE_MATRIX_WHEN_FULL (the default): a batch of more cloud pairs than half the CUs runs one workgroup per pair with the
- *     distances from v_mfma_i32_16x16x64_i8 (exact: integer products) and the registration state in LDS; fewer pairs run the popcount
- *     kernels, which spread a pair over several workgroups.  On 1024 real cloud pairs (KITTI stereo pairs, ~750 points a side, 1.6 % of
- *     the pairs within 50 bits) 1.6x the popcount kernels, on uniform random rows 2.2x (profiles/r06/README.md).
+ *   PRS_BF_DENSE_MATRIX_WHEN_FULL (the default): a batch of 32 or more cloud pairs (of at least 256 x 64 points) runs one workgroup
+ *     per pair with the distances from v_mfma_i32_16x16x64_i8 (exact: integer products) and the registration state in LDS; fewer pairs
+ *     run the popcount kernels, which spread a pair over several workgroups.  On real cloud pairs (KITTI stereo pairs, ~750 points a
+ *     side, 1.6 % of the pairs within 50 bits) 1.8x the popcount kernels at 1024 pairs and 2x at 128, on 1024 pairs of uniform random
+ *     rows 2.7x; 32 - 63 pairs of uniform random rows are the one shape it loses on (0.23 against 0.14 ms) (profiles/r06/README.md).
  *   PRS_BF_DENSE_POPCOUNT: v_xor / v_bcnt on the vector units for every batch size.
  *   PRS_BF_DENSE_MATRIX: always the matrix cores (the fused shape where it applies, else a split matrix-core kernel + a registration
  *     launch that re-scores what it selects: fast on uniform random rows, slow on real ones; tests, A-B runs).

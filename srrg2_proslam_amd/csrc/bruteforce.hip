@@ -1159,8 +1159,8 @@ int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* param
       cus = prop.multiProcessorCount;
     }
   }
-  // Which kernels score the pairs (prs_context_set_bruteforce_dense_phase).  PRS_BF_DENSE_MATRIX_WHEN_FULL, the default: a batch that
-  // fills the chip (more cloud pairs than half the CUs) takes the fused shape with its dense phase on the matrix cores
+  // Which kernels score the pairs (prs_context_set_bruteforce_dense_phase).  PRS_BF_DENSE_MATRIX_WHEN_FULL, the default: a batch of
+  // 32 or more cloud pairs takes the fused shape with its dense phase on the matrix cores
   // (bruteforce_kernel<1, kBfFused, true>: 1024 real cloud pairs 0.99 -> 0.62 ms, 1024 pairs of 2000 uniform random rows 2.75 -> 1.23 ms);
   // a handful of pairs keeps the popcount kernels, whose split shape spreads a pair over more workgroups (one real pair of 1350 points:
   // 0.11 ms against 0.23 ms).
@@ -1181,8 +1181,11 @@ int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* param
   const bool matrix_forced = ctx->bf_mfma == PRS_BF_DENSE_MATRIX, matrix_when_full = ctx->bf_mfma == PRS_BF_DENSE_MATRIX_WHEN_FULL;
   // the fused shape with its dense phase on the matrix cores (bruteforce_kernel<1, kBfFused, true>): the registration state AND the
   // phase's scratch must fit the LDS
-  const bool fused_matrix = (matrix_forced || (matrix_when_full && batch->batch * 2 > cus && batch->fixed_stride >= 256 && batch->moving_stride >= 64)) &&
-                            fused_regime && bm_fits && ((off + bm_bytes + 255u) & ~(uint64_t) 255u) + kMxBytes <= 160u * 1024u;
+  // (by default from 32 cloud pairs on: one round of fused workgroups -- 0.14 ms for <= 256 real pairs of ~750 points -- beats the
+  //  popcount kernels' split shape from ~27 pairs of that size on, earlier for larger clouds: 128 pairs 0.27 ms, 136 pairs 0.14 ms
+  //  when the switch sat at half the CUs)
+  const bool fused_matrix = ((matrix_forced && fused_regime) || (matrix_when_full && batch->batch >= 32 && batch->fixed_stride >= 256 && batch->moving_stride >= 64)) &&
+                            bm_fits && ((off + bm_bytes + 255u) & ~(uint64_t) 255u) + kMxBytes <= 160u * 1024u;
   // (the split matrix-core kernel, bruteforce_dense_mfma_kernel + the registration launch: only when forced and the fused shape is
   //  not taken -- it is the fastest on uniform random rows and the slowest on real ones, see the header)
   const bool mfma = !fused_matrix && matrix_forced;
@@ -1191,7 +1194,7 @@ int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* param
   a.chunks = 1;
   if (mfma) {
     a.chunks = 2;  // (any value > 1: per-pair scratch rows + global accumulators, as in the split popcount shape)
-  } else if (batch->batch * 2 <= cus && batch->moving_stride >= 256) {
+  } else if (!fused_matrix && batch->batch * 2 <= cus && batch->moving_stride >= 256) {
     int c = cus / batch->batch;
     const int most = batch->moving_stride / 32;
     a.chunks = c < most ? c : most;

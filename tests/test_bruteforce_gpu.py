@@ -267,3 +267,22 @@ def test_capacity_overflow_is_reported_per_cloud_pair(oracle, hip_ctx):
         elif b % 7 == 0:
             ref, rflags = oracle.bruteforce_match(inputs[b][0], inputs[b][1], 50.0, 0.9)
             assert hp.corr_equal(ref, clouds.matches_of(b)) and status[b] == rflags, b
+
+
+def test_forty_cloud_pairs(oracle, hip_ctx):
+    # 32 or more cloud pairs of at least 256 x 64 points: the default switches to the fused matrix-core shape (fewer workgroups than CUs)
+    rng = np.random.default_rng(41)
+    B, fs, ms = 40, 420, 380
+    clouds = ops.BruteforceClouds(0, B, fs, ms, candidate_capacity=fs * ms)
+    inputs = []
+    for b in range(B):
+        nf, nm = int(rng.integers(1, fs + 1)), int(rng.integers(1, ms + 1))
+        df = _tie_heavy(rng, 30, nf, 30) if b % 2 else rng.integers(0, 256, (nf, 32), dtype=np.uint8)
+        dm = _tie_heavy(np.random.default_rng(41), 30, nm, 30) if b % 2 else df[rng.integers(0, nf, nm)].copy()
+        inputs.append((df, dm))
+        clouds.upload(b, df, dm)
+    ops.bruteforce_match_batch(hip_ctx, ops.bruteforce_params(45.0, 0.85), clouds)
+    hip_ctx.synchronize()
+    for b in range(0, B, 3):
+        ref, rflags = oracle.bruteforce_match(inputs[b][0], inputs[b][1], 45.0, 0.85)
+        assert hp.corr_equal(ref, clouds.matches_of(b)) and int(clouds.status[b].item()) == rflags, b
