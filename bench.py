@@ -507,6 +507,7 @@ def f_rows_leg():
         real["speedup_over_popcount"] = [real["popcount"][i]["ms_per_launch"] / real["default"][i]["ms_per_launch"] for i in range(2)]
         real["one_cloud_pair"] = [bench_bruteforce.run_real(1, 50.0, quiet=True, target=1000, capacity=65536),
                                   bench_bruteforce.run_real(1, 50.0, quiet=True, target=2000, capacity=262144)]
+        real["cpu_baseline"] = bench_bruteforce.cpu_port_real()
         tops = b["pairs_per_s"] * 512.0 / 1e12
         out["roofline_f4"] = {
             "kernel": "bruteforce dense phase + registration (CorrespondenceFinderDescriptorBasedBruteforce::compute: all N_f x N_m Hamming distances, pools by "

@@ -112,7 +112,55 @@ def run_real(B, max_dist=50.0, iters=5, quiet=False, target=1000, capacity=0, de
             "pairs_per_s": pairs / (ms * 1e-3)}
 
 
+def cpu_port_real(max_dist=50.0, target=1000, repeats=3):
+    """the CPU checker (oracle/, a single-threaded restatement of the reference's compute()) timed on the seven real stereo pairs'
+    descriptors, and the device's matches for the same pairs compared with its output (bench.py's cpu_baseline of the f4 row)"""
+    import time
+    from oracle import binding as ob
+    from tests import helpers as hp
+    z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ref_kitti.npz"))
+    left = [im for im in z["city_left"]] + [im for im in z["highway_left"]]
+    right = [im for im in z["city_right"]] + [im for im in z["highway_right"]]
+    dev = torch.device("cuda", 0)
+    ctx = ops.Context(0)
+    ctx.use_torch_stream()
+    img = torch.from_numpy(np.stack(left + right)).to(dev)
+    n_img, stride = img.shape[0], 1024 if target <= 1000 else 2048
+    kp = torch.zeros((n_img, stride, 2), dtype=torch.float32, device=dev)
+    desc = torch.zeros((n_img, stride, 32), dtype=torch.uint8, device=dev)
+    n = torch.zeros((n_img,), dtype=torch.int32, device=dev)
+    st = torch.zeros((n_img,), dtype=torch.int32, device=dev)
+    ops.extract_features_batch(ctx, ops.extractor_params(target=target, selection_order=ops.SELECT_LIBSTDCXX), img, kp, desc, n, st)
+    torch.cuda.synchronize()
+    pairs_n = len(left)
+    clouds = ops.BruteforceClouds(0, pairs_n, stride, stride, candidate_capacity=stride * 64)
+    clouds.fixed_desc.copy_(desc[:pairs_n])
+    clouds.moving_desc.copy_(desc[pairs_n:])
+    clouds.n_fixed.copy_(n[:pairs_n])
+    clouds.n_moving.copy_(n[pairs_n:])
+    ops.bruteforce_match_batch(ctx, ops.bruteforce_params(max_dist, 0.9), clouds)
+    ctx.synchronize()
+    hd, hn = desc.cpu().numpy(), n.cpu().numpy()
+    equal, scored, t_best = True, 0.0, None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        refs = [ob.bruteforce_match(hd[k, : hn[k]], hd[k + pairs_n, : hn[k + pairs_n]], max_dist, 0.9) for k in range(pairs_n)]
+        dt = time.perf_counter() - t0
+        t_best = dt if t_best is None or dt < t_best else t_best
+    for k in range(pairs_n):
+        scored += float(hn[k]) * float(hn[k + pairs_n])
+        equal = equal and hp.corr_equal(refs[k][0], clouds.matches_of(k)) and refs[k][1] == int(clouds.status[k].item())
+    ctx.close()
+    return {"value": scored / t_best, "unit": "descriptor pairs/s", "cores": 1, "kind": "port",
+            "sample": "the seven real stereo pairs (%.0f x %.0f points on average), best of %d runs: %.1f ms per cloud pair" % (
+                float(hn[:pairs_n].mean()), float(hn[pairs_n:].mean()), repeats, 1e3 * t_best / pairs_n),
+            "ms_per_cloud_pair": 1e3 * t_best / pairs_n, "device_matches_equal_checker": bool(equal)}
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "cpu":
+        print(cpu_port_real())
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "real":
         run_real(int(sys.argv[2]) if len(sys.argv) > 2 else 1024, float(sys.argv[3]) if len(sys.argv) > 3 else 50.0,
                  target=int(sys.argv[4]) if len(sys.argv) > 4 else 1000, capacity=int(sys.argv[5]) if len(sys.argv) > 5 else 0)
