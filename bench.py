@@ -440,6 +440,109 @@ def small_config_leg(name, cfg, keypoints, moving, max_fixed, batch, device_inde
 I8_MFMA_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2 x the dense BF16 rate (~2.5 PF)
 
 
+def _safe_cpu(fn):
+    """a row's CPU baseline (the checker in oracle/, timed on this box's host: a reported figure, never the product path); a failure
+    to produce it must not take the row's GPU figures with it"""
+    try:
+        return fn()
+    except Exception as exc:  # noqa: BLE001
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
+
+
+def _cpu_port_merge(NM=704, NS=2000, history=6, repeats=3):
+    """the CPU checker's MergerProjective_::compute + pose-based smoother on one map of the f1 shape (tools/bench_merge.py: NS landmarks
+    with `history` earlier measurements seen from the identity pose, a frame of NM measurements that re-observe them)"""
+    from oracle import binding as ob
+    from oracle import binding_mapping as om
+    from srrg2_proslam_amd import configs
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tests.test_oracle_mapping import merger_params as oracle_merger_params
+    ob.lib()
+    cfg = configs.get("kitti")
+    cam = cfg["camera"]
+    K = (cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    est = om.estimator_params(om.EST_SMOOTHER, 4, K, baseline_px=(cam["fx"] * cam["baseline_m"], 0.0), max_dist2=100.0, min_cov=0.01, max_cov_norm2=0.25,
+                              max_iterations=100, chi2_delta=1e-6, max_reprojection2=100.0, min_measurements=3)
+    p = oracle_merger_params(cfg, om.MERGER_STEREO_TRIANGULATION, est, enable_binning=1, row_bins=20, col_bins=60, max_appearance=100.0, target_merges=10 ** 6)
+    rng = np.random.default_rng(3)
+    z = (rng.random(NS) * 40 + 6).astype(np.float32)
+    x = ((rng.random(NS) - 0.5) * z).astype(np.float32)
+    y = ((rng.random(NS) - 0.5) * 0.3 * z).astype(np.float32)
+    uL, vL = cam["fx"] * x / z + cam["cx"], cam["fy"] * y / z + cam["cy"]
+    uR = uL - cam["fx"] * cam["baseline_m"] / z
+    base = om.Map(NS + NM, 8)
+    base.n_points = NS
+    base.coords[:NS, 0], base.coords[:NS, 1], base.coords[:NS, 2] = x, y, z
+    base.state[:NS] = base.coords[:NS]
+    base.covariance[:NS] = np.eye(3, dtype=np.float32).reshape(9)
+    for h in range(history):
+        base.meas["point_in_image"][:NS, h, 0], base.meas["point_in_image"][:NS, h, 1], base.meas["point_in_image"][:NS, h, 2] = uL, vL, uR
+        base.meas["point_in_camera"][:NS, h, 0], base.meas["point_in_camera"][:NS, h, 1], base.meas["point_in_camera"][:NS, h, 2] = x, y, z
+    base.n_meas[:NS] = history
+    base.n_opt[:NS] = history
+    poses = om.pose_table(16)
+    for f in range(16):
+        om.set_pose(poses, f, np.eye(4, dtype=np.float32))
+    n_c = min(NM, NS)
+    meas = np.stack([uL[:n_c], vL[:n_c], uR[:n_c], vL[:n_c]], axis=1).astype(np.float32)
+    desc = np.zeros((n_c, 32), np.uint8)
+    corr = np.zeros(n_c, dtype=ob.CORR_DTYPE)
+    corr["fixed_idx"], corr["moving_idx"], corr["response"] = np.arange(n_c), np.arange(n_c), 10.0
+    I4 = np.eye(4, dtype=np.float32)
+    best, merged = None, 0
+    for _ in range(repeats):
+        m = base.copy()
+        t0 = time.perf_counter()
+        rc, res = om.merge(p, I4, I4, poses, 1, m, meas, desc, corr)
+        dt = time.perf_counter() - t0
+        if rc < 0:
+            raise RuntimeError("orc_merge error %d" % rc)
+        best, merged = (dt if best is None or dt < best else best), int(res.n_merged)
+    return {"value": 1.0 / best, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "one frame of %d measurements into a %d-point map (%d landmarks merged, %d earlier measurements each), best of %d runs: %.2f ms" % (
+                NM, NS, merged, history, repeats, 1e3 * best)}
+
+
+def _cpu_port_clip(n=16000, repeats=5):
+    """the CPU checker's SceneClipperProjective3D::compute on one local map of the f2 shape (points in a box around the frustum)"""
+    from oracle import binding as ob
+    from srrg2_proslam_amd import configs
+    cam = configs.get("kitti")["camera"]
+    proj = ob.Projector(cam["fx"], cam["fy"], cam["cx"], cam["cy"], int(cam["cols"]), int(cam["rows"]), 0.1, 1000.0)
+    rng = np.random.default_rng(1)
+    xyzw = rng.random((n, 4), dtype=np.float32)
+    xyzw[:, 0] = (xyzw[:, 0] - 0.5) * 60
+    xyzw[:, 1] = (xyzw[:, 1] - 0.5) * 16
+    xyzw[:, 2] = xyzw[:, 2] * 50 + 2
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    I4 = np.eye(4, dtype=np.float32)
+    best = None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        kept = ob.scene_clip(proj, I4, I4, xyzw, desc)[0]
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    return {"value": 1.0 / best, "unit": "local maps/s", "cores": 1, "kind": "port",
+            "sample": "one local map of %d points with descriptors (%d kept), best of %d runs: %.3f ms" % (n, len(kept), repeats, 1e3 * best)}
+
+
+def _cpu_port_features(repeats=3):
+    """the CPU checker's extractor (FAST-9 + NMS, 3 x 3 binned selection in libstdc++'s order, ORB-256) on the reference's real KITTI images"""
+    from oracle import binding_features as of
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ref_kitti.npz"))
+    images = [im for im in z["city_left"]][:4]
+    p = of.extractor_params(selection_order=of.SELECT_LIBSTDCXX)
+    best = None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        n = [len(of.extract_features(p, im)[0]) for im in images]
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    return {"value": len(images) / best, "unit": "images/s", "cores": 1, "kind": "port",
+            "sample": "%d of the reference's KITTI images (1241 x 376, %.0f features each), best of %d runs: %.1f ms per image" % (
+                len(images), float(np.mean(n)), repeats, 1e3 * best / len(images))}
+
+
 def f_rows_leg():
     """f1 merger + landmark estimators, f2 scene clipper, f3 feature extraction, f4 brute-force matcher: one launch shape each (the
     shapes of tools/bench_{merge,clip,features,bruteforce}.py), inputs resident in HBM, time = HIP events around the operator's
@@ -465,7 +568,7 @@ def f_rows_leg():
                       "measurements into a 2000-point map per launch and map)",
             "ms_per_launch": rows[0]["ms_per_launch"], "frames_per_s": rows[0]["frames_per_s"], "algorithmic_bytes_per_launch": rows[0]["algorithmic_bytes_per_launch"],
             "algorithmic_bytes": "48 B per measurement + 12 B per correspondence + 2 x (112 B + 28 B per kept measurement) per merged landmark + 140 B per added one",
-            "estimators": rows,
+            "estimators": rows, "cpu_baseline": _safe_cpu(_cpu_port_merge),
             "note": "not bandwidth-bound: the smoother runs up to 100 Gauss-Newton iterations per merged landmark on its measurement history "
                     "(one lane per landmark, serial), the EKF a 3 x 3 f64 update; frac prices the landmark rows a merge touches"})
     except (SystemExit, RuntimeError, AssertionError) as exc:
@@ -477,7 +580,7 @@ def f_rows_leg():
             "kernel": "scene_clip_kernel (SceneClipperProjective3D::compute: transform, pinhole projection, frustum test, ordered compaction with descriptors)",
             "ms_per_launch": c8["ms_per_launch"], "algorithmic_bytes_per_launch": c8["algorithmic_bytes_per_launch"],
             "algorithmic_bytes": "48 B per scene point read (xyzw + 256-bit row) + 52 B per kept point written (+ global index) + 64 B per scene",
-            "shapes": [c, c8],
+            "shapes": [c, c8], "cpu_baseline": _safe_cpu(_cpu_port_clip),
             "note": "2048 local maps of 16000 points per launch (the headline figure) and of 2000 points (a KITTI local map; launch-latency share larger)"})
     except (SystemExit, RuntimeError, AssertionError) as exc:
         out["roofline_f2"] = {"error": str(exc)}
@@ -488,7 +591,7 @@ def f_rows_leg():
                       "std::sort order, 7x7 Gaussian on v_mfma_i32_16x16x32_i8, ORB-256)",
             "ms_per_launch": f["ms_per_launch"], "images_per_s": f["images_per_s"], "algorithmic_bytes_per_launch": f["algorithmic_bytes_per_launch"],
             "algorithmic_bytes": "the 8-bit image once (1241 x 376) + 44 B per kept feature (keypoint, descriptor, counters)",
-            "detail": f,
+            "detail": f, "cpu_baseline": _safe_cpu(_cpu_port_features),
             "note": "bound by vector issue, not by HBM: the tile kernel retires one vector instruction per cycle and CU (profiles/r05/features_pmc.txt); "
                     "frac prices the pixels and the features only"})
     except (SystemExit, RuntimeError, AssertionError, OSError) as exc:
@@ -507,7 +610,7 @@ def f_rows_leg():
         real["speedup_over_popcount"] = [real["popcount"][i]["ms_per_launch"] / real["default"][i]["ms_per_launch"] for i in range(2)]
         real["one_cloud_pair"] = [bench_bruteforce.run_real(1, 50.0, quiet=True, target=1000, capacity=65536),
                                   bench_bruteforce.run_real(1, 50.0, quiet=True, target=2000, capacity=262144)]
-        real["cpu_baseline"] = bench_bruteforce.cpu_port_real()
+        real["cpu_baseline"] = _safe_cpu(bench_bruteforce.cpu_port_real)
         tops = b["pairs_per_s"] * 512.0 / 1e12
         out["roofline_f4"] = {
             "kernel": "bruteforce dense phase + registration (CorrespondenceFinderDescriptorBasedBruteforce::compute: all N_f x N_m Hamming distances, pools by "
