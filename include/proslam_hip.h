@@ -105,7 +105,8 @@ PRS_API int prs_version(void);
 /* The parameter structs below carry no size field and grow at their END between versions (round 5 added three int32 fields to
  * prs_aligner_params).  PRS_ABI_VERSION is what this header describes, prs_version() what the loaded library was built from; a
  * client checks that they agree once (prs_abi_check: also the sizes of the structs it will pass, as the client's compiler laid
- * them out) instead of finding out through a library that reads past a shorter struct (101 -> 102: step_norm_exit).  Callers memset() parameter structs before
+ * them out) instead of finding out through a library that reads past a shorter struct (101 -> 102: step_norm_exit at the end of
+ * prs_aligner_params; 102 also adds the entry points prs_abi_check and prs_context_set_bruteforce_dense_phase).  Callers memset() parameter structs before
  * filling them, so that fields they do not know select the shipped defaults (all zero). */
 #define PRS_ABI_VERSION 102
 PRS_API int prs_abi_check(int32_t header_version, uint64_t sizeof_stereo_params, uint64_t sizeof_pcf_params, uint64_t sizeof_aligner_params,
