@@ -86,12 +86,17 @@ __device__ __forceinline__ bool lowe_ok(const uint32_t* bm, int nw, uint32_t cou
 }
 
 // dense phase of the fused shape on the matrix cores (defined with the matrix-core kernels below)
+template <int THREADS, int CHUNK>
 __device__ __forceinline__ void bf_matrix_phase1(const BfArgs& a, unsigned char* scratch, int nf, int nm, const uint32_t* gdf, const uint32_t* gdm, uint2* cand,
                                                  uint32_t* cnt_f, uint32_t* cnt_m, uint32_t* hist, uint32_t* counter, uint32_t* lbm_f, uint32_t* lbm_m);
 
-template <int KPT, int MODE, bool MX = false>
-__global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) {
+// THREADS = 1024 (one workgroup per CU) everywhere but in the matrix-core fused shape for clouds that leave room for TWO 512-thread
+// workgroups per CU (each at most 80 KiB of LDS): one scores while the other walks its latency-bound registration phases.
+template <int KPT, int MODE, bool MX = false, int THREADS = kBfThreads>
+__global__ __launch_bounds__(THREADS, 4) void bruteforce_kernel(const BfArgs a) {
   static_assert(!MX || (MODE == kBfFused && KPT == 1), "the matrix-core dense phase belongs to the fused shape");
+  static_assert(THREADS == kBfThreads || MX, "the popcount dense phase owns one fixed row per thread of a 1024-thread workgroup");
+  constexpr int kBfThreads = THREADS, kBfWaves = THREADS / 64;  // (shadow the file-scope constants inside the kernel)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* cnt_f  = reinterpret_cast<uint32_t*>(smem + a.off_cnt_f);   // candidates per fixed; later pool counts
   uint32_t* cnt_m  = reinterpret_cast<uint32_t*>(smem + a.off_cnt_m);
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(kBfThreads) void bruteforce_kernel(const BfArgs a) 
 
     // ---- phase 1: all pairs (bruteforce_impl.cpp:32-79) ----------------------------------------
     if constexpr (MX) {
-      bf_matrix_phase1(a, smem + a.off_mx, nf, nm, gdf,
+      bf_matrix_phase1<THREADS, THREADS == 1024 ? 64 : 32>(a, smem + a.off_mx, nf, nm, gdf,
                        reinterpret_cast<const uint32_t*>(a.b.moving_desc + (size_t) frame * a.b.moving_stride * PRS_DESC_BYTES), cand, cnt_f, cnt_m, hist, &misc[0],
                        lbm_f, lbm_m);
     } else {
@@ -898,17 +903,22 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
 // pair's LDS counter, the bitmaps / counts / histogram updated by LDS atomics.  No re-scoring from memory, no barrier, no global
 // atomic: the split kernel's flush spent 1.3 of its 1.7 ms per 1024 real cloud pairs on those.
 constexpr int kMxSeg        = 192;  // entries of a wave's segment (16 bytes each): drained when more than kMxSeg - 128 wait in it
-constexpr uint32_t kMxBytes = 2u * 4u * kBfmPlane + 2u * kBfmChunk * 4u + 2u * 16u * 4u + (uint32_t) (kBfThreads / 64) * kMxSeg * 16u;
+constexpr uint32_t bf_mx_bytes(const int threads, const int chunk) {  // LDS scratch of bf_matrix_phase1<threads, chunk>
+  return 2u * 4u * (uint32_t) (chunk * kBfmPlaneRow) + 2u * (uint32_t) chunk * 4u + 2u * 16u * 4u + (uint32_t) (threads / 64) * kMxSeg * 16u;
+}
+constexpr uint32_t kMxBytes = bf_mx_bytes(kBfThreads, 64), kMxBytesDual = bf_mx_bytes(512, 32);
 
+template <int THREADS, int CHUNK>
 __device__ __forceinline__ void bf_matrix_phase1(const BfArgs& a, unsigned char* scratch, const int nf, const int nm, const uint32_t* __restrict__ gdf,
                                                  const uint32_t* __restrict__ gdm, uint2* __restrict__ cand, uint32_t* cnt_f, uint32_t* cnt_m, uint32_t* hist,
                                                  uint32_t* counter, uint32_t* lbm_f, uint32_t* lbm_m) {
-  unsigned char* bbuf = scratch;                                                      // [2][4 planes][64 rows x 80 B]
-  int* popm           = reinterpret_cast<int*>(scratch + 2 * 4 * kBfmPlane);          // [2][64]
-  uint32_t* lut_a     = reinterpret_cast<uint32_t*>(popm + 2 * kBfmChunk);            // [16]
+  constexpr int kPlane = CHUNK * kBfmPlaneRow;  // a plane of the chunk image (CHUNK rows at the 80-byte stride: a multiple of 256 B)
+  static_assert(kPlane % 256 == 0 && CHUNK % 16 == 0 && (CHUNK * 8) % 64 == 0 && CHUNK * 8 <= THREADS, "chunk shape");
+  unsigned char* bbuf = scratch;                                                      // [2][4 planes][CHUNK rows x 80 B]
+  int* popm           = reinterpret_cast<int*>(scratch + 2 * 4 * kPlane);             // [2][CHUNK]
+  uint32_t* lut_a     = reinterpret_cast<uint32_t*>(popm + 2 * CHUNK);                // [16]
   uint32_t* lut_b     = lut_a + 16;                                                   // [16]
-  uint4* segments     = reinterpret_cast<uint4*>(lut_b + 16);                         // [16 waves][kMxSeg]
-  static_assert(kBfmPlane % 256 == 0, "planes must not shift the banks");
+  uint4* segments     = reinterpret_cast<uint4*>(lut_b + 16);                         // [waves][kMxSeg]
   auto lane_now = []() -> int {
     int l;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
@@ -997,28 +1007,28 @@ __device__ __forceinline__ void bf_matrix_phase1(const BfArgs& a, unsigned char*
     }
     my_count = 0;
   };
-  const int n_chunks       = (nm + kBfmChunk - 1) / kBfmChunk;
+  const int n_chunks       = (nm + CHUNK - 1) / CHUNK;
   const uint32_t last_word = 32u * (uint32_t) nm - 4u;  // (byte offset of the cloud's last word: rows past the end read it and are masked)
   auto fetch = [&](const int c) -> uint32_t {           // waves 0-7: one 32-bit word of the chunk per thread
-    const uint32_t off = (uint32_t) c * (kBfmChunk * 32u) + 256u * (uint32_t) wave_s + 4u * (uint32_t) lane_now();
+    const uint32_t off = (uint32_t) c * (CHUNK * 32u) + 256u * (uint32_t) wave_s + 4u * (uint32_t) lane_now();
     return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(gdm) + (off < last_word ? off : last_word));
   };
   auto stage = [&](const int c, const int buf, const uint32_t w) {
     const int l = lane_now(), row = 8 * wave_s + (l >> 3), j = l & 7;
-    unsigned char* dst = bbuf + buf * (4 * kBfmPlane) + (2 * (j & 1)) * kBfmPlane + __mul24(row, kBfmPlaneRow) + 16 * (j >> 1);
+    unsigned char* dst = bbuf + buf * (4 * kPlane) + (2 * (j & 1)) * kPlane + __mul24(row, kBfmPlaneRow) + 16 * (j >> 1);
     *reinterpret_cast<bf_v4i*>(dst)             = expand16(lut_b, w & 0xffffu);
-    *reinterpret_cast<bf_v4i*>(dst + kBfmPlane) = expand16(lut_b, w >> 16);
+    *reinterpret_cast<bf_v4i*>(dst + kPlane) = expand16(lut_b, w >> 16);
     int pop = __popc(w);
     pop += __builtin_amdgcn_update_dpp(0, pop, 0xb1, 0xf, 0xf, true);   // quad_perm [1, 0, 3, 2]
     pop += __builtin_amdgcn_update_dpp(0, pop, 0x4e, 0xf, 0xf, true);   // quad_perm [2, 3, 0, 1]
     pop += __builtin_amdgcn_update_dpp(0, pop, 0x141, 0xf, 0xf, true);  // row_half_mirror
     if (j == 0) {
-      popm[buf * kBfmChunk + row] = c * kBfmChunk + row < nm ? pop : (1 << 20);  // a row past the end never meets the threshold
+      popm[buf * CHUNK + row] = c * CHUNK + row < nm ? pop : (1 << 20);  // a row past the end never meets the threshold
     }
   };
-  const bool stager = wave_s < kBfmChunk * 8 / 64;  // (512 words per chunk)
+  const bool stager = wave_s < CHUNK * 8 / 64;  // (512 words per chunk)
   const bf_v4i zero = {0, 0, 0, 0};
-  for (int pass_first = 0; pass_first < nf; pass_first += kBfThreads) {
+  for (int pass_first = 0; pass_first < nf; pass_first += THREADS) {
     const int row0       = pass_first + wave_s * kBfmRowsWave;
     const bool wave_live = row0 < nf;
     bf_v4i A[4][4];
@@ -1057,12 +1067,12 @@ __device__ __forceinline__ void bf_matrix_phase1(const BfArgs& a, unsigned char*
       if (wave_live) {
         const int l = lane_now(), li = l & 15, lg = l >> 4;
 #pragma unroll 1
-        for (int bt = 0; bt < kBfmChunk / 16; ++bt) {
-          if (c * kBfmChunk + 16 * bt >= nm) {
+        for (int bt = 0; bt < CHUNK / 16; ++bt) {
+          if (c * CHUNK + 16 * bt >= nm) {
             break;  // (uniform) tiles past the end of the moving cloud
           }
-          const unsigned char* brow = bbuf + buf * (4 * kBfmPlane) + __mul24(lg, kBfmPlane) + __mul24(16 * bt + li, kBfmPlaneRow);
-          const int pop_b           = popm[buf * kBfmChunk + 16 * bt + li];
+          const unsigned char* brow = bbuf + buf * (4 * kPlane) + __mul24(lg, kPlane) + __mul24(16 * bt + li, kBfmPlaneRow);
+          const int pop_b           = popm[buf * CHUNK + 16 * bt + li];
           const int thr             = a.lim - pop_b;  // candidate  <=>  acc < thr
           bf_v4i B[4];
 #pragma unroll
@@ -1089,7 +1099,7 @@ __device__ __forceinline__ void bf_matrix_phase1(const BfArgs& a, unsigned char*
           const unsigned long long mask_t[4] = {__ballot(any_t[0]), __ballot(any_t[1]), __ballot(any_t[2]), __ballot(any_t[3])};
           if ((mask_t[0] | mask_t[1] | mask_t[2] | mask_t[3]) != 0ull) {  // (wave-uniform)
             const int lane            = lane_now();
-            const uint32_t base_entry = (uint32_t) (c * kBfmChunk + 16 * bt + (lane & 15)) | ((uint32_t) ((row0 + 4 * (lane >> 4)) >> 2) << 16);
+            const uint32_t base_entry = (uint32_t) (c * CHUNK + 16 * bt + (lane & 15)) | ((uint32_t) ((row0 + 4 * (lane >> 4)) >> 2) << 16);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
               if ((t & 1) == 0 && (mask_t[t] | mask_t[t + 1]) != 0ull && my_count > (uint32_t) (kMxSeg - 128)) {
@@ -1189,7 +1199,16 @@ int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* param
   // (the split matrix-core kernel, bruteforce_dense_mfma_kernel + the registration launch: only when forced and the fused shape is
   //  not taken -- it is the fastest on uniform random rows and the slowest on real ones, see the header)
   const bool mfma = !fused_matrix && matrix_forced;
-  const int grid = mfma ? batch->batch : (batch->batch < cus ? batch->batch : cus);
+  // ... as TWO 512-thread workgroups per CU where the clouds leave room (each at most 80 KiB of LDS: strides up to ~1024 at a
+  // threshold below 64 bits): a pair's registration phases are chains of dependent LDS trips with a sixth of the threads busy, and the
+  // other workgroup's dense phase fills the CU meanwhile
+  const uint32_t lds_limit_dual = 80u * 1024u - 512u;
+  // (for more cloud pairs than CUs: 1024 real pairs 0.54 -> 0.47 ms, 384 pairs 0.27 -> 0.24; with one pair per CU the half-sized
+  //  workgroup only takes longer, 128 real pairs 0.14 -> 0.20 ms.  PRS_BF_TWO_WORKGROUPS=1 / 0 forces it where it fits / never: tests, A-B)
+  const char* two_wg = getenv("PRS_BF_TWO_WORKGROUPS");
+  const bool dual = fused_matrix && (two_wg ? two_wg[0] == '1' : batch->batch > cus) &&
+                    ((off + bm_bytes + 255u) & ~(uint64_t) 255u) + kMxBytesDual <= lds_limit_dual;
+  const int grid = mfma ? batch->batch : (dual ? (batch->batch < 2 * cus ? batch->batch : 2 * cus) : (batch->batch < cus ? batch->batch : cus));
   // few pairs: spread the dense phase of each pair over several workgroups (slices of >= 32 moving rows: one drain block)
   a.chunks = 1;
   if (mfma) {
@@ -1222,20 +1241,20 @@ int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* param
     off       = fused_matrix ? (off + 255u) & ~255u : off;
     a.off_lvl = off;
     a.off_mx  = off;
-    const uint32_t room = (160u * 1024u - off) / 4u;
+    const uint32_t room = ((dual ? lds_limit_dual : 160u * 1024u) - off) / 4u;
     a.lvl_cap = (int) (room < (uint32_t) a.cap ? room : (uint32_t) a.cap);
-    const uint32_t lists = 4u * (uint32_t) a.lvl_cap;
-    off += fused_matrix && kMxBytes > lists ? kMxBytes : lists;
+    const uint32_t lists = 4u * (uint32_t) a.lvl_cap, mx = dual ? kMxBytesDual : kMxBytes;
+    off += fused_matrix && mx > lists ? mx : lists;
   }
   const int kpt = (batch->fixed_stride + kBfThreads - 1) / kBfThreads;
   hipStream_t stream = ctx_stream(ctx);
   hipError_t e       = hipSuccess;
-  auto launch = [&](auto kernel, dim3 g) {
+  auto launch = [&](auto kernel, dim3 g, const int threads = kBfThreads) {
     if (off > 64u * 1024u) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) off);
     }
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(kernel, g, dim3(kBfThreads), off, stream, a);
+      hipLaunchKernelGGL(kernel, g, dim3(threads), off, stream, a);
       e = hipGetLastError();
     }
   };
@@ -1264,7 +1283,9 @@ int bruteforce_batch_launch(prs_context* ctx, const prs_bruteforce_params* param
       launch_mode(std::integral_constant<int, kBfRegister>{}, dim3(batch->batch));
     }
   } else {
-    if (fused_matrix) {
+    if (dual) {
+      launch(bruteforce_kernel<1, kBfFused, true, 512>, dim3(grid), 512);
+    } else if (fused_matrix) {
       launch(bruteforce_kernel<1, kBfFused, true>, dim3(grid));
     } else {
       launch_mode(std::integral_constant<int, kBfFused>{}, dim3(grid));

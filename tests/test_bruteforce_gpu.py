@@ -201,7 +201,11 @@ def test_full_batch_with_dense_candidates_and_two_row_passes(oracle, hip_ctx):
             assert int(clouds.status[b].item()) == rflags, (b, max_dist)
 
 
-def test_real_descriptors_of_kitti_stereo_pairs(oracle, hip_ctx):
+@pytest.mark.parametrize("two_workgroups", ["0", "1"])
+def test_real_descriptors_of_kitti_stereo_pairs(oracle, hip_ctx, monkeypatch, two_workgroups):
+    # (the fused matrix-core shape as one 1024-thread workgroup per CU and as two 512-thread ones -- what batches of two cloud pairs
+    #  per CU take when the clouds leave room for two in the LDS, as these do; forced either way here)
+    monkeypatch.setenv("PRS_BF_TWO_WORKGROUPS", two_workgroups)
     # the descriptors our extractor finds in the reference's KITTI test images (left cloud = fixed, right cloud = moving): 1.6 % of the
     # pairs are within 50 bits, 7 % within 75 -- nothing like uniform random rows.  140 cloud pairs (the seven stereo pairs replicated):
     # the default takes the fused matrix-core shape; every distinct pair against the checker.
@@ -269,7 +273,9 @@ def test_capacity_overflow_is_reported_per_cloud_pair(oracle, hip_ctx):
             assert hp.corr_equal(ref, clouds.matches_of(b)) and status[b] == rflags, b
 
 
-def test_forty_cloud_pairs(oracle, hip_ctx):
+@pytest.mark.parametrize("two_workgroups", ["0", "1"])
+def test_forty_cloud_pairs(oracle, hip_ctx, monkeypatch, two_workgroups):
+    monkeypatch.setenv("PRS_BF_TWO_WORKGROUPS", two_workgroups)
     # 32 or more cloud pairs of at least 256 x 64 points: the default switches to the fused matrix-core shape (fewer workgroups than CUs)
     rng = np.random.default_rng(41)
     B, fs, ms = 40, 420, 380
