@@ -892,9 +892,11 @@ __global__ __launch_bounds__(kBfmThreads, 4) void bruteforce_dense_mfma_kernel(c
 }
 
 // ---- the dense phase of the FUSED shape on the matrix cores ------------------------------------------------------------
-// bruteforce_kernel<1, kBfFused, true>: one 1024-thread workgroup per cloud pair, the registration state in LDS as in the popcount
-// shape, the N_f x N_m distances from v_mfma_i32_16x16x64_i8 as in bruteforce_dense_mfma_kernel (a wave owns 64 fixed rows, the
-// workgroup walks the moving cloud in 64-row chunks that waves 0-7 expand into LDS), fixed rows beyond 1024 in further passes.
+// bruteforce_kernel<1, kBfFused, true, THREADS>: one workgroup per cloud pair -- 1024 threads on 64-row chunks, or two workgroups of
+// 512 threads per CU on 32-row chunks where the clouds leave room for two in the LDS --, the registration state in LDS as in the
+// popcount shape, the N_f x N_m distances from v_mfma_i32_16x16x64_i8 as in bruteforce_dense_mfma_kernel (a wave owns 64 fixed rows,
+// the workgroup walks the moving cloud in chunks that its first CHUNK / 8 waves expand into LDS, one 32-bit word per thread), fixed
+// rows beyond THREADS in further passes.
 // What differs is what happens to a candidate.  Real descriptors put 1.6 % of the pairs below a threshold of 50 bits: every tile of
 // every tile row holds one, so nothing here is rare.  A lane that met the threshold in one of its 4 rows of a tile parks ONE 16-byte
 // entry in its wave's LDS segment: (column, row group, tile), pop(b) and the tile's four accumulators as 16-bit halves (two v_perm; the
